@@ -1,0 +1,174 @@
+/*
+ * scasml_hip.h -- C ABI of libscasml_hip.so, the MI355X (gfx950) hot path of SCaSML_GP.
+ *
+ * The reference (Francis-Fan-create/SCaSML_GP) is pure Python/JAX and has no FFI boundary;
+ * its boundary is the Python class surface.  This header is the
+ * C ABI the build puts UNDER that surface: every entry point names the reference routine
+ * it replaces.  Conventions:
+ *   - all pointers are DEVICE pointers unless the name ends in _h (host);
+ *   - row-major, float32 unless stated, time in the LAST column of a point row
+ *     (solvers/MLP.py:161-162);
+ *   - the caller owns every buffer; nothing is allocated, freed or synchronised inside;
+ *   - `stream` is a hipStream_t (NULL = default stream); calls are asynchronous on it;
+ *   - return 0 on success, <0 on error (message via scasml_last_error(), thread-local);
+ *     no entry point throws or aborts;
+ *   - re-entrant: no global mutable state besides the thread-local error string.
+ */
+#ifndef SCASML_HIP_H
+#define SCASML_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCASML_ABI_VERSION 1
+#define SCASML_MAX_LEVEL 4   /* Picard level n <= 4 (kernels are instantiated per level)      */
+#define SCASML_MAX_Q 6       /* quadrature nodes per rule <= 6 (rho <= 5, solvers/MLP.py:132)  */
+#define SCASML_MAX_DIM 255   /* spatial dimension d <= 255 (one 4-dim quad per lane)          */
+#define SCASML_GP_TILE 32     /* collocation points per MFMA tile; n_pad is a multiple of it    */
+
+enum { SCASML_ERR_ARG = -1, SCASML_ERR_UNSUPPORTED = -2, SCASML_ERR_HIP = -3 };
+
+/* equations/equations.py:232-417 `Grad_Dependent_Nonlinear`: f = sigma*u*sum(z),
+ * g = 1 - 1/(1+exp(t+sum x)), mu = -1/d - sigma^2/2, sigma = 0.25. */
+enum { SCASML_EQ_GRAD_DEPENDENT_NONLINEAR = 0 };
+
+typedef struct {
+    int32_t d;        /* spatial dimension (n_input - 1)                                    */
+    int32_t eq_id;    /* SCASML_EQ_*                                                        */
+    float T;          /* terminal time (equations.py:356)                                   */
+    float mu;         /* drift    (equations.py:263-276)                                    */
+    float sigma;      /* diffusion (equations.py:278-288)                                   */
+    float clip;       /* norm_estimation (MLP.py:273-274) or uncertainty (ScaSML.py:282-284)*/
+} scasml_problem;
+
+/* Philox4x32-10 stream: counter = (quad, site, root0 + local root, stream), key = seed. */
+typedef struct {
+    uint64_t seed;
+    uint32_t stream;  /* advanced by the host once per solver call (replaces MLP.py:220 key splitting) */
+    uint32_t root0;   /* global index of the first root in this call (root sharding)       */
+    int32_t rank;     /* Monte-Carlo sample sharding of the ROOT call: unit % world == rank */
+    int32_t world;    /* 1 = no sample sharding; >1 => outputs are un-clipped partial sums  */
+} scasml_rng;
+
+/* One (level n', sub-level l) term of the Picard sum: MLP.py:210-271 / MLP_full_history.py:131-177. */
+typedef struct {
+    int32_t q;                    /* quadrature nodes (1 for full history)                  */
+    int32_t mc;                   /* sample paths MC_f                                      */
+    int32_t sites_l;              /* RNG sites of one child subtree of level l              */
+    int32_t sites_lm1;            /* ... of level l-1 (0 when l == 0)                       */
+    float dfrac[SCASML_MAX_Q];    /* (c[k]-c[k-1])/T : time step k as a fraction of T-t     */
+    float cfrac[SCASML_MAX_Q];    /* c[k]/T : node time; also delta_t of the "-" term       */
+    float wfrac[SCASML_MAX_Q];    /* w[k]/T : quadrature weight                             */
+    float dplus[SCASML_MAX_Q];    /* delta_t fraction of the "+" term (MLP.py:249 stale value) */
+} scasml_term;
+
+/* Static schedule of the recursion, built on the host from the tables of
+ * MLP.approx_parameters (solvers/MLP.py:111-139).  Passed by value to the kernels. */
+typedef struct {
+    int32_t variant;                                   /* 0 = quadrature, 1 = full history  */
+    int32_t n;                                         /* level of the root call            */
+    int32_t mg[SCASML_MAX_LEVEL + 1];                  /* terminal samples of a level-n' call */
+    int32_t sites[SCASML_MAX_LEVEL + 1];               /* RNG sites of a level-n' subtree   */
+    scasml_term term[SCASML_MAX_LEVEL + 1][SCASML_MAX_LEVEL];   /* [n'][l], l < n'          */
+} scasml_plan;
+
+enum {
+    SCASML_MODE_MLP = 0,        /* MLP / MLP_full_history: no surrogate                      */
+    SCASML_MODE_GENERATE = 1,   /* ScaSML pass 1: emit every tree point for the GP          */
+    SCASML_MODE_ACCUMULATE = 2  /* ScaSML pass 2: Picard sums on the defect, GP values given */
+};
+
+int scasml_abi_version(void);
+const char *scasml_last_error(void);
+/* sizeof() of the ABI structs as compiled, for binding self-checks:
+ * 0 scasml_problem, 1 scasml_rng, 2 scasml_term, 3 scasml_plan, 4 scasml_gp_model. */
+size_t scasml_sizeof(int which);
+
+/* Rows of the point buffer / GP-value buffer per root: sites[n] + 1 (the root itself last). */
+int64_t scasml_points_per_root(const scasml_plan *plan_h);
+/* Padded row length (floats) of a point row: round_up(d + 1, 8). */
+int32_t scasml_point_stride(int32_t d);
+
+/*
+ * The Picard tree: replaces MLP.uz_solve (solvers/MLP.py:141-274), ScaSML.uz_solve
+ * (solvers/ScaSML.py:149-284) and the two *_full_history.uz_solve
+ * (solvers/MLP_full_history.py:64-180, solvers/ScaSML_full_history.py:75-199) -- on-device
+ * Philox normals, Euler-Maruyama stepping, the recursive quadrature, f and g
+ * (equations/equations.py:248-304), clipping.
+ *   x_t      : B x (d+1) evaluation points.
+ *   points   : MODE_GENERATE out: B x points_per_root x point_stride  (X, t, zero pad).
+ *   gp_vals  : MODE_ACCUMULATE in: B x points_per_root x 4 = (u_hat, div_x u_hat, eps_PDE, 0)
+ *              from scasml_gp_eval on `points`.
+ *   out_uz   : B x (1+d): (u, z) clipped [MLP, ACCUMULATE]; un-clipped partial sums if world > 1.
+ *   out_uhat : B: u_hat at the root [ACCUMULATE] (ScaSML.py:303), may be NULL.
+ */
+int scasml_picard_tree(const scasml_problem *prob_h, const scasml_plan *plan_h, int mode,
+                       const float *x_t, int64_t B, scasml_rng rng,
+                       float *points, const float *gp_vals,
+                       float *out_uz, float *out_uhat, void *stream);
+
+/* Clip all-reduced partial sums in place (world > 1): MLP.py:272-274 / ScaSML.py:281-284. */
+int scasml_clip(float *uz, int64_t count, float clip, void *stream);
+
+/* Raw RNG access for parity tests: normals of `site` for roots root0..root0+B-1 -> B x d. */
+int scasml_debug_normals(scasml_rng rng, uint32_t site, int32_t d, int64_t B, float *out, void *stream);
+
+/* ------------------------------------------------------------------ Gaussian process */
+
+/* Trained surrogate, device resident (models/GP.py:185-192, 590-600). */
+typedef struct {
+    int32_t d;
+    int32_t n_dom, n_bdy;        /* N_Omega, N_dOmega                                        */
+    int32_t n_pad;               /* (n_dom + n_bdy) rounded up to 32                         */
+    int32_t kp;                  /* point stride = round_up(d+1, 8)                          */
+    float a;                     /* 1/sigma_k^2, sigma_k = 0.25*sqrt(d) (models/GP.py:25)    */
+    float sigma_eq;              /* equation sigma (models/GP.py:748)                        */
+    const float *colloc;         /* n_pad x kp   collocation points, domain first, zero pad  */
+    const float *colloc_frag;    /* the same, in MFMA A-fragment order [tile][kp/8][64][4]   */
+    const float *coef;           /* 8 x n_pad    (|y|^2, a*sum y, a*t_y, c0, cL, ct, cS, 0)  */
+} scasml_gp_model;
+
+/* Build `coef` and the padded `colloc` from points and right_vector (models/GP.py:599-600):
+ * c0 = rv[u(X)] (domain and boundary rows), cL = rv[Lap], ct = rv[dt], cS = rv[div] (zero on
+ * boundary rows).  x_dom: n_dom x (d+1), x_bdy: n_bdy x (d+1), rv: 4*n_dom + n_bdy (float64). */
+int scasml_gp_pack(int32_t d, float a, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy,
+                   const double *rv, float *colloc_out, float *colloc_frag_out, float *coef_out, void *stream);
+
+/*
+ * Fused posterior evaluation: replaces GP.predict (models/GP.py:653-671), the spatial-sum of
+ * GP.compute_gradient (:673-687) and GP_Grad_Dependent_Nonlinear.compute_PDE_loss (:746-769)
+ * without materialising any (n_inf x M) feature matrix.  FP32 MFMA (v_mfma_f32_32x32x2_f32)
+ * for x.y, closed-form derivative features in the epilogue.
+ *   points : n_inf x kp rows (X, t, zero pad)
+ *   out4   : n_inf x 4 = (u_hat, div_x u_hat, eps_PDE, dt u_hat)
+ *   lap    : n_inf Laplacian of u_hat, may be NULL
+ */
+int scasml_gp_eval(const scasml_gp_model *gp_h, const float *points, int64_t n_inf,
+                   float *out4, float *lap, void *stream);
+
+/* Full gradient of the posterior mean, n_inf x (d+1), time last: GP.compute_gradient (:673-687). */
+int scasml_gp_gradient(const scasml_gp_model *gp_h, const float *points, int64_t n_inf,
+                       float *grad, void *stream);
+
+/* 25-block feature Gram K(phi,phi), M x M float64, M = 4*n_dom + n_bdy, block order
+ * [u(dom), u(bdy), Lap(dom), dt(dom), div(dom)]: GP.kernel_phi_phi (models/GP.py:182-258). */
+int scasml_gp_gram(int32_t d, double a, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy,
+                   double *K, void *stream);
+
+/* In-place lower Cholesky of the SPD matrix A + nugget*I (float64, row-major, M x M); the strict
+ * upper triangle is zeroed.  Replaces the SVD factor U*sqrt(S+nugget), models/GP.py:260-267.
+ * info_dev: one int32 on the device, set to the 1-based index of a non-positive pivot, else 0. */
+int scasml_cholesky(double *A, int64_t M, double nugget, int32_t *info_dev, void *stream);
+
+/* Solve L X = B (trans=0) or L^T X = B (trans=1) in place; L lower M x M, B M x nrhs row-major
+ * float64: the solves of models/GP.py:439, 533, 599. */
+int scasml_trsm_lower(const double *L, int64_t M, double *Bmat, int64_t nrhs, int trans, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCASML_HIP_H */

@@ -1,0 +1,113 @@
+"""ctypes binding of libscasml_hip.so (include/scasml_hip.h).  Fails loudly when the library
+is missing -- the product has no CPU path."""
+import ctypes as C
+import os
+
+MAX_LEVEL = 4
+MAX_Q = 6
+MAX_DIM = 255
+GP_TILE = 32
+ABI_VERSION = 1
+
+MODE_MLP, MODE_GENERATE, MODE_ACCUMULATE = 0, 1, 2
+EQ_GRAD_DEPENDENT_NONLINEAR = 0
+
+
+class Problem(C.Structure):
+    _fields_ = [("d", C.c_int32), ("eq_id", C.c_int32), ("T", C.c_float), ("mu", C.c_float),
+                ("sigma", C.c_float), ("clip", C.c_float)]
+
+
+class Rng(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("stream", C.c_uint32), ("root0", C.c_uint32),
+                ("rank", C.c_int32), ("world", C.c_int32)]
+
+
+class Term(C.Structure):
+    _fields_ = [("q", C.c_int32), ("mc", C.c_int32), ("sites_l", C.c_int32), ("sites_lm1", C.c_int32),
+                ("dfrac", C.c_float * MAX_Q), ("cfrac", C.c_float * MAX_Q),
+                ("wfrac", C.c_float * MAX_Q), ("dplus", C.c_float * MAX_Q)]
+
+
+class Plan(C.Structure):
+    _fields_ = [("variant", C.c_int32), ("n", C.c_int32), ("mg", C.c_int32 * (MAX_LEVEL + 1)),
+                ("sites", C.c_int32 * (MAX_LEVEL + 1)), ("term", (Term * MAX_LEVEL) * (MAX_LEVEL + 1))]
+
+
+class GpModel(C.Structure):
+    _fields_ = [("d", C.c_int32), ("n_dom", C.c_int32), ("n_bdy", C.c_int32), ("n_pad", C.c_int32),
+                ("kp", C.c_int32), ("a", C.c_float), ("sigma_eq", C.c_float),
+                ("colloc", C.c_void_p), ("colloc_frag", C.c_void_p), ("coef", C.c_void_p)]
+
+
+_STRUCTS = (Problem, Rng, Term, Plan, GpModel)
+_LIB = None
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libscasml_hip.so")
+
+# name -> (restype, argtypes); every symbol include/scasml_hip.h declares
+SIGNATURES = {
+    "scasml_abi_version": (C.c_int, []),
+    "scasml_last_error": (C.c_char_p, []),
+    "scasml_sizeof": (C.c_size_t, [C.c_int]),
+    "scasml_points_per_root": (C.c_int64, [C.POINTER(Plan)]),
+    "scasml_point_stride": (C.c_int32, [C.c_int32]),
+    "scasml_picard_tree": (C.c_int, [C.POINTER(Problem), C.POINTER(Plan), C.c_int, C.c_void_p, C.c_int64, Rng,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "scasml_clip": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
+    "scasml_debug_normals": (C.c_int, [Rng, C.c_uint32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
+    "scasml_gp_pack": (C.c_int, [C.c_int32, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "scasml_gp_eval": (C.c_int, [C.POINTER(GpModel), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "scasml_gp_gradient": (C.c_int, [C.POINTER(GpModel), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "scasml_gp_gram": (C.c_int, [C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "scasml_cholesky": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_void_p]),
+    "scasml_trsm_lower": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+}
+
+
+class ScasmlError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library once; raise if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ScasmlError(
+            "libscasml_hip.so is not built (%s missing). Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `python -m scasml_gp_amd._build`; "
+            "scasml_gp_amd has no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)           # AttributeError if a declared symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    if lib.scasml_abi_version() != ABI_VERSION:
+        raise ScasmlError("libscasml_hip.so ABI %d != binding ABI %d" % (lib.scasml_abi_version(), ABI_VERSION))
+    for which, st in enumerate(_STRUCTS):
+        if lib.scasml_sizeof(which) != C.sizeof(st):
+            raise ScasmlError("struct %s: library says %d bytes, binding %d" % (st.__name__, lib.scasml_sizeof(which), C.sizeof(st)))
+    _LIB = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise ScasmlError("%s failed (%d): %s" % (what, rc, load().scasml_last_error().decode()))
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise ScasmlError("scasml_gp_amd needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU path")
+    return torch
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)

@@ -1,0 +1,352 @@
+// Fused posterior evaluation of the PDE-constrained GP surrogate (inference side of models/GP.py).
+//
+// Replaces GP.predict (models/GP.py:653-671), GP.compute_gradient (:673-687; its spatial sum is
+// produced here, the full gradient by gp_gradient_kernel) and
+// GP_Grad_Dependent_Nonlinear.compute_PDE_loss (:746-769), which in the reference build three
+// (n_inf x M) feature matrices by nested autodiff.  Here every feature is P(rho^2, S, r_t)*kappa
+// (SURVEY.md Appendix C), so one pass over the N = N_dom + N_bdy collocation points suffices:
+//
+//   x.y          FP32 MFMA  v_mfma_f32_32x32x2_f32  (A = 32 collocation rows, B = 32 points)
+//   epilogue     per (collocation i, point j):  r2 = |x|^2 + |y|^2 - 2 x.y,  kappa = exp(-a r2/2),
+//                L = a^2 rho^2 - a d,  p = a r_t,  s = a S,  E = c0 + cL L + ct p + cS s, and
+//                u   += kappa E
+//                dt  += kappa (a ct - p E)
+//                div += kappa (a (2 cL s + d cS) - s E)
+//                lap += kappa (L E - 2a (cL (2L + a d) + cS s))
+//   (these are the I / dt / div / lap rows of Appendix C contracted with right_vector; c0..cS are
+//   the right_vector entries of the u, Lap, dt, div features of collocation point i).
+//
+// Layout: points are the MFMA N dimension (column = lane & 31), so the four running sums of a
+// point live in the lane that owns its column and the Monte-Carlo-free reduction over collocation
+// points is a plain register accumulation; only the two half-waves are combined at the end.
+// The K loop is split between the half-waves (half h takes k in [h*kp/2, (h+1)*kp/2)), which makes
+// every lane's operand a contiguous run of its row: 16-byte loads, no LDS staging; the point tile
+// stays in VGPRs for the whole sweep and the collocation tile streams from L2 in fragment order.
+#include "common.hpp"
+
+namespace scasml {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GpArgs {
+    const float *points;       // n_inf x kp
+    const float *colloc_frag;  // [n_tiles][NK4][64][4]
+    const float *coef;         // [8][n_pad]
+    float4 *out4;              // n_inf x (u, div, eps, dt)
+    float *lap;                // n_inf or null
+    int64_t n_inf;
+    int32_t n_pad, kp, d;
+    float a, sigma;
+};
+
+// NK4 = kp / 8 float4 per lane per row; PT = point tiles (of 32) per wave
+template <int NK4, int PT>
+__global__ __launch_bounds__(256, 2) void gp_eval_kernel(const GpArgs g) {
+    const int lane = threadIdx.x & 63;
+    const int col = lane & 31, half = lane >> 5;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t p0 = wave * (32 * PT);
+    if (p0 >= g.n_inf) return;  // whole wave idle (uniform)
+
+    // ---- this wave's point tiles -> registers, plus |x|^2, a*sum x, a*t per point ------------
+    float4 xf[PT][NK4];
+    float nx[PT], sx[PT], tx[PT];
+    const int kbase = half * (4 * NK4);
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        int64_t row = p0 + 32 * p + col;
+        if (row >= g.n_inf) row = g.n_inf - 1;  // shadow rows, never stored
+        const float4 *src = reinterpret_cast<const float4 *>(g.points + row * g.kp + kbase);
+        float pn = 0.0f, ps = 0.0f, pt = 0.0f;
+#pragma unroll
+        for (int v = 0; v < NK4; ++v) {
+            const float4 q = src[v];
+            xf[p][v] = q;
+            const float e[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int k = kbase + 4 * v + c;
+                pn = fmaf(e[c], e[c], pn);
+                ps += k < g.d ? e[c] : 0.0f;
+                pt += k == g.d ? e[c] : 0.0f;
+            }
+        }
+        pn += __shfl_xor(pn, 32);
+        ps += __shfl_xor(ps, 32);
+        pt += __shfl_xor(pt, 32);
+        nx[p] = pn;
+        sx[p] = g.a * ps;
+        tx[p] = g.a * pt;
+    }
+
+    float au[PT], at[PT], ad[PT], al[PT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) au[p] = at[p] = ad[p] = al[p] = 0.0f;
+
+    const float a = g.a;
+    const float a2 = a * a;
+    const float ad_ = a * (float)g.d;
+    const float kexp = -0.5f * a * 1.44269504088896341f;  // exp(-a r2/2) = exp2(r2 * kexp)
+    const int n_tiles = g.n_pad / 32;
+    const float4 *frag = reinterpret_cast<const float4 *>(g.colloc_frag) + lane;
+
+    for (int jt = 0; jt < n_tiles; ++jt) {
+        // ---- x.y for a 32 (collocation) x 32 (points) tile, per point tile ---------------------
+        f32x16 acc[PT];
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
+        const float4 *yt = frag + (int64_t)jt * NK4 * 64;
+#pragma unroll
+        for (int v = 0; v < NK4; ++v) {
+            const float4 y = yt[v * 64];
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(y.x, xf[p][v].x, acc[p], 0, 0, 0);
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(y.y, xf[p][v].y, acc[p], 0, 0, 0);
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(y.z, xf[p][v].z, acc[p], 0, 0, 0);
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(y.w, xf[p][v].w, acc[p], 0, 0, 0);
+            }
+        }
+        // ---- epilogue: C row = (r&3) + 8*(r>>2) + 4*half, column = lane & 31 -------------------
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+            const int j0 = jt * 32 + 8 * grp + 4 * half;
+            const float4 ny = *reinterpret_cast<const float4 *>(g.coef + 0 * g.n_pad + j0);
+            const float4 sy = *reinterpret_cast<const float4 *>(g.coef + 1 * g.n_pad + j0);
+            const float4 ty = *reinterpret_cast<const float4 *>(g.coef + 2 * g.n_pad + j0);
+            const float4 c0 = *reinterpret_cast<const float4 *>(g.coef + 3 * g.n_pad + j0);
+            const float4 cL = *reinterpret_cast<const float4 *>(g.coef + 4 * g.n_pad + j0);
+            const float4 ct = *reinterpret_cast<const float4 *>(g.coef + 5 * g.n_pad + j0);
+            const float4 cS = *reinterpret_cast<const float4 *>(g.coef + 6 * g.n_pad + j0);
+            const float vny[4] = {ny.x, ny.y, ny.z, ny.w}, vsy[4] = {sy.x, sy.y, sy.z, sy.w};
+            const float vty[4] = {ty.x, ty.y, ty.z, ty.w}, vc0[4] = {c0.x, c0.y, c0.z, c0.w};
+            const float vcL[4] = {cL.x, cL.y, cL.z, cL.w}, vct[4] = {ct.x, ct.y, ct.z, ct.w};
+            const float vcS[4] = {cS.x, cS.y, cS.z, cS.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int p = 0; p < PT; ++p) {
+                    const float dot = acc[p][4 * grp + e];
+                    const float r2 = fmaf(-2.0f, dot, nx[p] + vny[e]);
+                    const float pp = tx[p] - vty[e];               // a * r_t
+                    const float ss = sx[p] - vsy[e];               // a * S
+                    const float kap = __builtin_amdgcn_exp2f(r2 * kexp);
+                    const float L = fmaf(-pp, pp, fmaf(a2, r2, -ad_));   // a^2 (r2 - r_t^2) - a d
+                    const float E = fmaf(vcS[e], ss, fmaf(vct[e], pp, fmaf(vcL[e], L, vc0[e])));
+                    au[p] = fmaf(kap, E, au[p]);
+                    at[p] = fmaf(kap, fmaf(-pp, E, a * vct[e]), at[p]);
+                    const float dv = fmaf(2.0f * vcL[e], ss, (float)g.d * vcS[e]);
+                    ad[p] = fmaf(kap, fmaf(-ss, E, a * dv), ad[p]);
+                    const float lv = fmaf(vcL[e], fmaf(2.0f, L, ad_), vcS[e] * ss);
+                    al[p] = fmaf(kap, fmaf(L, E, -2.0f * a * lv), al[p]);
+                }
+            }
+        }
+    }
+    // ---- combine the two half-waves (rows 4h..4h+3 of each group) and store -------------------
+    const float s2 = g.sigma * g.sigma;
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        const float u = au[p] + __shfl_xor(au[p], 32);
+        const float dt = at[p] + __shfl_xor(at[p], 32);
+        const float dv = ad[p] + __shfl_xor(ad[p], 32);
+        const float lp = al[p] + __shfl_xor(al[p], 32);
+        const int64_t row = p0 + 32 * p + col;
+        if (half == 0 && row < g.n_inf) {
+            // models/GP.py:767-768
+            const float eps = dt + (s2 * u - 1.0f / (float)g.d - 0.5f * s2) * dv + 0.5f * s2 * lp;
+            g.out4[row] = make_float4(u, dv, eps, dt);
+            if (g.lap) g.lap[row] = lp;
+        }
+    }
+}
+
+// Full gradient of the posterior mean (models/GP.py:673-687).  Not on the solver hot path
+// (f of Grad_Dependent_Nonlinear needs only the spatial sum, which gp_eval_kernel returns);
+// one wave per point, lanes stride the collocation points, d-vector partials in LDS-free form:
+//   d/dx_i u = x_i * A1 - sum_j alpha_j y_ji + A2,  alpha_j = kappa_j a (2 a cL_j - E_j),
+//   A1 = sum_j alpha_j,  A2 = sum_j kappa_j a cS_j;   d/dt u = sum_j kappa_j (a ct_j - p E_j).
+__global__ __launch_bounds__(256) void gp_gradient_kernel(const float *points, const float *colloc, const float *coef,
+                                                          float *grad, int64_t n_inf, int n_pad, int kp, int d, float a) {
+    extern __shared__ float sh[];  // per wave: kp floats of the point + 64 alphas
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + wv;
+    const bool valid = row < n_inf;
+    if (!valid) row = n_inf - 1;
+    float *xs = sh + wv * (kp + 64);
+    float *alpha = xs + kp;
+    for (int k = lane; k < kp; k += 64) xs[k] = points[row * kp + k];
+    __syncthreads();
+    float nxv = 0.0f, sxv = 0.0f;
+    for (int k = 0; k <= d; ++k) nxv = fmaf(xs[k], xs[k], nxv);
+    for (int k = 0; k < d; ++k) sxv += xs[k];
+    const float txa = a * xs[d], sxa = a * sxv;
+    const float a2 = a * a, ad_ = a * (float)d;
+    // each lane accumulates dims lane, lane+64, ... of  -sum_j alpha_j y_j
+    float gacc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float A1 = 0.0f, A2 = 0.0f, gt = 0.0f;
+    for (int j0 = 0; j0 < n_pad; j0 += 64) {
+        const int j = j0 + lane;
+        float al = 0.0f;
+        if (j < n_pad) {
+            const float *y = colloc + (int64_t)j * kp;
+            float dot = 0.0f;
+            for (int k = 0; k <= d; ++k) dot = fmaf(xs[k], y[k], dot);
+            const float r2 = fmaf(-2.0f, dot, nxv + coef[j]);
+            const float pp = txa - coef[2 * n_pad + j], ss = sxa - coef[1 * n_pad + j];
+            const float kap = expf(-0.5f * a * r2);
+            const float L = fmaf(-pp, pp, fmaf(a2, r2, -ad_));
+            const float c0 = coef[3 * n_pad + j], cL = coef[4 * n_pad + j], ct = coef[5 * n_pad + j], cS = coef[6 * n_pad + j];
+            const float E = fmaf(cS, ss, fmaf(ct, pp, fmaf(cL, L, c0)));
+            al = kap * a * (2.0f * a * cL - E);
+            A1 += al;
+            A2 += kap * a * cS;
+            gt += kap * fmaf(-pp, E, a * ct);
+        }
+        alpha[lane] = al;
+        __syncthreads();
+        const int jn = n_pad - j0 < 64 ? n_pad - j0 : 64;
+        for (int jj = 0; jj < jn; ++jj) {
+            const float aj = alpha[jj];
+            const float *y = colloc + (int64_t)(j0 + jj) * kp;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int k = lane + 64 * c;
+                if (k < d) gacc[c] = fmaf(-aj, y[k], gacc[c]);
+            }
+        }
+        __syncthreads();
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        A1 += __shfl_xor(A1, o);
+        A2 += __shfl_xor(A2, o);
+        gt += __shfl_xor(gt, o);
+    }
+    if (!valid) return;
+    float *out = grad + row * (d + 1);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int k = lane + 64 * c;
+        if (k < d) out[k] = fmaf(xs[k], A1, gacc[c]) + A2;
+    }
+    if (lane == 0) out[d] = gt;
+}
+
+// Build the device model from the training set and right_vector (models/GP.py:593-600).
+__global__ void gp_pack_kernel(int d, float a, const float *x_dom, int n_dom, const float *x_bdy, int n_bdy,
+                               const double *rv, float *colloc, float *frag, float *coef, int n_pad, int kp) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_pad) return;
+    const int N = n_dom + n_bdy;
+    const float *src = j < n_dom ? x_dom + (int64_t)j * (d + 1) : (j < N ? x_bdy + (int64_t)(j - n_dom) * (d + 1) : nullptr);
+    float ny = 0.0f, sy = 0.0f, ty = 0.0f;
+    const int nk4 = kp / 8, tile = j / 32, i = j % 32;
+    for (int k = 0; k < kp; ++k) {
+        const float v = (src && k <= d) ? src[k] : 0.0f;
+        colloc[(int64_t)j * kp + k] = v;
+        // fragment order [tile][v][lane = half*32 + i][4], half h covers k in [h*kp/2, (h+1)*kp/2)
+        const int h = k / (kp / 2), kk = k % (kp / 2);
+        frag[(((int64_t)tile * nk4 + kk / 4) * 64 + h * 32 + i) * 4 + (kk & 3)] = v;
+        ny = fmaf(v, v, ny);
+        if (k < d) sy += v;
+        if (k == d) ty = v;
+    }
+    coef[0 * n_pad + j] = ny;
+    coef[1 * n_pad + j] = a * sy;
+    coef[2 * n_pad + j] = a * ty;
+    float c0 = 0.0f, cL = 0.0f, ct = 0.0f, cS = 0.0f;
+    if (j < n_dom) {
+        c0 = (float)rv[j];
+        cL = (float)rv[n_dom + n_bdy + j];
+        ct = (float)rv[2 * n_dom + n_bdy + j];
+        cS = (float)rv[3 * n_dom + n_bdy + j];
+    } else if (j < N) {
+        c0 = (float)rv[j];
+    }
+    coef[3 * n_pad + j] = c0;
+    coef[4 * n_pad + j] = cL;
+    coef[5 * n_pad + j] = ct;
+    coef[6 * n_pad + j] = cS;
+    coef[7 * n_pad + j] = 0.0f;
+}
+
+template <int NK4>
+static int launch_eval(const GpArgs &g, hipStream_t s) {
+    constexpr int PT = NK4 <= 13 ? 2 : 1;
+    const int64_t waves = (g.n_inf + 32 * PT - 1) / (32 * PT);
+    const int64_t blocks = (waves + 3) / 4;
+    if (blocks > 0x7FFFFFFF) return fail(SCASML_ERR_UNSUPPORTED, "gp_eval: too many points");
+    hipLaunchKernelGGL((gp_eval_kernel<NK4, PT>), dim3((unsigned)blocks), dim3(256), 0, s, g);
+    return check_launch("gp_eval launch");
+}
+
+static int check_model(const scasml_gp_model *m, const char *who) {
+    if (!m || !m->colloc || !m->colloc_frag || !m->coef) return fail(SCASML_ERR_ARG, "%s: null model", who);
+    if (m->d < 1 || m->d > SCASML_MAX_DIM) return fail(SCASML_ERR_UNSUPPORTED, "%s: d=%d outside 1..%d", who, m->d, SCASML_MAX_DIM);
+    if (m->kp != scasml_point_stride(m->d)) return fail(SCASML_ERR_ARG, "%s: kp=%d does not match d=%d", who, m->kp, m->d);
+    if (m->n_pad < 32 || m->n_pad % SCASML_GP_TILE || m->n_pad < m->n_dom + m->n_bdy)
+        return fail(SCASML_ERR_ARG, "%s: n_pad=%d invalid for %d+%d points", who, m->n_pad, m->n_dom, m->n_bdy);
+    return 0;
+}
+
+}  // namespace scasml
+
+using namespace scasml;
+
+extern "C" int scasml_gp_pack(int32_t d, float a, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy,
+                              const double *rv, float *colloc_out, float *colloc_frag_out, float *coef_out, void *stream) {
+    if (!x_dom || !rv || !colloc_out || !colloc_frag_out || !coef_out || (n_bdy > 0 && !x_bdy))
+        return fail(SCASML_ERR_ARG, "gp_pack: null argument");
+    if (d < 1 || d > SCASML_MAX_DIM || n_dom < 1 || n_bdy < 0) return fail(SCASML_ERR_ARG, "gp_pack: bad sizes");
+    const int n_pad = (n_dom + n_bdy + 31) / 32 * 32;
+    const int kp = scasml_point_stride(d);
+    hipLaunchKernelGGL(gp_pack_kernel, dim3((n_pad + 63) / 64), dim3(64), 0, (hipStream_t)stream, d, a, x_dom, n_dom, x_bdy,
+                       n_bdy, rv, colloc_out, colloc_frag_out, coef_out, n_pad, kp);
+    return check_launch("gp_pack launch");
+}
+
+extern "C" int scasml_gp_eval(const scasml_gp_model *m, const float *points, int64_t n_inf, float *out4, float *lap,
+                              void *stream) {
+    if (int rc = check_model(m, "gp_eval")) return rc;
+    if (n_inf < 0 || (n_inf > 0 && (!points || !out4))) return fail(SCASML_ERR_ARG, "gp_eval: bad argument");
+    if (n_inf == 0) return 0;
+    GpArgs g;
+    g.points = points;
+    g.colloc_frag = m->colloc_frag;
+    g.coef = m->coef;
+    g.out4 = reinterpret_cast<float4 *>(out4);
+    g.lap = lap;
+    g.n_inf = n_inf;
+    g.n_pad = m->n_pad;
+    g.kp = m->kp;
+    g.d = m->d;
+    g.a = m->a;
+    g.sigma = m->sigma_eq;
+    hipStream_t s = (hipStream_t)stream;
+#define SCASML_EVAL_CASE(NK) \
+    case NK: return launch_eval<NK>(g, s);
+    switch (m->kp / 8) {
+        SCASML_EVAL_CASE(1) SCASML_EVAL_CASE(2) SCASML_EVAL_CASE(3) SCASML_EVAL_CASE(4) SCASML_EVAL_CASE(5) SCASML_EVAL_CASE(6)
+        SCASML_EVAL_CASE(7) SCASML_EVAL_CASE(8) SCASML_EVAL_CASE(9) SCASML_EVAL_CASE(10) SCASML_EVAL_CASE(11) SCASML_EVAL_CASE(12)
+        SCASML_EVAL_CASE(13) SCASML_EVAL_CASE(14) SCASML_EVAL_CASE(15) SCASML_EVAL_CASE(16) SCASML_EVAL_CASE(17) SCASML_EVAL_CASE(18)
+        SCASML_EVAL_CASE(19) SCASML_EVAL_CASE(20) SCASML_EVAL_CASE(21) SCASML_EVAL_CASE(22) SCASML_EVAL_CASE(23) SCASML_EVAL_CASE(24)
+        SCASML_EVAL_CASE(25) SCASML_EVAL_CASE(26) SCASML_EVAL_CASE(27) SCASML_EVAL_CASE(28) SCASML_EVAL_CASE(29) SCASML_EVAL_CASE(30)
+        SCASML_EVAL_CASE(31) SCASML_EVAL_CASE(32)
+    }
+#undef SCASML_EVAL_CASE
+    return fail(SCASML_ERR_UNSUPPORTED, "gp_eval: kp=%d", m->kp);
+}
+
+extern "C" int scasml_gp_gradient(const scasml_gp_model *m, const float *points, int64_t n_inf, float *grad, void *stream) {
+    if (int rc = check_model(m, "gp_gradient")) return rc;
+    if (n_inf < 0 || (n_inf > 0 && (!points || !grad))) return fail(SCASML_ERR_ARG, "gp_gradient: bad argument");
+    if (n_inf == 0) return 0;
+    const int64_t blocks = (n_inf + 3) / 4;
+    if (blocks > 0x7FFFFFFF) return fail(SCASML_ERR_UNSUPPORTED, "gp_gradient: too many points");
+    const size_t lds = 4 * (m->kp + 64) * sizeof(float);
+    hipLaunchKernelGGL(gp_gradient_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, points, m->colloc,
+                       m->coef, grad, n_inf, m->n_pad, m->kp, m->d, m->a);
+    return check_launch("gp_gradient launch");
+}

@@ -1,0 +1,268 @@
+// Training side of the PDE-constrained GP (models/GP.py:182-268, 430-444, 487-604): the
+// 25-block derivative-feature Gram matrix in closed form, a blocked right-looking Cholesky of
+// K + nugget*I (the reference factors by SVD, models/GP.py:260-267; for symmetric PSD K the
+// product L L^T is the same matrix) and blocked triangular solves.  Everything here is float64,
+// as the reference's x64 SVD is.  Matrix order M must be a multiple of 32; the host pads with an
+// identity block (chol([[A,0],[0,I]]) = [[L,0],[0,I]]).
+//
+// Block order of K (models/GP.py:251-258): [u(dom), u(bdy), Lap(dom), dt(dom), div(dom)].
+#include "common.hpp"
+
+namespace scasml {
+
+constexpr int NB = 32;
+
+// ---------------------------------------------------------------------------------- Gram
+// One thread per ordered pair (i, j) of collocation points; writes the up-to-16 operator
+// combinations of that pair into their blocks.
+__global__ void gp_gram_kernel(int d, double a, const float *x_dom, int n_dom, const float *x_bdy, int n_bdy, double *K) {
+    const int N = n_dom + n_bdy;
+    const int i = blockIdx.y * blockDim.y + threadIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N || j >= N) return;
+    const int64_t M = 4 * (int64_t)n_dom + n_bdy;
+    const float *xi = i < n_dom ? x_dom + (int64_t)i * (d + 1) : x_bdy + (int64_t)(i - n_dom) * (d + 1);
+    const float *yj = j < n_dom ? x_dom + (int64_t)j * (d + 1) : x_bdy + (int64_t)(j - n_dom) * (d + 1);
+    double r2 = 0.0, S = 0.0;
+    for (int k = 0; k < d; ++k) {
+        const double r = (double)xi[k] - (double)yj[k];
+        r2 = fma(r, r, r2);
+        S += r;
+    }
+    const double rt = (double)xi[d] - (double)yj[d];
+    const double rho2 = r2;
+    r2 = fma(rt, rt, r2);
+    const double kap = exp(-0.5 * a * r2);
+    const double lap = a * a * rho2 - a * d;
+    // operator polynomials P(opx, opy); ops: 0 = I, 1 = Lap, 2 = dt, 3 = div
+    double P[4][4];
+    P[0][0] = 1.0;
+    P[0][1] = lap;
+    P[0][2] = a * rt;
+    P[0][3] = a * S;
+    P[1][0] = lap;
+    P[1][1] = a * a * a * a * rho2 * rho2 - (2.0 * d + 4.0) * a * a * a * rho2 + ((double)d * d + 2.0 * d) * a * a;
+    P[1][2] = a * rt * lap;
+    P[1][3] = a * S * lap - 2.0 * a * a * S;
+    P[2][0] = -a * rt;
+    P[2][1] = -a * rt * lap;
+    P[2][2] = a - a * a * rt * rt;
+    P[2][3] = -a * a * rt * S;
+    P[3][0] = -a * S;
+    P[3][1] = -(a * S * lap - 2.0 * a * a * S);
+    P[3][2] = -a * a * rt * S;
+    P[3][3] = a * d - a * a * S * S;
+    // row / column index of (op, point): u(dom) | u(bdy) | Lap(dom) | dt(dom) | div(dom)
+    const int nops_i = i < n_dom ? 4 : 1, nops_j = j < n_dom ? 4 : 1;
+    for (int ox = 0; ox < nops_i; ++ox) {
+        const int64_t row = ox == 0 ? i : (int64_t)n_dom + n_bdy + (int64_t)(ox - 1) * n_dom + i;
+        for (int oy = 0; oy < nops_j; ++oy) {
+            const int64_t col = oy == 0 ? j : (int64_t)n_dom + n_bdy + (int64_t)(oy - 1) * n_dom + j;
+            K[row * M + col] = P[ox][oy] * kap;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------- Cholesky
+// (1) factor the NB x NB diagonal block in LDS (adds the nugget to the diagonal first)
+__global__ __launch_bounds__(NB *NB) void chol_diag_kernel(double *A, int64_t M, int64_t k0, int32_t *info) {
+    __shared__ double T[NB][NB + 1];
+    const int r = threadIdx.y, c = threadIdx.x;
+    T[r][c] = A[(k0 + r) * M + (k0 + c)];
+    __syncthreads();
+    for (int j = 0; j < NB; ++j) {
+        if (r == j && c == j) {
+            const double v = T[j][j];
+            if (!(v > 0.0)) {
+                if (*info == 0) *info = (int32_t)(k0 + j + 1);
+                T[j][j] = nan("");
+            } else {
+                T[j][j] = sqrt(v);
+            }
+        }
+        __syncthreads();
+        if (c == j && r > j) T[r][j] /= T[j][j];
+        __syncthreads();
+        if (c > j && r >= c) T[r][c] -= T[r][j] * T[c][j];
+        __syncthreads();
+    }
+    A[(k0 + r) * M + (k0 + c)] = r >= c ? T[r][c] : 0.0;
+}
+
+// (2) panel: rows below the diagonal block, X * L_kk^T = A_panel  (one thread per row)
+__global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int64_t M, int64_t k0) {
+    __shared__ double Lk[NB][NB + 1];
+    for (int idx = threadIdx.x; idx < NB * NB; idx += blockDim.x) Lk[idx / NB][idx % NB] = A[(k0 + idx / NB) * M + k0 + idx % NB];
+    __syncthreads();
+    const int64_t r = k0 + NB + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= M) return;
+    double x[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) x[j] = A[r * M + k0 + j];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        double v = x[j];
+#pragma unroll
+        for (int p = 0; p < j; ++p) v = fma(-x[p], Lk[j][p], v);
+        x[j] = v / Lk[j][j];
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) A[r * M + k0 + j] = x[j];
+}
+
+// (3) trailing update, lower triangle only: C[ti][tj] -= P[ti] * P[tj]^T, 32x32 tile per block
+__global__ __launch_bounds__(256) void chol_update_kernel(double *A, int64_t M, int64_t k0) {
+    const int64_t nt = (M - k0 - NB) / NB;
+    // linear lower-triangular tile index -> (ti, tj), tj <= ti
+    const int64_t t = blockIdx.x;
+    int64_t ti = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    while (ti * (ti + 1) / 2 > t) --ti;
+    const int64_t tj = t - ti * (ti + 1) / 2;
+    if (ti >= nt) return;
+    __shared__ double Pi[NB][NB + 1], Pj[NB][NB + 1];
+    const int64_t r0 = k0 + NB + ti * NB, c0 = k0 + NB + tj * NB;
+    for (int idx = threadIdx.x; idx < NB * NB; idx += blockDim.x) {
+        const int rr = idx / NB, cc = idx % NB;
+        Pi[rr][cc] = A[(r0 + rr) * M + k0 + cc];
+        Pj[rr][cc] = A[(c0 + rr) * M + k0 + cc];
+    }
+    __syncthreads();
+    const int c = threadIdx.x % NB, rb = threadIdx.x / NB;  // 8 row groups of 4 rows
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const double b = Pj[c][k];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fma(Pi[rb * 4 + e][k], b, acc[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) A[(r0 + rb * 4 + e) * M + c0 + c] -= acc[e];
+}
+
+// ---------------------------------------------------------------------------------- TRSM
+// diagonal-block solve: one thread per right-hand-side column
+template <int TRANS>
+__global__ __launch_bounds__(256) void trsm_diag_kernel(const double *L, int64_t M, double *B, int64_t nrhs, int64_t k0) {
+    __shared__ double Lk[NB][NB + 1];
+    for (int idx = threadIdx.x; idx < NB * NB; idx += blockDim.x) Lk[idx / NB][idx % NB] = L[(k0 + idx / NB) * M + k0 + idx % NB];
+    __syncthreads();
+    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= nrhs) return;
+    double x[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) x[j] = B[(k0 + j) * nrhs + col];
+    if (TRANS == 0) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            double v = x[j];
+#pragma unroll
+            for (int p = 0; p < j; ++p) v = fma(-Lk[j][p], x[p], v);
+            x[j] = v / Lk[j][j];
+        }
+    } else {
+#pragma unroll
+        for (int j = NB - 1; j >= 0; --j) {
+            double v = x[j];
+#pragma unroll
+            for (int p = j + 1; p < NB; ++p) v = fma(-Lk[p][j], x[p], v);
+            x[j] = v / Lk[j][j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) B[(k0 + j) * nrhs + col] = x[j];
+}
+
+// off-diagonal update with the freshly solved block row X_k (NB x nrhs):
+//   TRANS == 0:  B[r, :] -= L[r, k0:k0+NB] * X_k          for row blocks r > k
+//   TRANS == 1:  B[r, :] -= L[k0:k0+NB, r]^T * X_k        for row blocks r < k
+template <int TRANS>
+__global__ __launch_bounds__(256) void trsm_update_kernel(const double *L, int64_t M, double *B, int64_t nrhs, int64_t k0) {
+    __shared__ double Lt[NB][NB + 1], Xk[NB][NB + 1];
+    const int64_t rblk = TRANS == 0 ? k0 / NB + 1 + blockIdx.y : blockIdx.y;
+    const int64_t r0 = rblk * NB, c0 = (int64_t)blockIdx.x * NB;
+    for (int idx = threadIdx.x; idx < NB * NB; idx += blockDim.x) {
+        const int rr = idx / NB, cc = idx % NB;
+        Lt[rr][cc] = TRANS == 0 ? L[(r0 + rr) * M + k0 + cc] : L[(k0 + cc) * M + r0 + rr];
+        Xk[rr][cc] = c0 + cc < nrhs ? B[(k0 + rr) * nrhs + c0 + cc] : 0.0;
+    }
+    __syncthreads();
+    const int c = threadIdx.x % NB, rb = threadIdx.x / NB;
+    if (c0 + c >= nrhs) return;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const double b = Xk[k][c];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fma(Lt[rb * 4 + e][k], b, acc[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) B[(r0 + rb * 4 + e) * nrhs + c0 + c] -= acc[e];
+}
+
+__global__ void add_diag_kernel(double *A, int64_t M, double v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) A[i * M + i] += v;
+}
+
+__global__ void zero_upper_kernel(double *A, int64_t M) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t r = blockIdx.y;
+    if (c < M && c > r) A[r * M + c] = 0.0;
+}
+
+}  // namespace scasml
+
+using namespace scasml;
+
+extern "C" int scasml_gp_gram(int32_t d, double a, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy,
+                              double *K, void *stream) {
+    if (!x_dom || !K || (n_bdy > 0 && !x_bdy)) return fail(SCASML_ERR_ARG, "gp_gram: null argument");
+    if (d < 1 || n_dom < 1 || n_bdy < 0) return fail(SCASML_ERR_ARG, "gp_gram: bad sizes");
+    const int N = n_dom + n_bdy;
+    hipLaunchKernelGGL(gp_gram_kernel, dim3((N + 15) / 16, (N + 15) / 16), dim3(16, 16), 0, (hipStream_t)stream, d, a, x_dom,
+                       n_dom, x_bdy, n_bdy, K);
+    return check_launch("gp_gram launch");
+}
+
+extern "C" int scasml_cholesky(double *A, int64_t M, double nugget, int32_t *info_dev, void *stream) {
+    if (!A || !info_dev || M < 1) return fail(SCASML_ERR_ARG, "cholesky: bad argument");
+    if (M % NB) return fail(SCASML_ERR_UNSUPPORTED, "cholesky: M=%lld is not a multiple of %d (pad with an identity block)", (long long)M, NB);
+    if (M > 65535 * (int64_t)NB) return fail(SCASML_ERR_UNSUPPORTED, "cholesky: M too large for this build");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(info_dev, 0, sizeof(int32_t), s) != hipSuccess) return fail(SCASML_ERR_HIP, "cholesky: memset failed");
+    if (nugget != 0.0) hipLaunchKernelGGL(add_diag_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, A, M, nugget);
+    for (int64_t k0 = 0; k0 < M; k0 += NB) {
+        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(NB, NB), 0, s, A, M, k0, info_dev);
+        const int64_t rest = M - k0 - NB;
+        if (rest <= 0) break;
+        hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)((rest + 255) / 256)), dim3(256), 0, s, A, M, k0);
+        const int64_t nt = rest / NB;
+        hipLaunchKernelGGL(chol_update_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, s, A, M, k0);
+    }
+    hipLaunchKernelGGL(zero_upper_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)M), dim3(256), 0, s, A, M);
+    return check_launch("cholesky launch");
+}
+
+extern "C" int scasml_trsm_lower(const double *L, int64_t M, double *Bmat, int64_t nrhs, int trans, void *stream) {
+    if (!L || !Bmat || M < 1 || nrhs < 0) return fail(SCASML_ERR_ARG, "trsm: bad argument");
+    if (nrhs == 0) return 0;
+    if (M % NB) return fail(SCASML_ERR_UNSUPPORTED, "trsm: M=%lld is not a multiple of %d", (long long)M, NB);
+    if (M > 65535 * (int64_t)NB) return fail(SCASML_ERR_UNSUPPORTED, "trsm: M too large for this build");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned cb = (unsigned)((nrhs + 255) / 256), ct = (unsigned)((nrhs + NB - 1) / NB);
+    const int64_t nblk = M / NB;
+    if (trans == 0) {
+        for (int64_t k = 0; k < nblk; ++k) {
+            hipLaunchKernelGGL(trsm_diag_kernel<0>, dim3(cb), dim3(256), 0, s, L, M, Bmat, nrhs, k * NB);
+            if (k + 1 < nblk)
+                hipLaunchKernelGGL(trsm_update_kernel<0>, dim3(ct, (unsigned)(nblk - k - 1)), dim3(256), 0, s, L, M, Bmat, nrhs, k * NB);
+        }
+    } else {
+        for (int64_t k = nblk - 1; k >= 0; --k) {
+            hipLaunchKernelGGL(trsm_diag_kernel<1>, dim3(cb), dim3(256), 0, s, L, M, Bmat, nrhs, k * NB);
+            if (k > 0) hipLaunchKernelGGL(trsm_update_kernel<1>, dim3(ct, (unsigned)k), dim3(256), 0, s, L, M, Bmat, nrhs, k * NB);
+        }
+    }
+    return check_launch("trsm launch");
+}

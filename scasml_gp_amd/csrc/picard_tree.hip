@@ -1,0 +1,388 @@
+// Picard-tree kernel: the whole multilevel-Picard recursion of one evaluation point, walked
+// depth-first inside one group of lanes of a 64-wide wavefront.
+//
+// Replaces MLP.uz_solve (solvers/MLP.py:141-274), ScaSML.uz_solve (solvers/ScaSML.py:149-284),
+// MLP_full_history.uz_solve (solvers/MLP_full_history.py:64-180) and
+// ScaSML_full_history.uz_solve (solvers/ScaSML_full_history.py:75-199).
+//
+// Mapping (DESIGN.md "picard_tree"): a root point owns G = pow2 >= round_up(d+1,8)/4 lanes; lane
+// `gl` of the group holds spatial dims 4gl..4gl+3 of every d-vector (x, X, W, z) in one float4,
+// so one Philox4x32 block per lane per path-step yields exactly that lane's four normals.
+// 64/G roots share a wavefront and walk the SAME static tree in lock step -- the tree depends
+// only on the tables (MLP.py:111-139), never on data, so there is no divergence.  The
+// recursion is unrolled at compile time (level is a template parameter): every frame lives in
+// VGPRs, sum_i over the dims is a log2(G)-step xor-shuffle, sum over Monte-Carlo samples is a
+// register accumulation, and nothing but the root row is read from or written to HBM in
+// MODE_MLP.  For ScaSML the same walk runs twice around the batched GP evaluation:
+// MODE_GENERATE emits every tree point (coalesced float4 rows), MODE_ACCUMULATE replays the
+// identical Philox stream and consumes (u_hat, div u_hat, eps_PDE) per point.
+#include "common.hpp"
+#include "philox_normal.hpp"
+
+namespace scasml {
+
+struct TreeArgs {
+    scasml_plan plan;
+    const float *x_t;
+    float *points;
+    const float4 *gpv;
+    float *out_uz;
+    float *out_uhat;
+    int64_t B;
+    int64_t ppr;  // points per root = plan.sites[n] + 1
+    uint32_t k0, k1, stream, root0;
+    int32_t rank, world;
+    int32_t d, G, logG, kp;
+    float T, mu, sigma, clip;
+};
+
+__device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
+__device__ __forceinline__ float4 fma4(float s, float4 a, float4 b) {  // s*a + b
+    return make_float4(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z), fmaf(s, a.w, b.w));
+}
+__device__ __forceinline__ float4 add4(float4 a, float s) { return make_float4(a.x + s, a.y + s, a.z + s, a.w + s); }
+__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float clip1(float v, float c) { return v < -c ? -c : (v > c ? c : v); }  // keeps NaN (jnp.clip)
+
+template <int VAR, int MODE>
+struct Walker {
+    const TreeArgs &a;
+    float4 mask;       // 1 on this lane's live spatial dims, 0 on padding
+    uint32_t gl;       // lane index inside the root's group = Philox quad index
+    uint32_t root;     // global root index (Philox counter word 2)
+    int64_t row0;      // first row of this root in points / gpv
+    int unit;          // running unit index of the ROOT call (sample sharding)
+
+    __device__ __forceinline__ float group_sum(float v) const {
+        for (int o = a.G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        return v;
+    }
+    __device__ __forceinline__ float dim_sum(float4 v) const {
+        return group_sum(fmaf(mask.x, v.x, fmaf(mask.y, v.y, fmaf(mask.z, v.z, mask.w * v.w))));
+    }
+    __device__ __forceinline__ float4 normals(uint32_t site) const {
+        return mul4(normal4(gl, site, root, a.stream, a.k0, a.k1), mask);
+    }
+    __device__ __forceinline__ void emit_point(float4 X, float t, uint32_t site) const {
+        const int dim0 = 4 * (int)gl;
+        if (dim0 >= a.kp) return;
+        float4 v;
+        v.x = dim0 + 0 < a.d ? X.x : (dim0 + 0 == a.d ? t : 0.0f);
+        v.y = dim0 + 1 < a.d ? X.y : (dim0 + 1 == a.d ? t : 0.0f);
+        v.z = dim0 + 2 < a.d ? X.z : (dim0 + 2 == a.d ? t : 0.0f);
+        v.w = dim0 + 3 < a.d ? X.w : (dim0 + 3 == a.d ? t : 0.0f);
+        *reinterpret_cast<float4 *>(a.points + (row0 + site) * a.kp + dim0) = v;
+    }
+    __device__ __forceinline__ float4 gp_at(uint32_t site) const { return a.gpv[row0 + site]; }
+    __device__ __forceinline__ bool owned(bool top) {
+        if (!top || a.world == 1) return true;
+        const bool mine = (unit % a.world) == a.rank;
+        ++unit;
+        return mine;
+    }
+
+    // equations/equations.py:248-261 at time T; ScaSML.py:61-63 subtracts the surrogate
+    __device__ __forceinline__ float g_terminal(float4 XT, uint32_t site) const {
+        const float s = a.T + dim_sum(XT);
+        float g = 1.0f - 1.0f / (1.0f + expf(s));
+        if constexpr (MODE == SCASML_MODE_ACCUMULATE) g -= gp_at(site).x;
+        return g;
+    }
+    // equations/equations.py:290-304 (MLP.py:27-41) / ScaSML.py:29-47
+    __device__ __forceinline__ float f_eval(float uc, float4 zc, float4 gp) const {
+        const float sz = dim_sum(zc);
+        if constexpr (MODE == SCASML_MODE_ACCUMULATE) {
+            const float sg = a.sigma * gp.y;  // sum_i sigma * d_i u_hat
+            return a.sigma * (uc + gp.x) * (sg + sz) - a.sigma * gp.x * sg;
+        } else {
+            return a.sigma * uc * sz;
+        }
+    }
+
+    // ---- one (n', l) term of the Picard sum ------------------------------------------------
+    template <int N, int L, bool TOP>
+    __device__ __forceinline__ void level(float4 x, float t, float tau, uint32_t base, uint32_t &o, float &u, float4 &z) {
+        const scasml_term &tm = a.plan.term[N][L];
+        const int q = tm.q, mc = tm.mc;
+        const uint32_t s_l = (uint32_t)tm.sites_l, s_lm = (uint32_t)tm.sites_lm1;
+        const float inv_mc = 1.0f / (float)mc;
+        for (int m = 0; m < mc; ++m) {
+            if (!owned(TOP)) {
+                o += (uint32_t)q * (1u + s_l + s_lm);
+                continue;
+            }
+            float4 X = x, W = f4(0.0f);
+            for (int k = 0; k < q; ++k) {
+                const uint32_t site = base + o;
+                o += 1;
+                const float4 xi = normals(site);
+                float tk, wk;
+                float4 wvec;  // the vector multiplying y in the z estimator
+                float dplus, dminus;
+                if constexpr (VAR == 0) {                        // MLP.py:219-225
+                    const float dk = tau * tm.dfrac[k];
+                    const float sdk = sqrtf(dk);
+                    W = fma4(sdk, xi, W);
+                    X = fma4(a.sigma * sdk, xi, add4(X, a.mu * dk));
+                    tk = fmaf(tau, tm.cfrac[k], t);
+                    wk = tau * tm.wfrac[k];
+                    wvec = W;
+                    dplus = 1.0f / fmaf(tau, tm.dplus[k], 1e-6f);   // MLP.py:249 (stale) / ScaSML.py:253
+                    dminus = 1.0f / fmaf(tau, tm.cfrac[k], 1e-6f);  // MLP.py:270
+                } else {                                         // MLP_full_history.py:133-145
+                    const float D = uniform_tau(site, root, a.stream, a.k0, a.k1) * tau;
+                    const float sD = sqrtf(D);
+                    X = fma4(a.sigma * sD, xi, add4(x, a.mu * D));
+                    tk = t + D;
+                    wk = tau;
+                    wvec = xi;
+                    dplus = dminus = 1.0f / sqrtf(D + 1e-6f);     // :158-159
+                }
+                if constexpr (MODE == SCASML_MODE_GENERATE) emit_point(X, tk, site);
+                float4 gp = f4(0.0f);
+                if constexpr (MODE == SCASML_MODE_ACCUMULATE) gp = gp_at(site);
+
+                float uc;
+                float4 zc;
+                uz<L, false>(X, tk, base + o, uc, zc);
+                o += s_l;
+                if constexpr (MODE != SCASML_MODE_GENERATE) {
+                    const float y = f_eval(uc, zc, gp) * (wk * inv_mc);
+                    u += y;                                      // MLP.py:248
+                    z = fma4(y * dplus, wvec, z);                // MLP.py:249
+                }
+                if constexpr (L > 0) {
+                    uz<L - 1, false>(X, tk, base + o, uc, zc);
+                    o += s_lm;
+                    if constexpr (MODE != SCASML_MODE_GENERATE) {
+                        const float y = f_eval(uc, zc, gp) * (wk * inv_mc);
+                        u -= y;                                  // MLP.py:269
+                        z = fma4(-y * dminus, wvec, z);          // MLP.py:271
+                    }
+                } else if constexpr (MODE == SCASML_MODE_ACCUMULATE) {
+                    const float e = gp.z * (wk * inv_mc);        // ScaSML.py:274-280
+                    u += e;
+                    z = fma4(e * dminus, wvec, z);
+                }
+            }
+        }
+        if constexpr (L + 1 < N) level<N, L + 1, TOP>(x, t, tau, base, o, u, z);
+    }
+
+    // ---- uz_solve at compile-time level N -----------------------------------------------------
+    template <int N, bool TOP>
+    __device__ __forceinline__ void uz(float4 x, float t, uint32_t base, float &u_out, float4 &z_out) {
+        if constexpr (N == 0) {                                  // MLP.py:205-207
+            u_out = 0.0f;
+            z_out = f4(0.0f);
+        } else {
+            const float tau = a.T - t;
+            const int mg = a.plan.mg[N];
+            const float drift = a.mu * tau, vol = a.sigma * sqrtf(tau);
+            float su = 0.0f;
+            float4 sz = f4(0.0f);
+            for (int m = 0; m < mg; ++m) {                       // MLP.py:175-202
+                if (!owned(TOP)) continue;
+                const uint32_t site = base + (uint32_t)m;
+                const float4 nrm = normals(site);
+                const float4 XT = fma4(vol, nrm, add4(x, drift));
+                if constexpr (MODE == SCASML_MODE_GENERATE) {
+                    emit_point(XT, a.T, site);
+                } else {
+                    const float g = g_terminal(XT, site);
+                    su += g;
+                    sz = fma4(g, nrm, sz);
+                }
+            }
+            const float inv_mg = 1.0f / (float)mg;
+            float u = su * inv_mg;
+            const float zs = inv_mg / (VAR == 0 ? tau + 1e-6f : tau);   // MLP.py:201 / MLP_full_history.py:122
+            float4 z = make_float4(sz.x * zs, sz.y * zs, sz.z * zs, sz.w * zs);
+            uint32_t o = (uint32_t)mg;
+            level<N, 0, TOP>(x, t, tau, base, o, u, z);
+            if (!(TOP && a.world > 1)) {                         // MLP.py:272-274
+                u = clip1(u, a.clip);
+                z = make_float4(clip1(z.x, a.clip), clip1(z.y, a.clip), clip1(z.z, a.clip), clip1(z.w, a.clip));
+            }
+            u_out = u;
+            z_out = z;
+        }
+    }
+};
+
+template <int VAR, int MODE, int N>
+__global__ __launch_bounds__(256) void picard_tree_kernel(const TreeArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * (blockDim.x >> 6)) + (threadIdx.x >> 6);
+    const int rpw = 64 >> a.logG;
+    int64_t local = (int64_t)wave * rpw + (lane >> a.logG);
+    const bool valid = local < a.B;
+    if (!valid) local = a.B - 1;  // idle groups shadow the last root; their stores are masked
+
+    Walker<VAR, MODE> w{a};
+    w.gl = (uint32_t)(lane & (a.G - 1));
+    w.root = a.root0 + (uint32_t)local;
+    w.row0 = local * a.ppr;
+    w.unit = 0;
+    const int dim0 = 4 * (int)w.gl;
+    w.mask = make_float4(dim0 + 0 < a.d ? 1.0f : 0.0f, dim0 + 1 < a.d ? 1.0f : 0.0f,
+                         dim0 + 2 < a.d ? 1.0f : 0.0f, dim0 + 3 < a.d ? 1.0f : 0.0f);
+    const float *row = a.x_t + local * (a.d + 1);
+    float4 x;
+    x.x = dim0 + 0 < a.d ? row[dim0 + 0] : 0.0f;
+    x.y = dim0 + 1 < a.d ? row[dim0 + 1] : 0.0f;
+    x.z = dim0 + 2 < a.d ? row[dim0 + 2] : 0.0f;
+    x.w = dim0 + 3 < a.d ? row[dim0 + 3] : 0.0f;
+    const float t = row[a.d];
+
+    if constexpr (MODE == SCASML_MODE_GENERATE) {
+        if (valid) w.emit_point(x, t, (uint32_t)(a.ppr - 1));   // the root itself, for ScaSML.py:303
+    }
+    float u;
+    float4 z;
+    w.template uz<N, true>(x, t, 0u, u, z);
+    if constexpr (MODE != SCASML_MODE_GENERATE) {
+        if (valid) {
+            float *out = a.out_uz + local * (a.d + 1);
+            if (w.gl == 0) {
+                out[0] = u;
+                if constexpr (MODE == SCASML_MODE_ACCUMULATE) {
+                    if (a.out_uhat) a.out_uhat[local] = w.gp_at((uint32_t)(a.ppr - 1)).x;
+                }
+            }
+            if (dim0 + 0 < a.d) out[1 + dim0 + 0] = z.x;
+            if (dim0 + 1 < a.d) out[1 + dim0 + 1] = z.y;
+            if (dim0 + 2 < a.d) out[1 + dim0 + 2] = z.z;
+            if (dim0 + 3 < a.d) out[1 + dim0 + 3] = z.w;
+        }
+    }
+}
+
+template <int VAR, int MODE>
+static int launch_level(const TreeArgs &a, int n, dim3 grid, hipStream_t s) {
+    switch (n) {
+        case 1: hipLaunchKernelGGL((picard_tree_kernel<VAR, MODE, 1>), grid, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((picard_tree_kernel<VAR, MODE, 2>), grid, dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL((picard_tree_kernel<VAR, MODE, 3>), grid, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((picard_tree_kernel<VAR, MODE, 4>), grid, dim3(256), 0, s, a); break;
+        default: return fail(SCASML_ERR_UNSUPPORTED, "picard_tree: level n=%d outside 1..%d", n, SCASML_MAX_LEVEL);
+    }
+    return check_launch("picard_tree launch");
+}
+
+template <int VAR>
+static int launch_mode(const TreeArgs &a, int mode, int n, dim3 grid, hipStream_t s) {
+    switch (mode) {
+        case SCASML_MODE_MLP: return launch_level<VAR, SCASML_MODE_MLP>(a, n, grid, s);
+        case SCASML_MODE_GENERATE: return launch_level<VAR, SCASML_MODE_GENERATE>(a, n, grid, s);
+        case SCASML_MODE_ACCUMULATE: return launch_level<VAR, SCASML_MODE_ACCUMULATE>(a, n, grid, s);
+    }
+    return fail(SCASML_ERR_ARG, "picard_tree: unknown mode %d", mode);
+}
+
+__global__ void clip_kernel(float *v, int64_t n, float c) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = clip1(v[i], c);
+}
+
+__global__ void debug_normals_kernel(uint32_t k0, uint32_t k1, uint32_t stream, uint32_t root0, uint32_t site,
+                                     int d, int64_t B, float *out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nq = (d + 3) / 4;
+    if (i >= B * nq) return;
+    const int64_t b = i / nq;
+    const int q = (int)(i % nq);
+    const float4 n = normal4((uint32_t)q, site, root0 + (uint32_t)b, stream, k0, k1);
+    const float v[4] = {n.x, n.y, n.z, n.w};
+    for (int j = 0; j < 4; ++j)
+        if (4 * q + j < d) out[b * d + 4 * q + j] = v[j];
+}
+
+}  // namespace scasml
+
+using namespace scasml;
+
+extern "C" int64_t scasml_points_per_root(const scasml_plan *plan_h) {
+    if (!plan_h || plan_h->n < 0 || plan_h->n > SCASML_MAX_LEVEL) return -1;
+    return (int64_t)plan_h->sites[plan_h->n] + 1;
+}
+
+extern "C" int32_t scasml_point_stride(int32_t d) { return (d + 1 + 7) / 8 * 8; }
+
+extern "C" int scasml_picard_tree(const scasml_problem *prob, const scasml_plan *plan, int mode, const float *x_t,
+                                  int64_t B, scasml_rng rng, float *points, const float *gp_vals, float *out_uz,
+                                  float *out_uhat, void *stream) {
+    if (!prob || !plan || !x_t) return fail(SCASML_ERR_ARG, "picard_tree: null argument");
+    if (B < 0) return fail(SCASML_ERR_ARG, "picard_tree: negative batch");
+    if (B == 0) return 0;
+    if (prob->d < 1 || prob->d > SCASML_MAX_DIM)
+        return fail(SCASML_ERR_UNSUPPORTED, "picard_tree: d=%d outside 1..%d", prob->d, SCASML_MAX_DIM);
+    if (prob->eq_id != SCASML_EQ_GRAD_DEPENDENT_NONLINEAR)
+        return fail(SCASML_ERR_UNSUPPORTED, "picard_tree: unknown equation id %d", prob->eq_id);
+    if (plan->variant != 0 && plan->variant != 1) return fail(SCASML_ERR_ARG, "picard_tree: variant %d", plan->variant);
+    if (plan->n < 0 || plan->n > SCASML_MAX_LEVEL)
+        return fail(SCASML_ERR_UNSUPPORTED, "picard_tree: level n=%d outside 0..%d", plan->n, SCASML_MAX_LEVEL);
+    if (rng.world < 1 || rng.rank < 0 || rng.rank >= rng.world) return fail(SCASML_ERR_ARG, "picard_tree: bad rank/world");
+    if (mode == SCASML_MODE_GENERATE && !points) return fail(SCASML_ERR_ARG, "picard_tree: GENERATE needs points");
+    if (mode == SCASML_MODE_ACCUMULATE && !gp_vals) return fail(SCASML_ERR_ARG, "picard_tree: ACCUMULATE needs gp_vals");
+    if (mode != SCASML_MODE_GENERATE && !out_uz) return fail(SCASML_ERR_ARG, "picard_tree: out_uz is null");
+    for (int np = 1; np <= plan->n; ++np)
+        for (int l = 0; l < np; ++l) {
+            const scasml_term &t = plan->term[np][l];
+            if (t.q < 1 || t.q > SCASML_MAX_Q || t.mc < 1) return fail(SCASML_ERR_ARG, "picard_tree: bad term [%d][%d]", np, l);
+        }
+    hipStream_t s = (hipStream_t)stream;
+    if (plan->n == 0) {  // MLP.py:205-207: zeros (ScaSML: u_hat still requested by the caller through gp_eval)
+        if (mode != SCASML_MODE_GENERATE) {
+            if (hipMemsetAsync(out_uz, 0, sizeof(float) * B * (prob->d + 1), s) != hipSuccess)
+                return fail(SCASML_ERR_HIP, "picard_tree: memset failed");
+        }
+        return 0;
+    }
+    TreeArgs a;
+    a.plan = *plan;
+    a.x_t = x_t;
+    a.points = points;
+    a.gpv = reinterpret_cast<const float4 *>(gp_vals);
+    a.out_uz = out_uz;
+    a.out_uhat = out_uhat;
+    a.B = B;
+    a.ppr = (int64_t)plan->sites[plan->n] + 1;
+    a.k0 = (uint32_t)(rng.seed & 0xFFFFFFFFu);
+    a.k1 = (uint32_t)(rng.seed >> 32);
+    a.stream = rng.stream;
+    a.root0 = rng.root0;
+    a.rank = rng.rank;
+    a.world = rng.world;
+    a.d = prob->d;
+    a.kp = scasml_point_stride(prob->d);
+    a.G = ceil_pow2(a.kp / 4);
+    a.logG = 0;
+    while ((1 << a.logG) < a.G) ++a.logG;
+    a.T = prob->T;
+    a.mu = prob->mu;
+    a.sigma = prob->sigma;
+    a.clip = prob->clip;
+    const int rpw = 64 / a.G;
+    const int64_t waves = (B + rpw - 1) / rpw;
+    const int64_t blocks = (waves + 3) / 4;
+    if (blocks > 0x7FFFFFFF) return fail(SCASML_ERR_UNSUPPORTED, "picard_tree: batch too large");
+    const dim3 grid((unsigned)blocks);
+    return plan->variant == 0 ? launch_mode<0>(a, mode, plan->n, grid, s) : launch_mode<1>(a, mode, plan->n, grid, s);
+}
+
+extern "C" int scasml_clip(float *uz, int64_t count, float clip, void *stream) {
+    if (!uz || count < 0) return fail(SCASML_ERR_ARG, "clip: bad argument");
+    if (count == 0) return 0;
+    hipLaunchKernelGGL(clip_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, uz, count, clip);
+    return check_launch("clip launch");
+}
+
+extern "C" int scasml_debug_normals(scasml_rng rng, uint32_t site, int32_t d, int64_t B, float *out, void *stream) {
+    if (!out || d < 1 || B < 0) return fail(SCASML_ERR_ARG, "debug_normals: bad argument");
+    if (B == 0) return 0;
+    const int64_t n = B * ((d + 3) / 4);
+    hipLaunchKernelGGL(debug_normals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (uint32_t)(rng.seed & 0xFFFFFFFFu), (uint32_t)(rng.seed >> 32), rng.stream, rng.root0, site, d, B, out);
+    return check_launch("debug_normals launch");
+}

@@ -1,0 +1,40 @@
+"""``MLP`` with the reference's call surface (solvers/MLP.py:5-288), running on libscasml_hip."""
+from .. import tables
+from ._picard import PicardEngine, deliver
+
+
+class MLP:
+    '''Multilevel Picard Iteration for high dimensional semilinear PDE (solvers/MLP.py:5-25)'''
+    _variant = "quad"
+
+    def __init__(self, equation, seed=0):
+        self.equation = equation
+        self.sigma = equation.sigma
+        self.mu = equation.mu
+        equation.geometry()
+        self.T = equation.T
+        self.t0 = equation.t0
+        self.n_input = equation.n_input
+        self.n_output = equation.n_output
+        self.evaluation_counter = 0
+        self.key = seed                      # Philox seed; replaces random.PRNGKey(0) (:25)
+        self._engine = PicardEngine(equation, self._variant, gp=None, seed=seed)
+
+    def f(self, x_t, u, z):
+        return self.equation.f(x_t, u, z)                         # :27-41
+
+    def g(self, x_t):
+        return self.equation.g(x_t)[:, 0]                         # :43-55
+
+    def approx_parameters(self, rhomax):
+        return tables.approx_parameters(int(rhomax), float(self.T))   # :111-139 (cached)
+
+    def uz_solve(self, n, rho, x_t):
+        '''(batch, 1 + d): u and z of solvers/MLP.py:141-274.'''
+        self.Mf, self.Mg, self.Q, self.c, self.w = self.approx_parameters(rho)
+        uz, _, was_numpy = self._engine.solve(int(n), int(rho), x_t)
+        self.evaluation_counter += self._engine.evaluation_increment(int(n), int(rho))
+        return deliver(uz, was_numpy)
+
+    def u_solve(self, n, rho, x_t):
+        return self.uz_solve(n, rho, x_t)[:, 0:1]                 # :276-288

@@ -1,0 +1,55 @@
+"""``ScaSML`` (solvers/ScaSML.py:5-304): multilevel Picard on the defect u - u_GP, on libscasml_hip."""
+from .. import tables
+from ._picard import PicardEngine, deliver
+
+
+class ScaSML:
+    '''Multilevel Picard Iteration calibrated GP for high dimensional semilinear PDE'''
+    _variant = "quad"
+
+    def __init__(self, equation, GP, seed=0):
+        self.equation = equation
+        self.sigma = equation.sigma
+        self.mu = equation.mu
+        equation.geometry()
+        self.T = equation.T
+        self.t0 = equation.t0
+        self.n_input = equation.n_input
+        self.n_output = equation.n_output
+        self.GP = GP
+        self.evaluation_counter = 0
+        self.key = seed
+        self._engine = PicardEngine(equation, self._variant, gp=GP, seed=seed)
+
+    def __setattr__(self, name, value):
+        object.__setattr__(self, name, value)
+        if name == "GP" and "_engine" in self.__dict__:            # harness reassigns solver.GP
+            self._engine.gp = value
+
+    def f(self, x_t, u_breve, z_breve):
+        '''solvers/ScaSML.py:29-47 (host view; the kernels fuse this into the tree walk).'''
+        eq = self.equation
+        u_hat = self.GP.predict(x_t)
+        grad_x = self.GP.compute_gradient(x_t, u_hat)[:, :-1]
+        return eq.f(x_t, u_breve + u_hat, eq.sigma(x_t) * grad_x + z_breve) - eq.f(x_t, u_hat, eq.sigma(x_t) * grad_x)
+
+    def g(self, x_t):
+        return (self.equation.g(x_t) - self.GP.predict(x_t))[:, 0]   # :49-63
+
+    def approx_parameters(self, rhomax):
+        return tables.approx_parameters(int(rhomax), float(self.T))
+
+    def _solve(self, n, par, x_t):
+        uz, uhat, was_numpy = self._engine.solve(int(n), int(par), x_t)
+        self.evaluation_counter += self._engine.evaluation_increment(int(n), int(par))
+        return uz, uhat, was_numpy
+
+    def uz_solve(self, n, rho, x_t):
+        '''solvers/ScaSML.py:149-284.'''
+        uz, _, was_numpy = self._solve(n, rho, x_t)
+        return deliver(uz, was_numpy)
+
+    def u_solve(self, n, rho, x_t):
+        '''u_hat + u_breve, solvers/ScaSML.py:286-304.'''
+        uz, uhat, was_numpy = self._solve(n, rho, x_t)
+        return deliver(uz[:, 0:1] + uhat[:, None], was_numpy)

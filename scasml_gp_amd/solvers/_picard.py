@@ -1,0 +1,103 @@
+"""Host driver shared by the four solver classes: builds the static schedule, owns the
+device buffers and issues the HIP kernels through the C ABI.  No numerics happen here."""
+import ctypes as C
+
+import numpy as np
+
+from .. import _lib, tables
+
+# cap on the point buffer of one ScaSML chunk (bytes); larger batches are walked in root chunks
+POINT_BUFFER_BYTES = 24 << 30
+
+
+def _as_device(x_t, torch):
+    """-> (float32 contiguous CUDA tensor, was_numpy)."""
+    if isinstance(x_t, torch.Tensor):
+        return x_t.to(device="cuda", dtype=torch.float32).contiguous(), False
+    arr = np.ascontiguousarray(np.asarray(x_t), dtype=np.float32)
+    return torch.from_numpy(arr).cuda(), True
+
+
+class PicardEngine:
+    def __init__(self, equation, variant, gp=None, seed=0):
+        if getattr(equation, "eq_id", None) is None:
+            raise NotImplementedError("no HIP kernels for equation %s (eq_id unset)" % type(equation).__name__)
+        self.equation = equation
+        self.variant = variant
+        self.gp = gp
+        self.seed = int(seed)
+        self.calls = 0                 # Philox stream id: advances once per uz_solve (E-9)
+        self.last_timing = None
+        self._plans = {}
+
+    def plan(self, n, par):
+        key = (n, par)
+        if key not in self._plans:
+            self._plans[key] = tables.build_plan(self.variant, n, par, float(self.equation.T),
+                                                 stale_delta_t=self.gp is None)
+        return self._plans[key]
+
+    def problem(self):
+        eq = self.equation
+        p = _lib.Problem()
+        p.d, p.eq_id = eq.n_input - 1, eq.eq_id
+        p.T, p.mu, p.sigma = float(eq.T), float(eq.mu()), float(eq.sigma())
+        p.clip = float(eq.uncertainty if self.gp is not None else eq.norm_estimation)
+        return p
+
+    def solve(self, n, par, x_t, root0=0, rank=0, world=1, stream_id=None):
+        """-> (uz (B, 1+d), u_hat (B,) or None) as torch CUDA tensors, plus was_numpy."""
+        torch = _lib.require_gpu()
+        lib = _lib.load()
+        x, was_numpy = _as_device(x_t, torch)
+        d = self.equation.n_input - 1
+        if x.dim() != 2 or x.shape[1] != d + 1:
+            raise ValueError("x_t must have shape (batch, %d), got %s" % (d + 1, tuple(x.shape)))
+        B = x.shape[0]
+        plan, prob = self.plan(n, par), self.problem()
+        rng = _lib.Rng(self.seed, self.calls if stream_id is None else stream_id, root0, rank, world)
+        if stream_id is None:
+            self.calls += 1
+        out = torch.empty((B, d + 1), dtype=torch.float32, device="cuda")
+        s = _lib.stream_ptr()
+        if self.gp is None:
+            _lib.check(lib.scasml_picard_tree(C.byref(prob), C.byref(plan), _lib.MODE_MLP, _lib.ptr(x), B, rng,
+                                              None, None, _lib.ptr(out), None, s), "picard_tree")
+            return out, None, was_numpy
+        model = self.gp._device_model()
+        uhat = torch.empty((B,), dtype=torch.float32, device="cuda")
+        ppr = int(lib.scasml_points_per_root(C.byref(plan)))
+        kp = int(lib.scasml_point_stride(d))
+        chunk = max(1, min(B, POINT_BUFFER_BYTES // (ppr * kp * 4)))
+        pts = torch.empty((chunk * ppr, kp), dtype=torch.float32, device="cuda")
+        if world > 1:
+            pts.zero_()                    # rows of un-owned units are never written
+        vals = torch.empty((chunk * ppr, 4), dtype=torch.float32, device="cuda")
+        for b0 in range(0, B, chunk):
+            nb = min(chunk, B - b0)
+            rng_c = _lib.Rng(rng.seed, rng.stream, root0 + b0, rank, world)
+            xc = x[b0:b0 + nb]
+            if n > 0:
+                _lib.check(lib.scasml_picard_tree(C.byref(prob), C.byref(plan), _lib.MODE_GENERATE, _lib.ptr(xc), nb, rng_c,
+                                                  _lib.ptr(pts), None, None, None, s), "picard_tree(generate)")
+                _lib.check(lib.scasml_gp_eval(C.byref(model), _lib.ptr(pts), nb * ppr, _lib.ptr(vals), None, s), "gp_eval")
+                _lib.check(lib.scasml_picard_tree(C.byref(prob), C.byref(plan), _lib.MODE_ACCUMULATE, _lib.ptr(xc), nb, rng_c,
+                                                  None, _lib.ptr(vals), _lib.ptr(out[b0:b0 + nb]), _lib.ptr(uhat[b0:b0 + nb]), s),
+                           "picard_tree(accumulate)")
+            else:                          # n == 0: zeros (ScaSML.py:217-219); u_hat still needed by u_solve
+                out[b0:b0 + nb].zero_()
+                uhat[b0:b0 + nb] = self.gp._predict_device(xc)[:, 0]
+        return out, uhat, was_numpy
+
+    def finalize_partials(self, summed):
+        """Clip all-reduced partial sums of a sample-sharded solve (MLP.py:272-274)."""
+        lib = _lib.load()
+        _lib.check(lib.scasml_clip(_lib.ptr(summed), summed.numel(), self.problem().clip, _lib.stream_ptr()), "clip")
+        return summed
+
+    def evaluation_increment(self, n, par):
+        return tables.reference_evaluation_count(self.variant, n, par, self.gp is not None, float(self.equation.T))
+
+
+def deliver(t, was_numpy):
+    return t.cpu().numpy() if was_numpy else t

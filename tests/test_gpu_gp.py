@@ -1,0 +1,101 @@
+"""GP kernels against the float64 oracle: Gram blocks, Cholesky / triangular solves, Newton
+training (right_vector), fused evaluation (u_hat, div, eps_PDE, dt, Lap) and the full gradient."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(d, nd, nb, seed=0):
+    from oracle.equation import GradDependentNonlinear, sample_points
+    from oracle.gp import OracleGP
+    from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
+    from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
+    dom, bdy = sample_points(np.random.default_rng(seed), d, nd, nb)
+    return GP_Grad_Dependent_Nonlinear(Grad_Dependent_Nonlinear(d + 1)), OracleGP(GradDependentNonlinear(d + 1)), dom, bdy
+
+
+@pytest.mark.parametrize("d,nd,nb", [(5, 40, 9), (20, 70, 25), (100, 33, 7)])
+def test_gram_matches_oracle(d, nd, nb):
+    gp, ora, dom, bdy = _setup(d, nd, nb)
+    K = gp.kernel_phi_phi(dom, bdy).cpu().numpy()
+    want = ora.kernel_phi_phi(dom, bdy) + ora.nugget * np.eye(4 * nd + nb)
+    scale = np.abs(want).max()
+    assert np.abs(K - want).max() <= 1e-11 * scale
+    L = gp.cholesky_phi_phi_perturb.cpu().numpy()
+    assert np.allclose(np.triu(L, 1), 0) and np.abs(L @ L.T - want).max() <= 1e-10 * scale
+
+
+def test_cholesky_and_trsm_against_numpy():
+    import torch
+    from scasml_gp_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    M = 160
+    R = rng.standard_normal((M, M))
+    A = R @ R.T + M * np.eye(M)
+    At = torch.from_numpy(A.copy()).cuda()
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _lib.check(lib.scasml_cholesky(_lib.ptr(At), M, 0.5, _lib.ptr(info), _lib.stream_ptr()), "chol")
+    Lw = np.linalg.cholesky(A + 0.5 * np.eye(M))
+    assert int(info.item()) == 0 and np.abs(At.cpu().numpy() - Lw).max() < 1e-10
+    for nrhs in (1, 37, 160):
+        Bm = rng.standard_normal((M, nrhs))
+        for trans, ref in ((0, np.linalg.solve(Lw, Bm)), (1, np.linalg.solve(Lw.T, Bm))):
+            Bt = torch.from_numpy(Bm.copy()).cuda()
+            _lib.check(lib.scasml_trsm_lower(_lib.ptr(At), M, _lib.ptr(Bt), nrhs, trans, _lib.stream_ptr()), "trsm")
+            assert np.abs(Bt.cpu().numpy() - ref).max() < 1e-9
+    # not positive definite -> info reports the pivot, no exception from the C ABI
+    Bad = torch.from_numpy(-np.eye(32)).cuda()
+    _lib.check(lib.scasml_cholesky(_lib.ptr(Bad), 32, 0.0, _lib.ptr(info), _lib.stream_ptr()), "chol")
+    assert int(info.item()) == 1
+    # unsupported order is an error code + message, not a crash
+    rc = lib.scasml_cholesky(_lib.ptr(At), 33, 0.0, _lib.ptr(info), _lib.stream_ptr())
+    assert rc == -2 and b"multiple of 32" in lib.scasml_last_error()
+
+
+@pytest.mark.parametrize("d,nd,nb", [(4, 30, 10), (20, 120, 40)])
+def test_training_matches_oracle(d, nd, nb):
+    gp, ora, dom, bdy = _setup(d, nd, nb, seed=2)
+    sol_dom = gp.GPsolver(dom, bdy, GN_steps=20)
+    want_dom = ora.GPsolver(dom, bdy, GN_steps=20)
+    assert len(gp.loss_history) == len(ora.loss_history)
+    assert np.allclose(gp.loss_history, ora.loss_history, rtol=1e-8)
+    rv, rvo = gp.right_vector, ora.right_vector
+    assert rv.shape == (4 * nd + nb, 1)
+    assert np.abs(rv - rvo).max() <= 1e-7 * np.abs(rvo).max()
+    assert np.allclose(sol_dom, want_dom, atol=2e-5)
+
+
+@pytest.mark.parametrize("d,nd,nb,n_inf", [(4, 30, 10, 100), (20, 120, 40, 1000), (100, 50, 14, 77), (250, 40, 8, 40), (63, 31, 1, 65)])
+def test_fused_evaluation_and_gradient_match_oracle(d, nd, nb, n_inf):
+    """float32 MFMA + float32 epilogue vs float64: errors scale with sum_j |kappa_j c_j|, so the
+    tolerance is relative to that magnitude (1e-5) rather than to the (cancelling) result."""
+    import torch
+    gp, ora, dom, bdy = _setup(d, nd, nb, seed=3)
+    ora.GPsolver(dom, bdy, GN_steps=10)
+    gp.load_right_vector(dom, bdy, ora.right_vector)
+    X = np.random.default_rng(4).uniform(-0.6, 0.6, (n_inf, d + 1)).astype(np.float32)
+    X[:, -1] = np.abs(X[:, -1])
+    mag = (np.abs(ora._features("I", X)) @ np.abs(ora.right_vector))[:, 0] + 1e-3
+    u = gp.predict(X)[:, 0]
+    assert np.all(np.abs(u - ora.predict(X)[:, 0]) <= 2e-5 * mag)
+    eps = gp.compute_PDE_loss(X)[:, 0]
+    dt, div, lap = ora.pde_parts(X)
+    a = ora.a
+    magp = mag * (1 + a * (1 + d))                      # derivative features carry factors of a, a*d
+    assert np.all(np.abs(eps - ora.compute_PDE_loss(X)[:, 0]) <= 2e-5 * magp)
+    pts, _ = gp._points_device(X)
+    out4 = gp._eval_device(pts).cpu().numpy()
+    assert np.all(np.abs(out4[:, 1] - div[:, 0]) <= 2e-5 * magp)
+    assert np.all(np.abs(out4[:, 3] - dt[:, 0]) <= 2e-5 * magp)
+    g = gp.compute_gradient(X)
+    go = ora.compute_gradient(X)
+    assert g.shape == (n_inf, d + 1)
+    assert np.all(np.abs(g - go) <= 2e-5 * magp[:, None])
+    assert np.all(np.abs(g[:, :-1].sum(1) - out4[:, 1]) <= 4e-5 * magp * np.sqrt(d))
+    # torch in -> torch out, empty batch
+    assert isinstance(gp.predict(torch.from_numpy(X).cuda()), torch.Tensor)
+    assert gp.predict(X[:0]).shape == (0, 1)
