@@ -74,6 +74,10 @@ def load():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # torch bundles its own libamdhip64; import it FIRST so this library binds to the same HIP
+    # runtime instance (loading the system copy first leaves two runtimes in one process and
+    # ours then sees no device).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ScasmlError(
             "libscasml_hip.so is not built (%s missing). Build it with "

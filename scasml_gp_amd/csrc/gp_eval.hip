@@ -309,9 +309,9 @@ extern "C" int scasml_gp_pack(int32_t d, float a, const float *x_dom, int32_t n_
 
 extern "C" int scasml_gp_eval(const scasml_gp_model *m, const float *points, int64_t n_inf, float *out4, float *lap,
                               void *stream) {
-    if (int rc = check_model(m, "gp_eval")) return rc;
-    if (n_inf < 0 || (n_inf > 0 && (!points || !out4))) return fail(SCASML_ERR_ARG, "gp_eval: bad argument");
     if (n_inf == 0) return 0;
+    if (int rc = check_model(m, "gp_eval")) return rc;
+    if (n_inf < 0 || !points || !out4) return fail(SCASML_ERR_ARG, "gp_eval: bad argument");
     GpArgs g;
     g.points = points;
     g.colloc_frag = m->colloc_frag;
@@ -340,9 +340,9 @@ extern "C" int scasml_gp_eval(const scasml_gp_model *m, const float *points, int
 }
 
 extern "C" int scasml_gp_gradient(const scasml_gp_model *m, const float *points, int64_t n_inf, float *grad, void *stream) {
-    if (int rc = check_model(m, "gp_gradient")) return rc;
-    if (n_inf < 0 || (n_inf > 0 && (!points || !grad))) return fail(SCASML_ERR_ARG, "gp_gradient: bad argument");
     if (n_inf == 0) return 0;
+    if (int rc = check_model(m, "gp_gradient")) return rc;
+    if (n_inf < 0 || !points || !grad) return fail(SCASML_ERR_ARG, "gp_gradient: bad argument");
     const int64_t blocks = (n_inf + 3) / 4;
     if (blocks > 0x7FFFFFFF) return fail(SCASML_ERR_UNSUPPORTED, "gp_gradient: too many points");
     const size_t lds = 4 * (m->kp + 64) * sizeof(float);

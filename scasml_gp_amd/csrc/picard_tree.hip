@@ -312,9 +312,10 @@ extern "C" int32_t scasml_point_stride(int32_t d) { return (d + 1 + 7) / 8 * 8; 
 extern "C" int scasml_picard_tree(const scasml_problem *prob, const scasml_plan *plan, int mode, const float *x_t,
                                   int64_t B, scasml_rng rng, float *points, const float *gp_vals, float *out_uz,
                                   float *out_uhat, void *stream) {
-    if (!prob || !plan || !x_t) return fail(SCASML_ERR_ARG, "picard_tree: null argument");
+    if (!prob || !plan) return fail(SCASML_ERR_ARG, "picard_tree: null argument");
     if (B < 0) return fail(SCASML_ERR_ARG, "picard_tree: negative batch");
     if (B == 0) return 0;
+    if (!x_t) return fail(SCASML_ERR_ARG, "picard_tree: x_t is null");
     if (prob->d < 1 || prob->d > SCASML_MAX_DIM)
         return fail(SCASML_ERR_UNSUPPORTED, "picard_tree: d=%d outside 1..%d", prob->d, SCASML_MAX_DIM);
     if (prob->eq_id != SCASML_EQ_GRAD_DEPENDENT_NONLINEAR)
