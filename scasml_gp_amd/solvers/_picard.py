@@ -27,8 +27,35 @@ class PicardEngine:
         self.gp = gp
         self.seed = int(seed)
         self.calls = 0                 # Philox stream id: advances once per uz_solve (E-9)
-        self.last_timing = None
+        self.profile = False           # bench.py: bracket every launch with HIP events on the launch stream
+        self._events = []
         self._plans = {}
+
+    def __getstate__(self):               # deep-copyable (tests/ComputingBudget.py:138): drop caches and events
+        st = dict(self.__dict__)
+        st["_plans"], st["_events"] = {}, []
+        return st
+
+    def _timed(self, name, fn):
+        if not self.profile:
+            return fn()
+        torch = _lib.require_gpu()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn()
+        e1.record()
+        self._events.append((name, e0, e1))
+        return rc
+
+    def collect_kernel_ms(self):
+        """Average HIP-event duration per kernel name since profiling was switched on."""
+        torch = _lib.require_gpu()
+        torch.cuda.synchronize()
+        acc = {}
+        for name, e0, e1 in self._events:
+            acc.setdefault(name, []).append(e0.elapsed_time(e1))
+        self._events = []
+        return {k: sum(v) / len(v) for k, v in acc.items()}
 
     def plan(self, n, par):
         key = (n, par)
@@ -61,8 +88,8 @@ class PicardEngine:
         out = torch.empty((B, d + 1), dtype=torch.float32, device="cuda")
         s = _lib.stream_ptr()
         if self.gp is None:
-            _lib.check(lib.scasml_picard_tree(C.byref(prob), C.byref(plan), _lib.MODE_MLP, _lib.ptr(x), B, rng,
-                                              None, None, _lib.ptr(out), None, s), "picard_tree")
+            _lib.check(self._timed("picard_mlp", lambda: lib.scasml_picard_tree(
+                C.byref(prob), C.byref(plan), _lib.MODE_MLP, _lib.ptr(x), B, rng, None, None, _lib.ptr(out), None, s)), "picard_tree")
             return out, None, was_numpy
         model = self.gp._device_model()
         uhat = torch.empty((B,), dtype=torch.float32, device="cuda")
@@ -78,12 +105,15 @@ class PicardEngine:
             rng_c = _lib.Rng(rng.seed, rng.stream, root0 + b0, rank, world)
             xc = x[b0:b0 + nb]
             if n > 0:
-                _lib.check(lib.scasml_picard_tree(C.byref(prob), C.byref(plan), _lib.MODE_GENERATE, _lib.ptr(xc), nb, rng_c,
-                                                  _lib.ptr(pts), None, None, None, s), "picard_tree(generate)")
-                _lib.check(lib.scasml_gp_eval(C.byref(model), _lib.ptr(pts), nb * ppr, _lib.ptr(vals), None, s), "gp_eval")
-                _lib.check(lib.scasml_picard_tree(C.byref(prob), C.byref(plan), _lib.MODE_ACCUMULATE, _lib.ptr(xc), nb, rng_c,
-                                                  None, _lib.ptr(vals), _lib.ptr(out[b0:b0 + nb]), _lib.ptr(uhat[b0:b0 + nb]), s),
-                           "picard_tree(accumulate)")
+                ob, ub = out[b0:b0 + nb], uhat[b0:b0 + nb]
+                _lib.check(self._timed("picard_generate", lambda: lib.scasml_picard_tree(
+                    C.byref(prob), C.byref(plan), _lib.MODE_GENERATE, _lib.ptr(xc), nb, rng_c,
+                    _lib.ptr(pts), None, None, None, s)), "picard_tree(generate)")
+                _lib.check(self._timed("gp_eval", lambda: lib.scasml_gp_eval(
+                    C.byref(model), _lib.ptr(pts), nb * ppr, _lib.ptr(vals), None, s)), "gp_eval")
+                _lib.check(self._timed("picard_accumulate", lambda: lib.scasml_picard_tree(
+                    C.byref(prob), C.byref(plan), _lib.MODE_ACCUMULATE, _lib.ptr(xc), nb, rng_c,
+                    None, _lib.ptr(vals), _lib.ptr(ob), _lib.ptr(ub), s)), "picard_tree(accumulate)")
             else:                          # n == 0: zeros (ScaSML.py:217-219); u_hat still needed by u_solve
                 out[b0:b0 + nb].zero_()
                 uhat[b0:b0 + nb] = self.gp._predict_device(xc)[:, 0]
