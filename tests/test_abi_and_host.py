@@ -1,0 +1,131 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every symbol
+include/scasml_hip.h declares (no compute without a GPU), struct layouts agree, argument errors
+come back as codes + messages, the host tables / schedule match the oracle, and the solvers fail
+loudly instead of falling back when there is no GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from scasml_gp_amd import _lib, tables
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from scasml_gp_amd import _build
+    _build.build_library()
+    return _lib.load()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    header = open(os.path.join(ROOT, "include", "scasml_hip.h")).read()
+    declared = set(re.findall(r"\b(scasml_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name)
+
+
+def test_struct_layouts_and_version(lib):
+    assert lib.scasml_abi_version() == 1
+    for which, st in enumerate((_lib.Problem, _lib.Rng, _lib.Term, _lib.Plan, _lib.GpModel)):
+        assert lib.scasml_sizeof(which) == C.sizeof(st)
+    assert C.sizeof(_lib.Plan) < 3900          # travels by value in the kernarg segment (4 KiB)
+    assert lib.scasml_point_stride(100) == 104 and lib.scasml_point_stride(20) == 24 and lib.scasml_point_stride(7) == 8
+
+
+def test_argument_errors_are_codes_not_crashes(lib):
+    plan = tables.build_plan("quad", 2, 2, 0.5, True)
+    prob = _lib.Problem(300, 0, 0.5, -0.1, 0.25, 1.0)            # d too large
+    rc = lib.scasml_picard_tree(C.byref(prob), C.byref(plan), 0, C.c_void_p(8), 4, _lib.Rng(0, 0, 0, 0, 1),
+                                None, None, C.c_void_p(8), None, None)
+    assert rc == -2 and b"d=300" in lib.scasml_last_error()
+    prob.d = 20
+    rc = lib.scasml_picard_tree(C.byref(prob), C.byref(plan), 0, C.c_void_p(8), 4, _lib.Rng(0, 0, 0, 2, 2),
+                                None, None, C.c_void_p(8), None, None)
+    assert rc == -1 and b"rank" in lib.scasml_last_error()
+    assert lib.scasml_picard_tree(C.byref(prob), C.byref(plan), 0, None, 0, _lib.Rng(0, 0, 0, 0, 1), None, None, None, None, None) == 0
+    assert lib.scasml_points_per_root(C.byref(plan)) == 29
+    assert lib.scasml_trsm_lower(C.c_void_p(8), 33, C.c_void_p(8), 1, 0, None) == -2
+
+
+@pytest.mark.parametrize("variant,n,par", [("quad", 1, 1), ("quad", 2, 2), ("quad", 3, 3), ("quad", 4, 4), ("quad", 2, 4),
+                                            ("fh", 2, 3), ("fh", 3, 3), ("fh", 4, 3), ("fh", 3, 2)])
+def test_schedule_matches_oracle_counts(variant, n, par):
+    from oracle.mlp import reference_counts, site_count
+    from oracle.tables import approx_parameters
+    tab = approx_parameters(par) if variant == "quad" else None
+    plan = tables.build_plan(variant, n, par, 0.5, True)
+    assert tables.executed_path_steps(plan) == site_count(variant, n, par, tab)
+    assert tables.reference_path_steps(variant, n, par) == reference_counts(variant, n, par, tab)["path_steps"]
+    for np_ in range(1, n + 1):
+        assert plan.sites[np_] == site_count(variant, np_, par, tab)
+
+
+@pytest.mark.parametrize("rho", [1, 2, 3, 4, 5])
+def test_host_tables_equal_oracle_tables(rho):
+    from oracle.tables import approx_parameters
+    for a, b in zip(tables.approx_parameters(rho), approx_parameters(rho)):
+        assert np.array_equal(np.nan_to_num(a, nan=-7.0), np.nan_to_num(b, nan=-7.0))
+
+
+def test_stale_delta_t_schedule():
+    """MLP.py:249 reuses the previous delta_t for the '+' term; ScaSML.py:253 recomputes it."""
+    mlp = tables.build_plan("quad", 3, 3, 0.5, True)
+    sca = tables.build_plan("quad", 3, 3, 0.5, False)
+    t0, t1, t2 = (mlp.term[3][l] for l in range(3))
+    assert list(t0.dplus)[:t0.q] == [1.0] * t0.q                       # level 0 never updates delta_t
+    assert t1.dplus[0] == 1.0 and t1.dplus[1] == t1.cfrac[0] and t1.dplus[2] == t1.cfrac[1]
+    assert t2.dplus[0] == t1.cfrac[t1.q - 1]                           # carried over from the previous level
+    for l in range(3):
+        s = sca.term[3][l]
+        assert list(s.dplus)[:s.q] == list(s.cfrac)[:s.q]
+
+
+def test_reference_evaluation_counter_formula():
+    # MLP n=rho=1: root call adds Mg=1 and, at l=0, per node k (q=2): child call (Mg[0,0]=1) + MC_f=1
+    assert tables.reference_evaluation_count("quad", 1, 1, False) == 1 + 2 * (1 + 1)
+    # ScaSML adds 1 per f and per g call on top (ScaSML.py:41,59)
+    assert tables.reference_evaluation_count("quad", 1, 1, True) == (1 + 1) + 2 * ((1 + 1) + 1 + 1)
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
+    from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
+    from scasml_gp_amd.solvers.MLP import MLP
+    eq = Grad_Dependent_Nonlinear(11)
+    with pytest.raises(_lib.ScasmlError):
+        MLP(eq).u_solve(1, 1, np.zeros((2, 11), dtype=np.float16))
+    with pytest.raises(_lib.ScasmlError):
+        GP_Grad_Dependent_Nonlinear(eq).GPsolver(np.zeros((4, 11)), np.zeros((2, 11)))
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "scasml_gp_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+
+
+def test_equation_surface_and_sampler():
+    from oracle.equation import GradDependentNonlinear
+    from scasml_gp_amd.equations.equations import Equation, Grad_Dependent_Nonlinear
+    eq = Grad_Dependent_Nonlinear(21)
+    assert isinstance(eq, Equation) and eq.uncertainty == 0.1 and eq.norm_estimation == 1
+    np.random.seed(3)
+    dom, bdy = eq.generate_data(50, 20)
+    assert dom.dtype == np.float16 and dom.shape == (50, 21) and bdy.shape == (20, 21)
+    assert (np.abs(bdy[:, :-1]).max(axis=1) == 0.5).all() and (bdy[:, -1] >= 0).all() and (bdy[:, -1] <= 0.5).all()
+    ora = GradDependentNonlinear(21)
+    assert np.allclose(eq.exact_solution(dom), ora.exact_solution(dom)) and np.allclose(eq.g(bdy), ora.g(bdy))
+    u, z = np.random.rand(50, 1), np.random.rand(50, 20)
+    assert np.allclose(eq.f(dom, u, z), ora.f(dom, u, z)) and eq.mu() == ora.mu()
+    with pytest.raises(NotImplementedError):
+        Equation(3).f(None, None, None)
