@@ -129,7 +129,7 @@ typedef struct {
     float sigma_eq;              /* equation sigma (models/GP.py:748)                        */
     const float *colloc;         /* n_pad x kp   collocation points, domain first, zero pad  */
     const float *colloc_frag;    /* the same, in MFMA A-fragment order [tile][kp/8][64][4]   */
-    const float *coef;           /* 8 x n_pad    (|y|^2, a*sum y, a*t_y, c0, cL, ct, cS, 0)  */
+    const float *coef;           /* n_pad x 8    (|y|^2, a*sum y, a*t_y, c0, cL, ct, cS, 0)  */
 } scasml_gp_model;
 
 /* Build `coef` and the padded `colloc` from points and right_vector (models/GP.py:599-600):

@@ -31,7 +31,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct GpArgs {
     const float *points;       // n_inf x kp
     const float *colloc_frag;  // [n_tiles][NK4][64][4]
-    const float *coef;         // [8][n_pad]
+    const float *coef;         // [n_pad][8]
     float4 *out4;              // n_inf x (u, div, eps, dt)
     float *lap;                // n_inf or null
     int64_t n_inf;
@@ -39,14 +39,113 @@ struct GpArgs {
     float a, sigma;
 };
 
-// NK4 = kp / 8 float4 per lane per row; PT = point tiles (of 32) per wave
+// NK4 = kp / 8 float4 per lane per row; PT = point tiles (of 32) per wave.
+//
+// Workgroup = 8 waves (512 threads); wave w and wave w+4 share a SIMD (MI355X_MICROARCH.md "Two waves
+// per SIMD").  Per collocation tile the workgroup stages [NK4 KiB of A fragments | 1 KiB of
+// coefficients] into one of three LDS slots with global_load_lds (16 B per lane, lane-linear image =
+// the pre-packed fragment order), one tile ahead, and meets at ONE barrier per tile.  The two SIMD
+// partners run half a tile apart: waves 0-3 do MFMA(t) then epilogue(t); waves 4-7 do epilogue(t-1)
+// then MFMA(t), keeping their accumulators across the barrier -- so on every SIMD one wave's VALU
+// epilogue runs under the other's MFMAs and the matrix pipe stays fed.
+struct GpStageView {
+    const float4 *y;    // [NK4][64] A fragments of one collocation tile
+    const float *coef;  // [32 rows][8]
+};
+
+template <int NK4>
+__device__ __forceinline__ constexpr int gp_stage_floats() { return NK4 * 256 + 256; }
+
 template <int NK4, int PT>
-__global__ __launch_bounds__(256, 2) void gp_eval_kernel(const GpArgs g) {
-    const int lane = threadIdx.x & 63;
+__device__ __forceinline__ void gp_mfma_tile(const GpStageView &st, const float4 (&xf)[PT][NK4], f32x16 (&acc)[PT], int lane) {
+#pragma unroll
+    for (int p = 0; p < PT; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
+    // one-deep register prefetch of the A fragment: the ds_read of step v+1 is issued before the 4*PT
+    // MFMAs of step v (>= 256 cycles of cover); the scheduling barrier keeps the compiler from hoisting
+    // all NK4 reads (4*NK4 VGPRs) to the top.
+    float4 y = st.y[lane];
+#pragma unroll
+    for (int v = 0; v < NK4; ++v) {
+        float4 yn = y;
+        if (v + 1 < NK4) yn = st.y[(v + 1) * 64 + lane];
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(y.x, xf[p][v].x, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(y.y, xf[p][v].y, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(y.z, xf[p][v].z, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(y.w, xf[p][v].w, acc[p], 0, 0, 0);
+        }
+        y = yn;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+struct GpConsts {
+    float a, a2, ad, kexp, dF;
+};
+
+// C row = (r&3) + 8*(r>>2) + 4*half, column = lane & 31.  Coefficients of a collocation row are 8
+// consecutive floats (|y|^2, a*sum y, a*t_y, c0, cL, ct, cS, 0): two broadcast ds_read_b128 per row.
+template <int PT>
+__device__ __forceinline__ void gp_epilogue_tile(const GpStageView &st, const f32x16 (&acc)[PT], const GpConsts &c, int half,
+                                                 const float (&nx)[PT], const float (&sx)[PT], const float (&tx)[PT],
+                                                 float (&au)[PT], float (&at)[PT], float (&ad)[PT], float (&al)[PT]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        // one row (PT independent chains) per scheduling region: more ILP only costs VGPRs, and the
+        // point tile must stay resident in registers across the epilogue
+        __builtin_amdgcn_sched_barrier(0);
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float4 q0 = *reinterpret_cast<const float4 *>(st.coef + row * 8);
+        const float4 q1 = *reinterpret_cast<const float4 *>(st.coef + row * 8 + 4);
+        const float vny = q0.x, vsy = q0.y, vty = q0.z, vc0 = q0.w, vcL = q1.x, vct = q1.y, vcS = q1.z;
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            const float dot = acc[p][r];
+            const float r2 = fmaf(-2.0f, dot, nx[p] + vny);
+            const float pp = tx[p] - vty;                  // a * r_t
+            const float ss = sx[p] - vsy;                  // a * S
+            const float kap = __builtin_amdgcn_exp2f(r2 * c.kexp);
+            const float L = fmaf(-pp, pp, fmaf(c.a2, r2, -c.ad));   // a^2 (r2 - r_t^2) - a d
+            const float E = fmaf(vcS, ss, fmaf(vct, pp, fmaf(vcL, L, vc0)));
+            au[p] = fmaf(kap, E, au[p]);
+            at[p] = fmaf(kap, fmaf(-pp, E, c.a * vct), at[p]);
+            const float dv = fmaf(2.0f * vcL, ss, c.dF * vcS);
+            ad[p] = fmaf(kap, fmaf(-ss, E, c.a * dv), ad[p]);
+            const float lv = fmaf(vcL, fmaf(2.0f, L, c.ad), vcS * ss);
+            al[p] = fmaf(kap, fmaf(L, E, -2.0f * c.a * lv), al[p]);
+        }
+    }
+}
+
+template <int NK4, int PT>
+__global__ __launch_bounds__(512, 2) void gp_eval_kernel(const GpArgs g) {
+    constexpr int STAGE = gp_stage_floats<NK4>();       // floats per LDS slot
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // 3 slots
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int col = lane & 31, half = lane >> 5;
-    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int64_t p0 = wave * (32 * PT);
-    if (p0 >= g.n_inf) return;  // whole wave idle (uniform)
+    // the half-tile-late SIMD partner; readfirstlane makes the role a scalar (provably wave-uniform)
+    // condition, so the barriers inside the two role loops are never reached under a partial EXEC
+    const bool late = __builtin_amdgcn_readfirstlane(wv) >= 4;
+    const int64_t p0 = ((int64_t)blockIdx.x * 8 + wv) * (32 * PT);
+    const int n_tiles = g.n_pad / 32;
+
+    // ---- stage a collocation tile: wave w copies fragment rows v = w, w+8, ..; wave (NK4 % 8) the coefficients
+    auto stage = [&](int tile, int slot) {
+        float *dst = lds + slot * STAGE;
+        const float *src = g.colloc_frag + (int64_t)tile * NK4 * 256;
+        for (int v = wv; v < NK4; v += 8)
+            __builtin_amdgcn_global_load_lds(src + v * 256 + lane * 4, dst + v * 256, 16, 0, 0);
+        if (wv == (NK4 & 7))
+            __builtin_amdgcn_global_load_lds(g.coef + (int64_t)tile * 256 + lane * 4, dst + NK4 * 256, 16, 0, 0);
+    };
+    auto view = [&](int slot) {
+        const float *b = lds + slot * STAGE;
+        return GpStageView{reinterpret_cast<const float4 *>(b), b + NK4 * 256};
+    };
+    stage(0, 0);
 
     // ---- this wave's point tiles -> registers, plus |x|^2, a*sum x, a*t per point ------------
     float4 xf[PT][NK4];
@@ -78,73 +177,35 @@ __global__ __launch_bounds__(256, 2) void gp_eval_kernel(const GpArgs g) {
         sx[p] = g.a * ps;
         tx[p] = g.a * pt;
     }
-
     float au[PT], at[PT], ad[PT], al[PT];
 #pragma unroll
     for (int p = 0; p < PT; ++p) au[p] = at[p] = ad[p] = al[p] = 0.0f;
+    GpConsts c;
+    c.a = g.a;
+    c.a2 = g.a * g.a;
+    c.ad = g.a * (float)g.d;
+    c.kexp = -0.5f * g.a * 1.44269504088896341f;  // exp(-a r2/2) = exp2(r2 * kexp)
+    c.dF = (float)g.d;
 
-    const float a = g.a;
-    const float a2 = a * a;
-    const float ad_ = a * (float)g.d;
-    const float kexp = -0.5f * a * 1.44269504088896341f;  // exp(-a r2/2) = exp2(r2 * kexp)
-    const int n_tiles = g.n_pad / 32;
-    const float4 *frag = reinterpret_cast<const float4 *>(g.colloc_frag) + lane;
-
-    for (int jt = 0; jt < n_tiles; ++jt) {
-        // ---- x.y for a 32 (collocation) x 32 (points) tile, per point tile ---------------------
-        f32x16 acc[PT];
-#pragma unroll
-        for (int p = 0; p < PT; ++p)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
-        const float4 *yt = frag + (int64_t)jt * NK4 * 64;
-#pragma unroll
-        for (int v = 0; v < NK4; ++v) {
-            const float4 y = yt[v * 64];
-#pragma unroll
-            for (int p = 0; p < PT; ++p) {
-                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(y.x, xf[p][v].x, acc[p], 0, 0, 0);
-                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(y.y, xf[p][v].y, acc[p], 0, 0, 0);
-                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(y.z, xf[p][v].z, acc[p], 0, 0, 0);
-                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(y.w, xf[p][v].w, acc[p], 0, 0, 0);
-            }
+    f32x16 acc[PT];
+    __syncthreads();  // tile 0 has landed (the barrier drains the LDS-DMA: vmcnt(0))
+    if (!late) {
+        for (int jt = 0; jt < n_tiles; ++jt) {
+            if (jt + 1 < n_tiles) stage(jt + 1, (jt + 1) % 3);
+            gp_mfma_tile<NK4, PT>(view(jt % 3), xf, acc, lane);
+            gp_epilogue_tile<PT>(view(jt % 3), acc, c, half, nx, sx, tx, au, at, ad, al);
+            __syncthreads();
         }
-        // ---- epilogue: C row = (r&3) + 8*(r>>2) + 4*half, column = lane & 31 -------------------
-#pragma unroll
-        for (int grp = 0; grp < 4; ++grp) {
-            const int j0 = jt * 32 + 8 * grp + 4 * half;
-            const float4 ny = *reinterpret_cast<const float4 *>(g.coef + 0 * g.n_pad + j0);
-            const float4 sy = *reinterpret_cast<const float4 *>(g.coef + 1 * g.n_pad + j0);
-            const float4 ty = *reinterpret_cast<const float4 *>(g.coef + 2 * g.n_pad + j0);
-            const float4 c0 = *reinterpret_cast<const float4 *>(g.coef + 3 * g.n_pad + j0);
-            const float4 cL = *reinterpret_cast<const float4 *>(g.coef + 4 * g.n_pad + j0);
-            const float4 ct = *reinterpret_cast<const float4 *>(g.coef + 5 * g.n_pad + j0);
-            const float4 cS = *reinterpret_cast<const float4 *>(g.coef + 6 * g.n_pad + j0);
-            const float vny[4] = {ny.x, ny.y, ny.z, ny.w}, vsy[4] = {sy.x, sy.y, sy.z, sy.w};
-            const float vty[4] = {ty.x, ty.y, ty.z, ty.w}, vc0[4] = {c0.x, c0.y, c0.z, c0.w};
-            const float vcL[4] = {cL.x, cL.y, cL.z, cL.w}, vct[4] = {ct.x, ct.y, ct.z, ct.w};
-            const float vcS[4] = {cS.x, cS.y, cS.z, cS.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                for (int p = 0; p < PT; ++p) {
-                    const float dot = acc[p][4 * grp + e];
-                    const float r2 = fmaf(-2.0f, dot, nx[p] + vny[e]);
-                    const float pp = tx[p] - vty[e];               // a * r_t
-                    const float ss = sx[p] - vsy[e];               // a * S
-                    const float kap = __builtin_amdgcn_exp2f(r2 * kexp);
-                    const float L = fmaf(-pp, pp, fmaf(a2, r2, -ad_));   // a^2 (r2 - r_t^2) - a d
-                    const float E = fmaf(vcS[e], ss, fmaf(vct[e], pp, fmaf(vcL[e], L, vc0[e])));
-                    au[p] = fmaf(kap, E, au[p]);
-                    at[p] = fmaf(kap, fmaf(-pp, E, a * vct[e]), at[p]);
-                    const float dv = fmaf(2.0f * vcL[e], ss, (float)g.d * vcS[e]);
-                    ad[p] = fmaf(kap, fmaf(-ss, E, a * dv), ad[p]);
-                    const float lv = fmaf(vcL[e], fmaf(2.0f, L, ad_), vcS[e] * ss);
-                    al[p] = fmaf(kap, fmaf(L, E, -2.0f * a * lv), al[p]);
-                }
-            }
+    } else {
+        for (int jt = 0; jt < n_tiles; ++jt) {
+            if (jt + 1 < n_tiles) stage(jt + 1, (jt + 1) % 3);
+            if (jt > 0) gp_epilogue_tile<PT>(view((jt - 1) % 3), acc, c, half, nx, sx, tx, au, at, ad, al);
+            gp_mfma_tile<NK4, PT>(view(jt % 3), xf, acc, lane);
+            __syncthreads();
         }
+        gp_epilogue_tile<PT>(view((n_tiles - 1) % 3), acc, c, half, nx, sx, tx, au, at, ad, al);
     }
+
     // ---- combine the two half-waves (rows 4h..4h+3 of each group) and store -------------------
     const float s2 = g.sigma * g.sigma;
 #pragma unroll
@@ -194,11 +255,12 @@ __global__ __launch_bounds__(256) void gp_gradient_kernel(const float *points, c
             const float *y = colloc + (int64_t)j * kp;
             float dot = 0.0f;
             for (int k = 0; k <= d; ++k) dot = fmaf(xs[k], y[k], dot);
-            const float r2 = fmaf(-2.0f, dot, nxv + coef[j]);
-            const float pp = txa - coef[2 * n_pad + j], ss = sxa - coef[1 * n_pad + j];
+            const float *cf = coef + (int64_t)j * 8;
+            const float r2 = fmaf(-2.0f, dot, nxv + cf[0]);
+            const float pp = txa - cf[2], ss = sxa - cf[1];
             const float kap = expf(-0.5f * a * r2);
             const float L = fmaf(-pp, pp, fmaf(a2, r2, -ad_));
-            const float c0 = coef[3 * n_pad + j], cL = coef[4 * n_pad + j], ct = coef[5 * n_pad + j], cS = coef[6 * n_pad + j];
+            const float c0 = cf[3], cL = cf[4], ct = cf[5], cS = cf[6];
             const float E = fmaf(cS, ss, fmaf(ct, pp, fmaf(cL, L, c0)));
             al = kap * a * (2.0f * a * cL - E);
             A1 += al;
@@ -253,9 +315,10 @@ __global__ void gp_pack_kernel(int d, float a, const float *x_dom, int n_dom, co
         if (k < d) sy += v;
         if (k == d) ty = v;
     }
-    coef[0 * n_pad + j] = ny;
-    coef[1 * n_pad + j] = a * sy;
-    coef[2 * n_pad + j] = a * ty;
+    float *cf = coef + (int64_t)j * 8;
+    cf[0] = ny;
+    cf[1] = a * sy;
+    cf[2] = a * ty;
     float c0 = 0.0f, cL = 0.0f, ct = 0.0f, cS = 0.0f;
     if (j < n_dom) {
         c0 = (float)rv[j];
@@ -265,20 +328,27 @@ __global__ void gp_pack_kernel(int d, float a, const float *x_dom, int n_dom, co
     } else if (j < N) {
         c0 = (float)rv[j];
     }
-    coef[3 * n_pad + j] = c0;
-    coef[4 * n_pad + j] = cL;
-    coef[5 * n_pad + j] = ct;
-    coef[6 * n_pad + j] = cS;
-    coef[7 * n_pad + j] = 0.0f;
+    cf[3] = c0;
+    cf[4] = cL;
+    cf[5] = ct;
+    cf[6] = cS;
+    cf[7] = 0.0f;
 }
 
 template <int NK4>
 static int launch_eval(const GpArgs &g, hipStream_t s) {
     constexpr int PT = NK4 <= 13 ? 2 : 1;
     const int64_t waves = (g.n_inf + 32 * PT - 1) / (32 * PT);
-    const int64_t blocks = (waves + 3) / 4;
+    const int64_t blocks = (waves + 7) / 8;
     if (blocks > 0x7FFFFFFF) return fail(SCASML_ERR_UNSUPPORTED, "gp_eval: too many points");
-    hipLaunchKernelGGL((gp_eval_kernel<NK4, PT>), dim3((unsigned)blocks), dim3(256), 0, s, g);
+    constexpr size_t lds_bytes = 3 * (NK4 * 256 + 256) * sizeof(float);
+    static_assert(lds_bytes <= 160 * 1024, "LDS slots exceed 160 KiB");
+    auto kern = gp_eval_kernel<NK4, PT>;
+    if (lds_bytes > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+            return fail(SCASML_ERR_HIP, "gp_eval: cannot reserve %zu bytes of LDS", lds_bytes);
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds_bytes, s, g);
     return check_launch("gp_eval launch");
 }
 

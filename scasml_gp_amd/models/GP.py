@@ -206,7 +206,7 @@ class GP(object):
         self._n_pad = _round_up(self.N_domain + self.N_boundary, _lib.GP_TILE)
         self._colloc = torch.empty((self._n_pad, kp), dtype=torch.float32, device="cuda")
         self._frag = torch.empty((self._n_pad * kp,), dtype=torch.float32, device="cuda")
-        self._coef = torch.empty((8, self._n_pad), dtype=torch.float32, device="cuda")
+        self._coef = torch.empty((self._n_pad, 8), dtype=torch.float32, device="cuda")
         rv = rv.contiguous()
         _lib.check(lib.scasml_gp_pack(self.d, 1.0 / float(self.sigma) ** 2, _lib.ptr(self._xd), self.N_domain,
                                       _lib.ptr(self._xb), self.N_boundary, _lib.ptr(rv), _lib.ptr(self._colloc),
