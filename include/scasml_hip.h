@@ -27,7 +27,7 @@ extern "C" {
 #define SCASML_ABI_VERSION 1
 #define SCASML_MAX_LEVEL 4   /* Picard level n <= 4 (kernels are instantiated per level)      */
 #define SCASML_MAX_Q 6       /* quadrature nodes per rule <= 6 (rho <= 5, solvers/MLP.py:132)  */
-#define SCASML_MAX_DIM 255   /* spatial dimension d <= 255 (one 4-dim quad per lane)          */
+#define SCASML_MAX_DIM 254   /* spatial dimension d <= 254 (one 4-dim quad per lane, +t, +1 spare column) */
 #define SCASML_GP_TILE 32     /* collocation points per MFMA tile; n_pad is a multiple of it    */
 
 enum { SCASML_ERR_ARG = -1, SCASML_ERR_UNSUPPORTED = -2, SCASML_ERR_HIP = -3 };
@@ -90,7 +90,8 @@ size_t scasml_sizeof(int which);
 
 /* Rows of the point buffer / GP-value buffer per root: sites[n] + 1 (the root itself last). */
 int64_t scasml_points_per_root(const scasml_plan *plan_h);
-/* Padded row length (floats) of a point row: round_up(d + 1, 8). */
+/* Padded row length (floats) of a point row: round_up(d + 2, 16): X, t, one spare column the GP
+ * evaluation uses for a folded constant, zero pad to a whole bf16 MFMA K-step. */
 int32_t scasml_point_stride(int32_t d);
 
 /*
@@ -124,25 +125,29 @@ typedef struct {
     int32_t d;
     int32_t n_dom, n_bdy;        /* N_Omega, N_dOmega                                        */
     int32_t n_pad;               /* (n_dom + n_bdy) rounded up to 32                         */
-    int32_t kp;                  /* point stride = round_up(d+1, 8)                          */
+    int32_t kp;                  /* point stride = round_up(d+2, 16)                         */
+    int32_t split;               /* x.y arithmetic: 0 = fp32 MFMA, 2 / 3 = bf16 MFMA on 2 / 3 bf16 planes (3 = fp32-exact) */
     float a;                     /* 1/sigma_k^2, sigma_k = 0.25*sqrt(d) (models/GP.py:25)    */
     float sigma_eq;              /* equation sigma (models/GP.py:748)                        */
     const float *colloc;         /* n_pad x kp   collocation points, domain first, zero pad  */
-    const float *colloc_frag;    /* the same, in MFMA A-fragment order [tile][kp/8][64][4]   */
-    const float *coef;           /* n_pad x 8    (|y|^2, a*sum y, a*t_y, c0, cL, ct, cS, 0)  */
+    const float *colloc_frag;    /* the same, in fp32 MFMA A-fragment order [tile][kp/8][64][4] */
+    const uint16_t *colloc_bf16; /* the same as 3 truncated-bf16 planes, [tile][plane][kp/16][64][8] */
+    const float *coef;           /* n_pad x 16   per-row constants (|y|^2, a*sum y, a*t_y, c0, cL, ct, cS, 0, a*ct, ...) */
 } scasml_gp_model;
 
 /* Build `coef` and the padded `colloc` from points and right_vector (models/GP.py:599-600):
  * c0 = rv[u(X)] (domain and boundary rows), cL = rv[Lap], ct = rv[dt], cS = rv[div] (zero on
  * boundary rows).  x_dom: n_dom x (d+1), x_bdy: n_bdy x (d+1), rv: 4*n_dom + n_bdy (float64). */
 int scasml_gp_pack(int32_t d, float a, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy,
-                   const double *rv, float *colloc_out, float *colloc_frag_out, float *coef_out, void *stream);
+                   const double *rv, float *colloc_out, float *colloc_frag_out, uint16_t *colloc_bf16_out /* 3*n_pad*kp */,
+                   float *coef_out, void *stream);
 
 /*
  * Fused posterior evaluation: replaces GP.predict (models/GP.py:653-671), the spatial-sum of
  * GP.compute_gradient (:673-687) and GP_Grad_Dependent_Nonlinear.compute_PDE_loss (:746-769)
- * without materialising any (n_inf x M) feature matrix.  FP32 MFMA (v_mfma_f32_32x32x2_f32)
- * for x.y, closed-form derivative features in the epilogue.
+ * without materialising any (n_inf x M) feature matrix.  x.y on the matrix cores -- bf16 MFMA over
+ * 3 (fp32-exact) or 2 bf16 planes of each operand, or FP32 MFMA (gp_h->split) -- and the closed-form
+ * derivative features in the epilogue.
  *   points : n_inf x kp rows (X, t, zero pad)
  *   out4   : n_inf x 4 = (u_hat, div_x u_hat, eps_PDE, dt u_hat)
  *   lap    : n_inf Laplacian of u_hat, may be NULL

@@ -5,7 +5,7 @@ import os
 
 MAX_LEVEL = 4
 MAX_Q = 6
-MAX_DIM = 255
+MAX_DIM = 254
 GP_TILE = 32
 ABI_VERSION = 1
 
@@ -36,8 +36,8 @@ class Plan(C.Structure):
 
 class GpModel(C.Structure):
     _fields_ = [("d", C.c_int32), ("n_dom", C.c_int32), ("n_bdy", C.c_int32), ("n_pad", C.c_int32),
-                ("kp", C.c_int32), ("a", C.c_float), ("sigma_eq", C.c_float),
-                ("colloc", C.c_void_p), ("colloc_frag", C.c_void_p), ("coef", C.c_void_p)]
+                ("kp", C.c_int32), ("split", C.c_int32), ("a", C.c_float), ("sigma_eq", C.c_float),
+                ("colloc", C.c_void_p), ("colloc_frag", C.c_void_p), ("colloc_bf16", C.c_void_p), ("coef", C.c_void_p)]
 
 
 _STRUCTS = (Problem, Rng, Term, Plan, GpModel)
@@ -56,7 +56,7 @@ SIGNATURES = {
     "scasml_clip": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
     "scasml_debug_normals": (C.c_int, [Rng, C.c_uint32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "scasml_gp_pack": (C.c_int, [C.c_int32, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
-                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "scasml_gp_eval": (C.c_int, [C.POINTER(GpModel), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "scasml_gp_gradient": (C.c_int, [C.POINTER(GpModel), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "scasml_gp_gram": (C.c_int, [C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),

@@ -22,22 +22,9 @@
 // The K loop is split between the half-waves (half h takes k in [h*kp/2, (h+1)*kp/2)), which makes
 // every lane's operand a contiguous run of its row: 16-byte loads, no LDS staging; the point tile
 // stays in VGPRs for the whole sweep and the collocation tile streams from L2 in fragment order.
-#include "common.hpp"
+#include "gp_common.hpp"
 
 namespace scasml {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct GpArgs {
-    const float *points;       // n_inf x kp
-    const float *colloc_frag;  // [n_tiles][NK4][64][4]
-    const float *coef;         // [n_pad][8]
-    float4 *out4;              // n_inf x (u, div, eps, dt)
-    float *lap;                // n_inf or null
-    int64_t n_inf;
-    int32_t n_pad, kp, d;
-    float a, sigma;
-};
 
 // NK4 = kp / 8 float4 per lane per row; PT = point tiles (of 32) per wave.
 //
@@ -48,13 +35,8 @@ struct GpArgs {
 // partners run half a tile apart: waves 0-3 do MFMA(t) then epilogue(t); waves 4-7 do epilogue(t-1)
 // then MFMA(t), keeping their accumulators across the barrier -- so on every SIMD one wave's VALU
 // epilogue runs under the other's MFMAs and the matrix pipe stays fed.
-struct GpStageView {
-    const float4 *y;    // [NK4][64] A fragments of one collocation tile
-    const float *coef;  // [32 rows][8]
-};
-
 template <int NK4>
-__device__ __forceinline__ constexpr int gp_stage_floats() { return NK4 * 256 + 256; }
+__device__ __forceinline__ constexpr int gp_stage_floats() { return NK4 * 256 + 512; }
 
 template <int NK4, int PT>
 __device__ __forceinline__ void gp_mfma_tile(const GpStageView &st, const float4 (&xf)[PT][NK4], f32x16 (&acc)[PT], int lane) {
@@ -82,44 +64,6 @@ __device__ __forceinline__ void gp_mfma_tile(const GpStageView &st, const float4
     }
 }
 
-struct GpConsts {
-    float a, a2, ad, kexp, dF;
-};
-
-// C row = (r&3) + 8*(r>>2) + 4*half, column = lane & 31.  Coefficients of a collocation row are 8
-// consecutive floats (|y|^2, a*sum y, a*t_y, c0, cL, ct, cS, 0): two broadcast ds_read_b128 per row.
-template <int PT>
-__device__ __forceinline__ void gp_epilogue_tile(const GpStageView &st, const f32x16 (&acc)[PT], const GpConsts &c, int half,
-                                                 const float (&nx)[PT], const float (&sx)[PT], const float (&tx)[PT],
-                                                 float (&au)[PT], float (&at)[PT], float (&ad)[PT], float (&al)[PT]) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        // one row (PT independent chains) per scheduling region: more ILP only costs VGPRs, and the
-        // point tile must stay resident in registers across the epilogue
-        __builtin_amdgcn_sched_barrier(0);
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const float4 q0 = *reinterpret_cast<const float4 *>(st.coef + row * 8);
-        const float4 q1 = *reinterpret_cast<const float4 *>(st.coef + row * 8 + 4);
-        const float vny = q0.x, vsy = q0.y, vty = q0.z, vc0 = q0.w, vcL = q1.x, vct = q1.y, vcS = q1.z;
-#pragma unroll
-        for (int p = 0; p < PT; ++p) {
-            const float dot = acc[p][r];
-            const float r2 = fmaf(-2.0f, dot, nx[p] + vny);
-            const float pp = tx[p] - vty;                  // a * r_t
-            const float ss = sx[p] - vsy;                  // a * S
-            const float kap = __builtin_amdgcn_exp2f(r2 * c.kexp);
-            const float L = fmaf(-pp, pp, fmaf(c.a2, r2, -c.ad));   // a^2 (r2 - r_t^2) - a d
-            const float E = fmaf(vcS, ss, fmaf(vct, pp, fmaf(vcL, L, vc0)));
-            au[p] = fmaf(kap, E, au[p]);
-            at[p] = fmaf(kap, fmaf(-pp, E, c.a * vct), at[p]);
-            const float dv = fmaf(2.0f * vcL, ss, c.dF * vcS);
-            ad[p] = fmaf(kap, fmaf(-ss, E, c.a * dv), ad[p]);
-            const float lv = fmaf(vcL, fmaf(2.0f, L, c.ad), vcS * ss);
-            al[p] = fmaf(kap, fmaf(L, E, -2.0f * c.a * lv), al[p]);
-        }
-    }
-}
-
 template <int NK4, int PT>
 __global__ __launch_bounds__(512, 2) void gp_eval_kernel(const GpArgs g) {
     constexpr int STAGE = gp_stage_floats<NK4>();       // floats per LDS slot
@@ -139,7 +83,9 @@ __global__ __launch_bounds__(512, 2) void gp_eval_kernel(const GpArgs g) {
         for (int v = wv; v < NK4; v += 8)
             __builtin_amdgcn_global_load_lds(src + v * 256 + lane * 4, dst + v * 256, 16, 0, 0);
         if (wv == (NK4 & 7))
-            __builtin_amdgcn_global_load_lds(g.coef + (int64_t)tile * 256 + lane * 4, dst + NK4 * 256, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(g.coef + (int64_t)tile * 512 + lane * 4, dst + NK4 * 256, 16, 0, 0);
+        if (wv == ((NK4 + 1) & 7))
+            __builtin_amdgcn_global_load_lds(g.coef + (int64_t)tile * 512 + 256 + lane * 4, dst + NK4 * 256 + 256, 16, 0, 0);
     };
     auto view = [&](int slot) {
         const float *b = lds + slot * STAGE;
@@ -255,12 +201,12 @@ __global__ __launch_bounds__(256) void gp_gradient_kernel(const float *points, c
             const float *y = colloc + (int64_t)j * kp;
             float dot = 0.0f;
             for (int k = 0; k <= d; ++k) dot = fmaf(xs[k], y[k], dot);
-            const float *cf = coef + (int64_t)j * 8;
-            const float r2 = fmaf(-2.0f, dot, nxv + cf[0]);
-            const float pp = txa - cf[2], ss = sxa - cf[1];
+            const float *cf = coef + (int64_t)j * kCoefRow;
+            const float r2 = fmaf(-2.0f, dot, nxv + cf[12]);
+            const float pp = txa - cf[1], ss = sxa - cf[0];
             const float kap = expf(-0.5f * a * r2);
             const float L = fmaf(-pp, pp, fmaf(a2, r2, -ad_));
-            const float c0 = cf[3], cL = cf[4], ct = cf[5], cS = cf[6];
+            const float c0 = cf[2], cL = cf[3], ct = cf[4], cS = cf[5];
             const float E = fmaf(cS, ss, fmaf(ct, pp, fmaf(cL, L, c0)));
             al = kap * a * (2.0f * a * cL - E);
             A1 += al;
@@ -298,12 +244,15 @@ __global__ __launch_bounds__(256) void gp_gradient_kernel(const float *points, c
 
 // Build the device model from the training set and right_vector (models/GP.py:593-600).
 __global__ void gp_pack_kernel(int d, float a, const float *x_dom, int n_dom, const float *x_bdy, int n_bdy,
-                               const double *rv, float *colloc, float *frag, float *coef, int n_pad, int kp) {
+                               const double *rv, float *colloc, float *frag, uint16_t *bf, float *coef, int n_pad, int kp) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_pad) return;
     const int N = n_dom + n_bdy;
     const float *src = j < n_dom ? x_dom + (int64_t)j * (d + 1) : (j < N ? x_bdy + (int64_t)(j - n_dom) * (d + 1) : nullptr);
     float ny = 0.0f, sy = 0.0f, ty = 0.0f;
+    float ny_full = 0.0f;
+    if (src)
+        for (int k = 0; k <= d; ++k) ny_full = fmaf(src[k], src[k], ny_full);
     const int nk4 = kp / 8, tile = j / 32, i = j % 32;
     for (int k = 0; k < kp; ++k) {
         const float v = (src && k <= d) ? src[k] : 0.0f;
@@ -311,14 +260,25 @@ __global__ void gp_pack_kernel(int d, float a, const float *x_dom, int n_dom, co
         // fragment order [tile][v][lane = half*32 + i][4], half h covers k in [h*kp/2, (h+1)*kp/2)
         const int h = k / (kp / 2), kk = k % (kp / 2);
         frag[(((int64_t)tile * nk4 + kk / 4) * 64 + h * 32 + i) * 4 + (kk & 3)] = v;
+        // bf16 planes (truncation split, v = hi + mid + lo exactly up to 2^-24 |v|), MFMA 32x32x16 A-fragment
+        // order [tile][plane][step][lane = half*32 + i][8]: half h covers k in [h*kp/2, (h+1)*kp/2), step = kk/8
+        // the planes hold the FOLDED operand  -2 a^2 y_k  (k <= d)  and  a^2 |y|^2  in column d+1, which the
+        // evaluation kernel meets with a constant 1: the MFMA then yields a^2 (|y|^2 - 2 x.y) directly
+        const float vf = k <= d ? -2.0f * a * a * v : (k == d + 1 ? a * a * ny_full : 0.0f);
+        const uint32_t hb = __float_as_uint(vf) & 0xFFFF0000u;
+        const float r1 = vf - __uint_as_float(hb);
+        const uint32_t mb = __float_as_uint(r1) & 0xFFFF0000u;
+        const float r2 = r1 - __uint_as_float(mb);
+        const uint32_t lb = __float_as_uint(r2) & 0xFFFF0000u;
+        const int ks = kp / 16;
+        const int64_t e = (((int64_t)(kk / 8)) * 64 + h * 32 + i) * 8 + (kk & 7);
+        bf[((int64_t)tile * 3 + 0) * ks * 512 + e] = (uint16_t)(hb >> 16);
+        bf[((int64_t)tile * 3 + 1) * ks * 512 + e] = (uint16_t)(mb >> 16);
+        bf[((int64_t)tile * 3 + 2) * ks * 512 + e] = (uint16_t)(lb >> 16);
         ny = fmaf(v, v, ny);
         if (k < d) sy += v;
         if (k == d) ty = v;
     }
-    float *cf = coef + (int64_t)j * 8;
-    cf[0] = ny;
-    cf[1] = a * sy;
-    cf[2] = a * ty;
     float c0 = 0.0f, cL = 0.0f, ct = 0.0f, cS = 0.0f;
     if (j < n_dom) {
         c0 = (float)rv[j];
@@ -328,11 +288,22 @@ __global__ void gp_pack_kernel(int d, float a, const float *x_dom, int n_dom, co
     } else if (j < N) {
         c0 = (float)rv[j];
     }
-    cf[3] = c0;
-    cf[4] = cL;
-    cf[5] = ct;
-    cf[6] = cS;
-    cf[7] = 0.0f;
+    const float fd = (float)d;
+    float *cf = coef + (int64_t)j * kCoefRow;   // layout: gp_common.hpp
+    cf[0] = a * sy;
+    cf[1] = a * ty;
+    cf[2] = c0;
+    cf[3] = cL;
+    cf[4] = ct;
+    cf[5] = cS;
+    cf[6] = a * ct;
+    cf[7] = 2.0f * a * cL;
+    cf[8] = a * fd * cS;
+    cf[9] = -4.0f * a * cL;
+    cf[10] = -2.0f * a * cS;
+    cf[11] = -2.0f * a * a * fd * cL;
+    cf[12] = ny;
+    cf[13] = cf[14] = cf[15] = 0.0f;
 }
 
 template <int NK4>
@@ -341,7 +312,7 @@ static int launch_eval(const GpArgs &g, hipStream_t s) {
     const int64_t waves = (g.n_inf + 32 * PT - 1) / (32 * PT);
     const int64_t blocks = (waves + 7) / 8;
     if (blocks > 0x7FFFFFFF) return fail(SCASML_ERR_UNSUPPORTED, "gp_eval: too many points");
-    constexpr size_t lds_bytes = 3 * (NK4 * 256 + 256) * sizeof(float);
+    constexpr size_t lds_bytes = 3 * (NK4 * 256 + 512) * sizeof(float);
     static_assert(lds_bytes <= 160 * 1024, "LDS slots exceed 160 KiB");
     auto kern = gp_eval_kernel<NK4, PT>;
     if (lds_bytes > 64 * 1024) {
@@ -366,14 +337,15 @@ static int check_model(const scasml_gp_model *m, const char *who) {
 using namespace scasml;
 
 extern "C" int scasml_gp_pack(int32_t d, float a, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy,
-                              const double *rv, float *colloc_out, float *colloc_frag_out, float *coef_out, void *stream) {
-    if (!x_dom || !rv || !colloc_out || !colloc_frag_out || !coef_out || (n_bdy > 0 && !x_bdy))
+                              const double *rv, float *colloc_out, float *colloc_frag_out, uint16_t *colloc_bf16_out,
+                              float *coef_out, void *stream) {
+    if (!x_dom || !rv || !colloc_out || !colloc_frag_out || !colloc_bf16_out || !coef_out || (n_bdy > 0 && !x_bdy))
         return fail(SCASML_ERR_ARG, "gp_pack: null argument");
     if (d < 1 || d > SCASML_MAX_DIM || n_dom < 1 || n_bdy < 0) return fail(SCASML_ERR_ARG, "gp_pack: bad sizes");
     const int n_pad = (n_dom + n_bdy + 31) / 32 * 32;
     const int kp = scasml_point_stride(d);
     hipLaunchKernelGGL(gp_pack_kernel, dim3((n_pad + 63) / 64), dim3(64), 0, (hipStream_t)stream, d, a, x_dom, n_dom, x_bdy,
-                       n_bdy, rv, colloc_out, colloc_frag_out, coef_out, n_pad, kp);
+                       n_bdy, rv, colloc_out, colloc_frag_out, colloc_bf16_out, coef_out, n_pad, kp);
     return check_launch("gp_pack launch");
 }
 
@@ -385,6 +357,7 @@ extern "C" int scasml_gp_eval(const scasml_gp_model *m, const float *points, int
     GpArgs g;
     g.points = points;
     g.colloc_frag = m->colloc_frag;
+    g.colloc_bf16 = m->colloc_bf16;
     g.coef = m->coef;
     g.out4 = reinterpret_cast<float4 *>(out4);
     g.lap = lap;
@@ -395,15 +368,20 @@ extern "C" int scasml_gp_eval(const scasml_gp_model *m, const float *points, int
     g.a = m->a;
     g.sigma = m->sigma_eq;
     hipStream_t s = (hipStream_t)stream;
+    if (m->split == 2 || m->split == 3) {
+        if (!m->colloc_bf16) return fail(SCASML_ERR_ARG, "gp_eval: split=%d needs colloc_bf16", m->split);
+        return launch_gp_eval_bf16(g, m->split, s);
+    }
+    if (m->split != 0) return fail(SCASML_ERR_ARG, "gp_eval: split must be 0, 2 or 3");
 #define SCASML_EVAL_CASE(NK) \
     case NK: return launch_eval<NK>(g, s);
     switch (m->kp / 8) {
-        SCASML_EVAL_CASE(1) SCASML_EVAL_CASE(2) SCASML_EVAL_CASE(3) SCASML_EVAL_CASE(4) SCASML_EVAL_CASE(5) SCASML_EVAL_CASE(6)
-        SCASML_EVAL_CASE(7) SCASML_EVAL_CASE(8) SCASML_EVAL_CASE(9) SCASML_EVAL_CASE(10) SCASML_EVAL_CASE(11) SCASML_EVAL_CASE(12)
-        SCASML_EVAL_CASE(13) SCASML_EVAL_CASE(14) SCASML_EVAL_CASE(15) SCASML_EVAL_CASE(16) SCASML_EVAL_CASE(17) SCASML_EVAL_CASE(18)
-        SCASML_EVAL_CASE(19) SCASML_EVAL_CASE(20) SCASML_EVAL_CASE(21) SCASML_EVAL_CASE(22) SCASML_EVAL_CASE(23) SCASML_EVAL_CASE(24)
-        SCASML_EVAL_CASE(25) SCASML_EVAL_CASE(26) SCASML_EVAL_CASE(27) SCASML_EVAL_CASE(28) SCASML_EVAL_CASE(29) SCASML_EVAL_CASE(30)
-        SCASML_EVAL_CASE(31) SCASML_EVAL_CASE(32)
+         SCASML_EVAL_CASE(2)  SCASML_EVAL_CASE(4)  SCASML_EVAL_CASE(6)
+         SCASML_EVAL_CASE(8)  SCASML_EVAL_CASE(10)  SCASML_EVAL_CASE(12)
+         SCASML_EVAL_CASE(14)  SCASML_EVAL_CASE(16)  SCASML_EVAL_CASE(18)
+         SCASML_EVAL_CASE(20)  SCASML_EVAL_CASE(22)  SCASML_EVAL_CASE(24)
+         SCASML_EVAL_CASE(26)  SCASML_EVAL_CASE(28)  SCASML_EVAL_CASE(30)
+         SCASML_EVAL_CASE(32)
     }
 #undef SCASML_EVAL_CASE
     return fail(SCASML_ERR_UNSUPPORTED, "gp_eval: kp=%d", m->kp);

@@ -1,0 +1,208 @@
+// Fused GP posterior evaluation with x.y on the bf16 matrix cores (split-bf16 arithmetic).
+//
+// Why: on gfx950 the fp32-input MFMA (v_mfma_f32_32x32x2_f32) runs at the fp32 VALU rate AND does not
+// co-execute with VALU work (tools/ubench_mfma_valu.hip: an MFMA-only and a VALU-only wave on one SIMD
+// take the SUM of their times), so the fp32 kernel's time is matrix time + epilogue time.  bf16 MFMA is
+// 16x faster per flop and does overlap with VALU.  Each fp32 operand is split by truncation into bf16
+// planes  v = hi + mid + lo  (exact to 2^-24 |v|); the products hi*hi, hi*mid, mid*hi, mid*mid, hi*lo,
+// lo*hi carry every term down to 2^-24, i.e. x.y is as exact as the fp32 MFMA (SPLIT = 3, 6 MFMAs per
+// K-step); SPLIT = 2 keeps hi/mid only (3 MFMAs, ~2^-17 per product).  Accumulation is fp32 in the MFMA.
+//
+// Structure (same as gp_eval.hip): workgroup of 8 waves, 32 points per wave held in VGPRs as bf16 planes
+// for the whole sweep; per collocation tile one LDS slot [SPLIT*KS KiB of A fragments | 1 KiB coefficients]
+// filled one tile ahead by global_load_lds; one barrier per tile; SIMD partner waves (w, w+4) run half a
+// tile apart so one's VALU epilogue overlaps the other's MFMAs.  The epilogue is gp_common.hpp's.
+#include "gp_common.hpp"
+
+namespace scasml {
+
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3(float v, uint32_t &h, uint32_t &m, uint32_t &l) {
+    h = __float_as_uint(v) & 0xFFFF0000u;
+    const float r1 = v - __uint_as_float(h);
+    m = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(m);
+    l = __float_as_uint(r2) & 0xFFFF0000u;
+}
+
+union Frag {
+    s16x8 v;
+    uint32_t u[4];
+    float4 f;
+};
+
+// KS = kp / 16 K-steps of the 32x32x16 MFMA; half-wave h covers k in [h*8*KS, (h+1)*8*KS)
+template <int KS, int SPLIT>
+__device__ __forceinline__ void gp_mfma_tile_bf16(const float4 *lds_a, const s16x8 (&xb)[SPLIT][KS], f32x16 &acc, int lane) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    // A fragments ping-pong between two register sets selected by the (compile-time) parity of the
+    // step: the ds_reads of step s+1 are issued before the MFMAs of step s, with no register copies.
+    Frag a[2][SPLIT];
+#pragma unroll
+    for (int pl = 0; pl < SPLIT; ++pl) a[0][pl].f = lds_a[(pl * KS) * 64 + lane];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int cur = s & 1, nxt = cur ^ 1;
+        if (s + 1 < KS) {
+#pragma unroll
+            for (int pl = 0; pl < SPLIT; ++pl) a[nxt][pl].f = lds_a[(pl * KS + s + 1) * 64 + lane];
+        }
+        // small terms first; plane 0 = hi, 1 = mid, 2 = lo
+        if (SPLIT == 3) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][2].v, xb[0][s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0].v, xb[SPLIT - 1][s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][1].v, xb[1][s], acc, 0, 0, 0);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][1].v, xb[0][s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0].v, xb[1][s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0].v, xb[0][s], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int KS, int SPLIT>
+__global__ __launch_bounds__(512, 2) void gp_eval_bf16_kernel(const GpArgs g) {
+    constexpr int STAGE = SPLIT * KS * 256 + 512;       // floats per LDS slot (A fragments + 32 rows x 16 coefficients)
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // 3 slots
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const bool late = __builtin_amdgcn_readfirstlane(wv) >= 4;    // scalar, wave-uniform role
+    const int64_t p0 = ((int64_t)blockIdx.x * 8 + wv) * 32;
+    const int n_tiles = g.n_pad / 32;
+
+    // stage one collocation tile: 1 KiB chunks, chunk c < SPLIT*KS = A fragment (plane, step), last = coefficients
+    auto stage = [&](int tile, int slot) {
+        float *dst = lds + slot * STAGE;
+        const float *src = reinterpret_cast<const float *>(g.colloc_bf16) + (int64_t)tile * 3 * KS * 256;
+        for (int c = wv; c < SPLIT * KS; c += 8)
+            __builtin_amdgcn_global_load_lds(src + c * 256 + lane * 4, dst + c * 256, 16, 0, 0);
+        if (wv == ((SPLIT * KS) & 7))
+            __builtin_amdgcn_global_load_lds(g.coef + (int64_t)tile * 512 + lane * 4, dst + SPLIT * KS * 256, 16, 0, 0);
+        if (wv == ((SPLIT * KS + 1) & 7))
+            __builtin_amdgcn_global_load_lds(g.coef + (int64_t)tile * 512 + 256 + lane * 4, dst + SPLIT * KS * 256 + 256, 16, 0, 0);
+    };
+    stage(0, 0);
+
+    // ---- this wave's 32 points: fp32 row halves -> |x|^2, a*sum x, a*t, and the bf16 planes ------
+    s16x8 xb[SPLIT][KS];
+    float nx[1], sx[1], tx[1];
+    {
+        int64_t row = p0 + col;
+        if (row >= g.n_inf) row = g.n_inf - 1;  // shadow rows, never stored
+        const int kbase = half * (8 * KS);
+        const float4 *src = reinterpret_cast<const float4 *>(g.points + row * g.kp + kbase);
+        float pn = 0.0f, ps = 0.0f, pt = 0.0f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const float4 q0 = src[2 * s], q1 = src[2 * s + 1];
+            float e[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            uint32_t hb[8], mb[8], lb[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int k = kbase + 8 * s + c;
+                pn = fmaf(e[c], e[c], pn);
+                ps += k < g.d ? e[c] : 0.0f;
+                pt += k == g.d ? e[c] : 0.0f;
+                if (k == g.d + 1) e[c] = 1.0f;   // the constant column that picks up a^2 |y|^2 (gp_pack_kernel)
+                split3(e[c], hb[c], mb[c], lb[c]);
+            }
+            Frag fh, fm, fl;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {   // element 2c in the low half-word, 2c+1 in the high one
+                fh.u[c] = (hb[2 * c] >> 16) | hb[2 * c + 1];
+                fm.u[c] = (mb[2 * c] >> 16) | mb[2 * c + 1];
+                fl.u[c] = (lb[2 * c] >> 16) | lb[2 * c + 1];
+            }
+            xb[0][s] = fh.v;
+            xb[1][s] = fm.v;
+            if (SPLIT == 3) xb[SPLIT - 1][s] = fl.v;
+        }
+        pn += __shfl_xor(pn, 32);
+        ps += __shfl_xor(ps, 32);
+        pt += __shfl_xor(pt, 32);
+        nx[0] = g.a * g.a * pn - g.a * (float)g.d;   // folded epilogue: L0 = acc + nx
+        sx[0] = g.a * ps;
+        tx[0] = g.a * pt;
+    }
+    float au[1] = {0.0f}, at[1] = {0.0f}, ad[1] = {0.0f}, al[1] = {0.0f};
+    GpConsts c;
+    c.a = g.a;
+    c.a2 = g.a * g.a;
+    c.ad = g.a * (float)g.d;
+    c.kexp = -0.5f * g.a * 1.44269504088896341f;
+    c.dF = (float)g.d;
+    c.k1 = -0.5f * 1.44269504088896341f / g.a;    // exp(-a r2 / 2) = exp2(k1 * (a^2 r2 - a d) + k2)
+    c.k2 = c.k1 * c.ad;
+
+    auto a_of = [&](int slot) { return reinterpret_cast<const float4 *>(lds + slot * STAGE); };
+    auto view = [&](int slot) {
+        const float *b = lds + slot * STAGE;
+        return GpStageView{reinterpret_cast<const float4 *>(b), b + SPLIT * KS * 256};
+    };
+    f32x16 acc[1];
+    __syncthreads();  // tile 0 has landed (the barrier drains the LDS-DMA)
+    if (!late) {
+        for (int jt = 0; jt < n_tiles; ++jt) {
+            if (jt + 1 < n_tiles) stage(jt + 1, (jt + 1) % 3);
+            gp_mfma_tile_bf16<KS, SPLIT>(a_of(jt % 3), xb, acc[0], lane);
+            gp_epilogue_tile<1, true>(view(jt % 3), acc, c, half, nx, sx, tx, au, at, ad, al);
+            __syncthreads();
+        }
+    } else {
+        for (int jt = 0; jt < n_tiles; ++jt) {
+            if (jt + 1 < n_tiles) stage(jt + 1, (jt + 1) % 3);
+            if (jt > 0) gp_epilogue_tile<1, true>(view((jt - 1) % 3), acc, c, half, nx, sx, tx, au, at, ad, al);
+            gp_mfma_tile_bf16<KS, SPLIT>(a_of(jt % 3), xb, acc[0], lane);
+            __syncthreads();
+        }
+        gp_epilogue_tile<1, true>(view((n_tiles - 1) % 3), acc, c, half, nx, sx, tx, au, at, ad, al);
+    }
+
+    const float s2 = g.sigma * g.sigma;
+    const float u = au[0] + __shfl_xor(au[0], 32);
+    const float dt = at[0] + __shfl_xor(at[0], 32);
+    const float dv = ad[0] + __shfl_xor(ad[0], 32);
+    const float lp = al[0] + __shfl_xor(al[0], 32);
+    const int64_t row = p0 + col;
+    if (half == 0 && row < g.n_inf) {
+        const float eps = dt + (s2 * u - 1.0f / (float)g.d - 0.5f * s2) * dv + 0.5f * s2 * lp;   // models/GP.py:767-768
+        g.out4[row] = make_float4(u, dv, eps, dt);
+        if (g.lap) g.lap[row] = lp;
+    }
+}
+
+template <int KS, int SPLIT>
+static int launch_one(const GpArgs &g, hipStream_t s) {
+    const int64_t waves = (g.n_inf + 31) / 32;
+    const int64_t blocks = (waves + 7) / 8;
+    if (blocks > 0x7FFFFFFF) return fail(SCASML_ERR_UNSUPPORTED, "gp_eval: too many points");
+    constexpr size_t lds_bytes = 3 * (SPLIT * KS * 256 + 512) * sizeof(float);
+    static_assert(lds_bytes <= 160 * 1024, "LDS slots exceed 160 KiB");
+    auto kern = gp_eval_bf16_kernel<KS, SPLIT>;
+    if (lds_bytes > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+            return fail(SCASML_ERR_HIP, "gp_eval: cannot reserve %zu bytes of LDS", lds_bytes);
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds_bytes, s, g);
+    return check_launch("gp_eval(bf16) launch");
+}
+
+template <int SPLIT>
+static int launch_split(const GpArgs &g, hipStream_t s) {
+    switch (g.kp / 16) {
+#define SCASML_CASE(K) \
+    case K: return launch_one<K, SPLIT>(g, s);
+        SCASML_CASE(1) SCASML_CASE(2) SCASML_CASE(3) SCASML_CASE(4) SCASML_CASE(5) SCASML_CASE(6) SCASML_CASE(7) SCASML_CASE(8)
+        SCASML_CASE(9) SCASML_CASE(10) SCASML_CASE(11) SCASML_CASE(12) SCASML_CASE(13) SCASML_CASE(14) SCASML_CASE(15) SCASML_CASE(16)
+#undef SCASML_CASE
+    }
+    return fail(SCASML_ERR_UNSUPPORTED, "gp_eval: kp=%d", g.kp);
+}
+
+int launch_gp_eval_bf16(const GpArgs &g, int split, hipStream_t s) {
+    return split == 3 ? launch_split<3>(g, s) : launch_split<2>(g, s);
+}
+
+}  // namespace scasml

@@ -88,12 +88,28 @@ __device__ __forceinline__ void sincos_u24(uint32_t k, float &cc, float &ss) {
     ss = quad == 0 ? s : quad == 1 ? c : quad == 2 ? -s : -c;
 }
 
+// Correctly rounded binary32 square root, spelled out so that it does not depend on compiler flags or
+// on which lowering the optimiser happens to pick (a scalar sqrtf may legally get a 2.5-ulp expansion):
+// v_sqrt_f32 is within 1 ulp; the two neighbours are tested with exact FMA residuals (the scheme of
+// LLVM's correctly-rounded f32 sqrt lowering).  Valid for x = 0 and normal x, which is all Box-Muller
+// produces (x = -2 ln u is 0 or >= 1.19e-7).
+__device__ __forceinline__ float sqrt_rn(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float down = __uint_as_float(__float_as_uint(s) - 1u);
+    const float up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float vp = __builtin_fmaf(-down, s, x);
+    const float vs = __builtin_fmaf(-up, s, x);
+    float r = vp <= 0.0f ? down : s;
+    r = vs > 0.0f ? up : r;
+    return r;
+}
+
 __device__ __forceinline__ void box_muller(uint32_t ra, uint32_t rb, float &n0, float &n1) {
     const uint32_t k1 = (ra >> 8) + 1u;
     const uint32_t k2 = rb >> 8;
     float t = -2.0f * ln_u24(k1);
     t = t < 0.0f ? 0.0f : t;
-    const float rad = __fsqrt_rn(t);
+    const float rad = sqrt_rn(t);
     float c, s;
     sincos_u24(k2, c, s);
     n0 = rad * c;

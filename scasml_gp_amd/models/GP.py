@@ -16,6 +16,7 @@ the 5-index subsample (:28-39; the index set is threefry-dependent), no float16 
 L / K_p / outputs, Newton start at 0 instead of 1e-3*N(0,1) from PRNGKey(0) (:501).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -40,6 +41,9 @@ class GP(object):
         self.sigma = equation.sigma() * np.sqrt(self.d)      # models/GP.py:25
         self.nugget = 1e-2                                   # :26
         self.right_vector = None
+        # arithmetic of x.y in the fused evaluation: 3 = three bf16 planes on the bf16 matrix cores
+        # (products exact to fp32), 2 = two planes (~2^-17 per product), 0 = fp32-input MFMA
+        self.eval_split = int(os.environ.get("SCASML_GP_SPLIT", "3"))
 
     # ------------------------------------------------------------------ device helpers
     def _points_device(self, x):
@@ -61,9 +65,11 @@ class GP(object):
         m = _lib.GpModel()
         m.d, m.n_dom, m.n_bdy, m.n_pad = self.d, self.N_domain, self.N_boundary, self._n_pad
         m.kp = self._colloc.shape[1]
+        m.split = int(self.eval_split)
         m.a = 1.0 / float(self.sigma) ** 2
         m.sigma_eq = float(self.equation.sigma())
         m.colloc, m.colloc_frag, m.coef = self._colloc.data_ptr(), self._frag.data_ptr(), self._coef.data_ptr()
+        m.colloc_bf16 = self._bf16.data_ptr()
         return m
 
     def _eval_device(self, pts):
@@ -206,11 +212,12 @@ class GP(object):
         self._n_pad = _round_up(self.N_domain + self.N_boundary, _lib.GP_TILE)
         self._colloc = torch.empty((self._n_pad, kp), dtype=torch.float32, device="cuda")
         self._frag = torch.empty((self._n_pad * kp,), dtype=torch.float32, device="cuda")
-        self._coef = torch.empty((self._n_pad, 8), dtype=torch.float32, device="cuda")
+        self._bf16 = torch.empty((3 * self._n_pad * kp,), dtype=torch.int16, device="cuda")
+        self._coef = torch.empty((self._n_pad, 16), dtype=torch.float32, device="cuda")
         rv = rv.contiguous()
         _lib.check(lib.scasml_gp_pack(self.d, 1.0 / float(self.sigma) ** 2, _lib.ptr(self._xd), self.N_domain,
                                       _lib.ptr(self._xb), self.N_boundary, _lib.ptr(rv), _lib.ptr(self._colloc),
-                                      _lib.ptr(self._frag), _lib.ptr(self._coef), _lib.stream_ptr()), "gp_pack")
+                                      _lib.ptr(self._frag), _lib.ptr(self._bf16), _lib.ptr(self._coef), _lib.stream_ptr()), "gp_pack")
         torch.cuda.current_stream().synchronize()                  # rv may be freed by the caller
 
     def load_right_vector(self, x_t_domain, x_t_boundary, right_vector):

@@ -34,7 +34,7 @@ def test_struct_layouts_and_version(lib):
     for which, st in enumerate((_lib.Problem, _lib.Rng, _lib.Term, _lib.Plan, _lib.GpModel)):
         assert lib.scasml_sizeof(which) == C.sizeof(st)
     assert C.sizeof(_lib.Plan) < 3900          # travels by value in the kernarg segment (4 KiB)
-    assert lib.scasml_point_stride(100) == 104 and lib.scasml_point_stride(20) == 24 and lib.scasml_point_stride(7) == 8
+    assert lib.scasml_point_stride(100) == 112 and lib.scasml_point_stride(20) == 32 and lib.scasml_point_stride(7) == 16
 
 
 def test_argument_errors_are_codes_not_crashes(lib):

@@ -7,7 +7,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("d,site,seed,stream,root0", [(100, 0, 0, 0, 0), (7, 12345, 0xDEADBEEFCAFE, 9, 1 << 20), (255, 2 ** 32 - 1, 1, 2 ** 32 - 1, 77)])
+@pytest.mark.parametrize("d,site,seed,stream,root0", [(100, 0, 0, 0, 0), (7, 12345, 0xDEADBEEFCAFE, 9, 1 << 20), (254, 2 ** 32 - 1, 1, 2 ** 32 - 1, 77)])
 def test_normals_bit_identical(d, site, seed, stream, root0):
     import torch
     from oracle import philox

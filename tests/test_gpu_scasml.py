@@ -71,7 +71,7 @@ def test_chunked_batches_equal_one_shot(monkeypatch):
     xt = _test_points(20, 50, 33)
     hip._engine.calls = 0
     one = hip.uz_solve(2, 2, xt)
-    monkeypatch.setattr(P, "POINT_BUFFER_BYTES", 29 * 24 * 4 * 7)      # 7 roots per chunk
+    monkeypatch.setattr(P, "POINT_BUFFER_BYTES", 29 * 32 * 4 * 7)      # 7 roots per chunk
     hip._engine.calls = 0
     assert np.array_equal(one, hip.uz_solve(2, 2, xt))
 
