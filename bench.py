@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md chip table (spec)
 MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md "Peak FP32 (matrix)"
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md chip table
 
 
 def parse():
@@ -133,20 +134,32 @@ def main():
     flops = n_inf * (2.0 * n_colloc * (d + 1) + 10.0 * m_feat)     # 2 N_inf N (d+1) + 10 N_inf M
     gp_ms = kernel_ms.get("gp_eval")
     traffic = None
+    # HBM bytes per launch come from separate rocprofv3 --pmc passes of this same command, condensed by
+    # profiles/summarize.py (they cannot be collected inside this process)
     prof = os.path.join(ROOT, "profiles", "r01_gp_eval_pmc.json")
     if os.path.exists(prof):
         try:
             pj = json.load(open(prof))
-            if pj.get("n_inf") == n_inf and pj.get("d") == d:
+            if pj.get("n_inf") == n_inf and pj.get("d") == d and pj.get("split") == int(gp.eval_split):
                 traffic = pj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     roofline = None
     if gp_ms:
         ach = flops / (gp_ms * 1e-3) / 1e12
-        roofline = {"kernel": "gp_eval_kernel", "bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "avg_launch_ms": round(gp_ms, 4), "flops_per_launch": flops}
+        split = int(gp.eval_split)
+        kp = (d + 2 + 15) // 16 * 16
+        n_pad = (n_colloc + 31) // 32 * 32
+        products = {0: 1, 2: 3, 3: 6}[split]
+        issued = products * 2.0 * n_inf * n_pad * kp / (gp_ms * 1e-3) / 1e12      # MFMA flops actually issued
+        peak = MFMA_F32_PEAK_TFLOPS if split == 0 else MFMA_BF16_PEAK_TFLOPS
+        roofline = {"kernel": "gp_eval_kernel (fp32 MFMA)" if split == 0 else "gp_eval_bf16_kernel (%d bf16 planes)" % split,
+                    "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": traffic, "avg_launch_ms": round(gp_ms, 4),
+                    "flops_per_launch": flops, "achieved_vs_fp32_mfma_peak": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+                    "mfma_issued_tflops": round(issued, 1), "mfma_issued_frac": round(issued / peak, 4),
+                    "note": "achieved = algorithmic fp32 flops (SURVEY 8(d)); the split-bf16 kernel issues %dx as many bf16 "
+                            "MFMA flops to keep products exact to fp32; on gfx950 MFMA and VALU time add (DESIGN.md 4.2)" % products}
     # the path kernels, priced with the materialised-state model of SURVEY.md 8(d): 16*d bytes per path-step
     path_ms = (kernel_ms.get("picard_generate") or 0.0) + (kernel_ms.get("picard_accumulate") or 0.0)
     path_roof = None

@@ -28,7 +28,8 @@ def one(pattern):
 
 def main():
     tag, trace_dir = sys.argv[1], sys.argv[2]
-    pmc_dirs = sys.argv[3:]
+    pmc_dirs = [a for a in sys.argv[3:] if "=" not in a]
+    extra = dict(a.split("=", 1) for a in sys.argv[3:] if "=" in a)      # e.g. n_inf=10911744 d=100 split=3
     stats = one(os.path.join(trace_dir, "*", "*_kernel_stats.csv"))
     shutil.copy(stats, os.path.join(HERE, tag + "_kernel_stats.csv"))
     rows = list(csv.DictReader(open(one(os.path.join(trace_dir, "*", "*_kernel_trace.csv")))))
@@ -44,8 +45,9 @@ def main():
             v = groups[key]
             f.write("%s | %d | %d | %.4f | %.4f | %.4f | %s\n" % (key[0], key[1], len(v), sum(v) / len(v), min(v), max(v), " ".join(meta[key])))
     if pmc_dirs:
-        big = max((k for k in groups if "gp_eval_kernel" in k[0]), key=lambda k: k[1])
+        big = max((k for k in groups if "gp_eval" in k[0]), key=lambda k: k[1])
         out = {"kernel": big[0], "grid_threads": big[1], "avg_ms_kernel_trace": sum(groups[big]) / len(groups[big])}
+        out.update({k: int(v) for k, v in extra.items()})
         for d in pmc_dirs:
             for r in csv.DictReader(open(one(os.path.join(d, "*", "*_counter_collection.csv")))):
                 if r["Kernel_Name"] == big[0] and int(r["Grid_Size"]) == big[1]:

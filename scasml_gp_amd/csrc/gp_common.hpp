@@ -17,6 +17,7 @@ struct GpArgs {
     int64_t n_inf;
     int32_t n_pad, kp, d;
     float a, sigma;
+    int32_t dbg;   // ablation switches (SCASML_GP_DBG, development only): 1 skip MFMA, 2 skip epilogue, 4 no stagger, 8 stage once
 };
 
 struct GpStageView {
@@ -42,25 +43,34 @@ constexpr int kCoefRow = 16;
 // extra K column a^2 |y|^2 against a constant 1 in the point row), and nx[] holds a^2 |x|^2 - a d, so
 // L0 = acc + nx = a^2 r2 - a d costs one add and kappa one fma + exp2; every row constant that would
 // cost a multiply per element is precomputed.  19 VALU per (collocation, point) pair.
-template <int PT, bool FOLD = false>
+template <int PT, bool FOLD = false, bool PF = true>
 __device__ __forceinline__ void gp_epilogue_tile(const GpStageView &st, const f32x16 (&acc)[PT], const GpConsts &c, int half,
                                                  const float (&nx)[PT], const float (&sx)[PT], const float (&tx)[PT],
                                                  float (&au)[PT], float (&at)[PT], float (&ad)[PT], float (&al)[PT]) {
     // C row = (r&3) + 8*(r>>2) + 4*half: one per-lane base (depends on the half-wave), compile-time row offsets
     const float4 *cb = reinterpret_cast<const float4 *>(__builtin_assume_aligned(st.coef + 4 * kCoefRow * half, 16));
     constexpr int NQ = FOLD ? 3 : 4;                     // float4 reads per row
-    float4 q[2][NQ];
+    // PF: rows ping-pong between two register sets (the reads of row r+1 are issued before row r is
+    // consumed); without PF one set is used and the other resident waves cover the LDS latency.  One
+    // row (PT independent chains) per scheduling region keeps the VGPR budget flat.
+    float4 q[PF ? 2 : 1][NQ];
+    if constexpr (PF) {
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) q[0][i] = cb[i];
+        for (int i = 0; i < NQ; ++i) q[0][i] = cb[i];
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        // rows ping-pong between two register sets: the reads of row r+1 are issued before row r is
-        // consumed; one row (PT independent chains) per scheduling region keeps the VGPR budget flat
-        const int cur = r & 1, nxt = cur ^ 1;
-        if (r + 1 < 16) {
-            const int off = (((r + 1) & 3) + 8 * ((r + 1) >> 2)) * (kCoefRow / 4);
+        const int cur = PF ? (r & 1) : 0, nxt = cur ^ 1;
+        if constexpr (PF) {
+            if (r + 1 < 16) {
+                const int off = (((r + 1) & 3) + 8 * ((r + 1) >> 2)) * (kCoefRow / 4);
 #pragma unroll
-            for (int i = 0; i < NQ; ++i) q[nxt][i] = cb[off + i];
+                for (int i = 0; i < NQ; ++i) q[nxt][i] = cb[off + i];
+            }
+        } else {
+            const int off = ((r & 3) + 8 * (r >> 2)) * (kCoefRow / 4);
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) q[0][i] = cb[off + i];
         }
         __builtin_amdgcn_sched_barrier(0);
         const float vsy = q[cur][0].x, vty = q[cur][0].y, vc0 = q[cur][0].z, vcL = q[cur][0].w;

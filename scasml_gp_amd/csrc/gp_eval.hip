@@ -22,6 +22,8 @@
 // The K loop is split between the half-waves (half h takes k in [h*kp/2, (h+1)*kp/2)), which makes
 // every lane's operand a contiguous run of its row: 16-byte loads, no LDS staging; the point tile
 // stays in VGPRs for the whole sweep and the collocation tile streams from L2 in fragment order.
+#include <stdlib.h>
+
 #include "gp_common.hpp"
 
 namespace scasml {
@@ -367,6 +369,8 @@ extern "C" int scasml_gp_eval(const scasml_gp_model *m, const float *points, int
     g.d = m->d;
     g.a = m->a;
     g.sigma = m->sigma_eq;
+    const char *dbg = getenv("SCASML_GP_DBG");
+    g.dbg = dbg ? atoi(dbg) : 0;
     hipStream_t s = (hipStream_t)stream;
     if (m->split == 2 || m->split == 3) {
         if (!m->colloc_bf16) return fail(SCASML_ERR_ARG, "gp_eval: split=%d needs colloc_bf16", m->split);

@@ -33,21 +33,28 @@ union Frag {
 };
 
 // KS = kp / 16 K-steps of the 32x32x16 MFMA; half-wave h covers k in [h*8*KS, (h+1)*8*KS)
-template <int KS, int SPLIT>
+template <int KS, int SPLIT, bool PF>
 __device__ __forceinline__ void gp_mfma_tile_bf16(const float4 *lds_a, const s16x8 (&xb)[SPLIT][KS], f32x16 &acc, int lane) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     // A fragments ping-pong between two register sets selected by the (compile-time) parity of the
     // step: the ds_reads of step s+1 are issued before the MFMAs of step s, with no register copies.
-    Frag a[2][SPLIT];
+    Frag a[PF ? 2 : 1][SPLIT];
+    if constexpr (PF) {
 #pragma unroll
-    for (int pl = 0; pl < SPLIT; ++pl) a[0][pl].f = lds_a[(pl * KS) * 64 + lane];
+        for (int pl = 0; pl < SPLIT; ++pl) a[0][pl].f = lds_a[(pl * KS) * 64 + lane];
+    }
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-        const int cur = s & 1, nxt = cur ^ 1;
-        if (s + 1 < KS) {
+        const int cur = PF ? (s & 1) : 0, nxt = cur ^ 1;
+        if constexpr (PF) {
+            if (s + 1 < KS) {
 #pragma unroll
-            for (int pl = 0; pl < SPLIT; ++pl) a[nxt][pl].f = lds_a[(pl * KS + s + 1) * 64 + lane];
+                for (int pl = 0; pl < SPLIT; ++pl) a[nxt][pl].f = lds_a[(pl * KS + s + 1) * 64 + lane];
+            }
+        } else {
+#pragma unroll
+            for (int pl = 0; pl < SPLIT; ++pl) a[0][pl].f = lds_a[(pl * KS + s) * 64 + lane];
         }
         // small terms first; plane 0 = hi, 1 = mid, 2 = lo
         if (SPLIT == 3) {
@@ -62,25 +69,30 @@ __device__ __forceinline__ void gp_mfma_tile_bf16(const float4 *lds_a, const s16
     }
 }
 
-template <int KS, int SPLIT>
-__global__ __launch_bounds__(512, 2) void gp_eval_bf16_kernel(const GpArgs g) {
+// WPB waves per workgroup (one workgroup per CU): 8 -> 2 waves/SIMD (<= 256 VGPRs, register prefetch
+// of LDS operands), 12 -> 3 waves/SIMD (<= 168 VGPRs, no register prefetch: a single wave issues a VALU
+// instruction only every ~7 cycles, so SIMD-level VALU throughput -- the epilogue -- scales with the
+// number of resident waves until the matrix pipe becomes the limit).
+template <int KS, int SPLIT, int WPB>
+__global__ __launch_bounds__(WPB * 64, WPB / 4) void gp_eval_bf16_kernel(const GpArgs g) {
+    constexpr bool PF = WPB <= 8;
     constexpr int STAGE = SPLIT * KS * 256 + 512;       // floats per LDS slot (A fragments + 32 rows x 16 coefficients)
     extern __shared__ __attribute__((aligned(16))) float lds[];   // 3 slots
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int col = lane & 31, half = lane >> 5;
-    const bool late = __builtin_amdgcn_readfirstlane(wv) >= 4;    // scalar, wave-uniform role
-    const int64_t p0 = ((int64_t)blockIdx.x * 8 + wv) * 32;
+    const bool late = (__builtin_amdgcn_readfirstlane(wv) >> 2) == 1 && !(g.dbg & 4);    // scalar, wave-uniform role
+    const int64_t p0 = ((int64_t)blockIdx.x * WPB + wv) * 32;
     const int n_tiles = g.n_pad / 32;
 
     // stage one collocation tile: 1 KiB chunks, chunk c < SPLIT*KS = A fragment (plane, step), last = coefficients
     auto stage = [&](int tile, int slot) {
         float *dst = lds + slot * STAGE;
         const float *src = reinterpret_cast<const float *>(g.colloc_bf16) + (int64_t)tile * 3 * KS * 256;
-        for (int c = wv; c < SPLIT * KS; c += 8)
+        for (int c = wv; c < SPLIT * KS; c += WPB)
             __builtin_amdgcn_global_load_lds(src + c * 256 + lane * 4, dst + c * 256, 16, 0, 0);
-        if (wv == ((SPLIT * KS) & 7))
+        if (wv == ((SPLIT * KS) % WPB))
             __builtin_amdgcn_global_load_lds(g.coef + (int64_t)tile * 512 + lane * 4, dst + SPLIT * KS * 256, 16, 0, 0);
-        if (wv == ((SPLIT * KS + 1) & 7))
+        if (wv == ((SPLIT * KS + 1) % WPB))
             __builtin_amdgcn_global_load_lds(g.coef + (int64_t)tile * 512 + 256 + lane * 4, dst + SPLIT * KS * 256 + 256, 16, 0, 0);
     };
     stage(0, 0);
@@ -145,19 +157,19 @@ __global__ __launch_bounds__(512, 2) void gp_eval_bf16_kernel(const GpArgs g) {
     __syncthreads();  // tile 0 has landed (the barrier drains the LDS-DMA)
     if (!late) {
         for (int jt = 0; jt < n_tiles; ++jt) {
-            if (jt + 1 < n_tiles) stage(jt + 1, (jt + 1) % 3);
-            gp_mfma_tile_bf16<KS, SPLIT>(a_of(jt % 3), xb, acc[0], lane);
-            gp_epilogue_tile<1, true>(view(jt % 3), acc, c, half, nx, sx, tx, au, at, ad, al);
+            if (jt + 1 < n_tiles && !(g.dbg & 8)) stage(jt + 1, (jt + 1) % 3);
+            if (!(g.dbg & 1)) gp_mfma_tile_bf16<KS, SPLIT, PF>(a_of(jt % 3), xb, acc[0], lane);
+            if (!(g.dbg & 2)) gp_epilogue_tile<1, true, PF>(view(jt % 3), acc, c, half, nx, sx, tx, au, at, ad, al);
             __syncthreads();
         }
     } else {
         for (int jt = 0; jt < n_tiles; ++jt) {
-            if (jt + 1 < n_tiles) stage(jt + 1, (jt + 1) % 3);
-            if (jt > 0) gp_epilogue_tile<1, true>(view((jt - 1) % 3), acc, c, half, nx, sx, tx, au, at, ad, al);
-            gp_mfma_tile_bf16<KS, SPLIT>(a_of(jt % 3), xb, acc[0], lane);
+            if (jt + 1 < n_tiles && !(g.dbg & 8)) stage(jt + 1, (jt + 1) % 3);
+            if (jt > 0 && !(g.dbg & 2)) gp_epilogue_tile<1, true, PF>(view((jt - 1) % 3), acc, c, half, nx, sx, tx, au, at, ad, al);
+            if (!(g.dbg & 1)) gp_mfma_tile_bf16<KS, SPLIT, PF>(a_of(jt % 3), xb, acc[0], lane);
             __syncthreads();
         }
-        gp_epilogue_tile<1, true>(view((n_tiles - 1) % 3), acc, c, half, nx, sx, tx, au, at, ad, al);
+        gp_epilogue_tile<1, true, PF>(view((n_tiles - 1) % 3), acc, c, half, nx, sx, tx, au, at, ad, al);
     }
 
     const float s2 = g.sigma * g.sigma;
@@ -175,17 +187,19 @@ __global__ __launch_bounds__(512, 2) void gp_eval_bf16_kernel(const GpArgs g) {
 
 template <int KS, int SPLIT>
 static int launch_one(const GpArgs &g, hipStream_t s) {
+    // three waves per SIMD while the bf16 planes of the point tile (SPLIT*4*KS VGPRs) leave room under 168
+    constexpr int WPB = (SPLIT * 4 * KS <= 96) ? 12 : 8;
     const int64_t waves = (g.n_inf + 31) / 32;
-    const int64_t blocks = (waves + 7) / 8;
+    const int64_t blocks = (waves + WPB - 1) / WPB;
     if (blocks > 0x7FFFFFFF) return fail(SCASML_ERR_UNSUPPORTED, "gp_eval: too many points");
     constexpr size_t lds_bytes = 3 * (SPLIT * KS * 256 + 512) * sizeof(float);
     static_assert(lds_bytes <= 160 * 1024, "LDS slots exceed 160 KiB");
-    auto kern = gp_eval_bf16_kernel<KS, SPLIT>;
+    auto kern = gp_eval_bf16_kernel<KS, SPLIT, WPB>;
     if (lds_bytes > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
             return fail(SCASML_ERR_HIP, "gp_eval: cannot reserve %zu bytes of LDS", lds_bytes);
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds_bytes, s, g);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WPB * 64), lds_bytes, s, g);
     return check_launch("gp_eval(bf16) launch");
 }
 

@@ -99,3 +99,22 @@ def test_fused_evaluation_and_gradient_match_oracle(d, nd, nb, n_inf):
     # torch in -> torch out, empty batch
     assert isinstance(gp.predict(torch.from_numpy(X).cuda()), torch.Tensor)
     assert gp.predict(X[:0]).shape == (0, 1)
+
+
+def test_evaluation_arithmetic_modes_agree():
+    """split = 3 (three bf16 planes, default) must be as exact as the fp32-input MFMA path
+    (split = 0); split = 2 (two truncated planes) is the documented lower-precision fast mode."""
+    gp, ora, dom, bdy = _setup(100, 150, 42, seed=6)
+    ora.GPsolver(dom, bdy, GN_steps=10)
+    gp.load_right_vector(dom, bdy, ora.right_vector)
+    X = np.random.default_rng(7).uniform(-0.6, 0.6, (513, 101)).astype(np.float32)
+    X[:, -1] = np.abs(X[:, -1])
+    mag = (np.abs(ora._features("I", X)) @ np.abs(ora.right_vector))[:, 0] + 1e-3
+    want = ora.predict(X)[:, 0]
+    err = {}
+    for split in (0, 2, 3):
+        gp.eval_split = split
+        err[split] = np.max(np.abs(gp.predict(X)[:, 0] - want) / mag)
+    assert err[3] <= 2e-6 and err[0] <= 2e-6, err
+    assert err[3] <= 2 * err[0] + 2e-7, err            # fp32-exact products
+    assert err[2] <= 1e-4, err

@@ -5,13 +5,14 @@
 //   2: both, interleaved in ONE wave (1 MFMA : 4 VALU)
 //   3: MFMA-only waves and VALU-only waves sharing a SIMD (waves 0-3 MFMA, 4-7 VALU of a 512-thread block)
 //   4: bf16 MFMA 32x32x16 only;  5: bf16 MFMA + VALU interleaved in one wave
+//   6: bf16-MFMA-only waves (0-3) and VALU-only waves (4-7) sharing a SIMD;  7: like 6 with 2 VALU waves per SIMD (waves 4-11)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 template <int MODE>
-__global__ __launch_bounds__(512) void k(float *out, int iters, float a, float b) {
+__global__ __launch_bounds__(768) void k(float *out, int iters, float a, float b) {
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     f32x16 acc0 = {0}, acc1 = {0};
     float v[32];
@@ -21,7 +22,18 @@ __global__ __launch_bounds__(512) void k(float *out, int iters, float a, float b
     const bool do_m = MODE == 0 || MODE == 2 || (MODE == 3 && wv < 4);
     const bool do_v = MODE == 1 || MODE == 2 || (MODE == 3 && wv >= 4);
     for (int it = 0; it < iters; ++it) {
-        if (MODE == 4 || MODE == 5) {
+        if (MODE == 6 || MODE == 7) {
+            if (wv < 4) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (j & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, ab, acc1, 0, 0, 0);
+                    else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, ab, acc0, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 32; ++i) v[i] = __builtin_fmaf(v[i], a, b);
+            }
+        } else if (MODE == 4 || MODE == 5) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 if (j & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, ab, acc1, 0, 0, 0);
@@ -75,7 +87,7 @@ float run(float *out, int threads, int iters) {
 
 int main() {
     float *out;
-    hipMalloc(&out, 256 * 512 * 4);
+    hipMalloc(&out, 256 * 768 * 4);
     const int it = 200000;
     printf("one wave per SIMD (256 threads/block, 1 block/CU)\n");
     printf("  0 mfma_f32 only      : %.3f ms\n", run<0>(out, 256, it));
@@ -89,5 +101,10 @@ int main() {
     printf("  3 mfma waves || valu waves : %.3f ms\n", run<3>(out, 512, it));
     printf("  2 interleaved, both waves  : %.3f ms\n", run<2>(out, 512, it));
     printf("  5 bf16+valu, both waves    : %.3f ms\n", run<5>(out, 512, it));
+    printf("  4 mfma_bf16 only, both     : %.3f ms\n", run<4>(out, 512, it));
+    printf("  6 bf16 mfma waves || valu waves (1+1 per SIMD) : %.3f ms\n", run<6>(out, 512, it));
+    printf("three waves per SIMD (768 threads/block)\n");
+    printf("  1 valu only                : %.3f ms\n", run<1>(out, 768, it));
+    printf("  7 bf16 mfma wave || 2 valu waves per SIMD : %.3f ms\n", run<7>(out, 768, it));
     return 0;
 }
