@@ -126,12 +126,13 @@ typedef struct {
     int32_t n_dom, n_bdy;        /* N_Omega, N_dOmega                                        */
     int32_t n_pad;               /* (n_dom + n_bdy) rounded up to 32                         */
     int32_t kp;                  /* point stride = round_up(d+2, 16)                         */
-    int32_t split;               /* x.y arithmetic: 0 = fp32 MFMA, 2 / 3 = bf16 MFMA on 2 / 3 bf16 planes (3 = fp32-exact) */
+    int32_t split;               /* x.y arithmetic: 0 = fp32 MFMA; 3 / 2 = bf16 MFMA on 3 (fp32-exact) / 2 bf16 planes;
+                                    22 = fp16 MFMA on two fp16 planes (22-bit products, 3 MFMAs per K-step) */
     float a;                     /* 1/sigma_k^2, sigma_k = 0.25*sqrt(d) (models/GP.py:25)    */
     float sigma_eq;              /* equation sigma (models/GP.py:748)                        */
     const float *colloc;         /* n_pad x kp   collocation points, domain first, zero pad  */
     const float *colloc_frag;    /* the same, in fp32 MFMA A-fragment order [tile][kp/8][64][4] */
-    const uint16_t *colloc_bf16; /* the same as 3 truncated-bf16 planes, [tile][plane][kp/16][64][8] */
+    const uint16_t *colloc_bf16; /* 5*n_pad*kp halfwords: 3 truncated-bf16 planes [tile][plane][kp/16][64][8], then 2 fp16 planes */
     const float *coef;           /* n_pad x 16   per-row constants (|y|^2, a*sum y, a*t_y, c0, cL, ct, cS, 0, a*ct, ...) */
 } scasml_gp_model;
 
@@ -139,7 +140,7 @@ typedef struct {
  * c0 = rv[u(X)] (domain and boundary rows), cL = rv[Lap], ct = rv[dt], cS = rv[div] (zero on
  * boundary rows).  x_dom: n_dom x (d+1), x_bdy: n_bdy x (d+1), rv: 4*n_dom + n_bdy (float64). */
 int scasml_gp_pack(int32_t d, float a, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy,
-                   const double *rv, float *colloc_out, float *colloc_frag_out, uint16_t *colloc_bf16_out /* 3*n_pad*kp */,
+                   const double *rv, float *colloc_out, float *colloc_frag_out, uint16_t *colloc_bf16_out /* 5*n_pad*kp */,
                    float *coef_out, void *stream);
 
 /*

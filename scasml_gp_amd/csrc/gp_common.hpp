@@ -11,6 +11,7 @@ struct GpArgs {
     const float *points;       // n_inf x kp
     const float *colloc_frag;  // [n_tiles][NK4][64][4]
     const uint16_t *colloc_bf16;  // [n_tiles][3 planes][kp/16][64][8] truncated-bf16 planes
+    const uint16_t *colloc_f16;   // [n_tiles][2 planes][kp/16][64][8] fp16 planes (h, 2^11 * l)
     const float *coef;         // [n_pad][8]
     float4 *out4;              // n_inf x (u, div, eps, dt)
     float *lap;                // n_inf or null

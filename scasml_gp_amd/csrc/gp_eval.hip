@@ -277,6 +277,12 @@ __global__ void gp_pack_kernel(int d, float a, const float *x_dom, int n_dom, co
         bf[((int64_t)tile * 3 + 0) * ks * 512 + e] = (uint16_t)(hb >> 16);
         bf[((int64_t)tile * 3 + 1) * ks * 512 + e] = (uint16_t)(mb >> 16);
         bf[((int64_t)tile * 3 + 2) * ks * 512 + e] = (uint16_t)(lb >> 16);
+        // fp16 planes (h, 2^11 * l) of the same folded operand, stored behind the bf16 planes
+        uint16_t *hf = bf + (int64_t)3 * n_pad * kp;
+        const _Float16 fh = (_Float16)vf;
+        const _Float16 fl = (_Float16)((vf - (float)fh) * 2048.0f);
+        hf[((int64_t)tile * 2 + 0) * ks * 512 + e] = __builtin_bit_cast(unsigned short, fh);
+        hf[((int64_t)tile * 2 + 1) * ks * 512 + e] = __builtin_bit_cast(unsigned short, fl);
         ny = fmaf(v, v, ny);
         if (k < d) sy += v;
         if (k == d) ty = v;
@@ -360,6 +366,7 @@ extern "C" int scasml_gp_eval(const scasml_gp_model *m, const float *points, int
     g.points = points;
     g.colloc_frag = m->colloc_frag;
     g.colloc_bf16 = m->colloc_bf16;
+    g.colloc_f16 = m->colloc_bf16 ? m->colloc_bf16 + (int64_t)3 * m->n_pad * m->kp : nullptr;
     g.coef = m->coef;
     g.out4 = reinterpret_cast<float4 *>(out4);
     g.lap = lap;
@@ -372,11 +379,11 @@ extern "C" int scasml_gp_eval(const scasml_gp_model *m, const float *points, int
     const char *dbg = getenv("SCASML_GP_DBG");
     g.dbg = dbg ? atoi(dbg) : 0;
     hipStream_t s = (hipStream_t)stream;
-    if (m->split == 2 || m->split == 3) {
+    if (m->split == 2 || m->split == 3 || m->split == 22) {
         if (!m->colloc_bf16) return fail(SCASML_ERR_ARG, "gp_eval: split=%d needs colloc_bf16", m->split);
         return launch_gp_eval_bf16(g, m->split, s);
     }
-    if (m->split != 0) return fail(SCASML_ERR_ARG, "gp_eval: split must be 0, 2 or 3");
+    if (m->split != 0) return fail(SCASML_ERR_ARG, "gp_eval: split must be 0, 2, 3 or 22");
 #define SCASML_EVAL_CASE(NK) \
     case NK: return launch_eval<NK>(g, s);
     switch (m->kp / 8) {

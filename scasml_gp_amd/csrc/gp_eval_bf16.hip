@@ -8,6 +8,12 @@
 // lo*hi carry every term down to 2^-24, i.e. x.y is as exact as the fp32 MFMA (SPLIT = 3, 6 MFMAs per
 // K-step); SPLIT = 2 keeps hi/mid only (3 MFMAs, ~2^-17 per product).  Accumulation is fp32 in the MFMA.
 //
+// MODE 22 ("fp16x2"): two fp16 planes  v = h + 2^-11 * l'  (h = fp16(v), l' = fp16(2^11 (v - h)); 11 + 11
+// mantissa bits, products exact in the fp32 MFMA accumulator).  h*h goes to one accumulator, the cross
+// terms h*l' + l'*h to a second one that enters as 2^-11 * acc2 (l'*l' ~ 2^-22 is dropped): 3 MFMAs per
+// K-step instead of 6, product accuracy ~2^-22 instead of 2^-24.  Planes are stored in the same buffer and
+// fragment order as the bf16 planes (plane 0 = h, plane 1 = l').
+//
 // Structure (same as gp_eval.hip): workgroup of 8 waves, 32 points per wave held in VGPRs as bf16 planes
 // for the whole sweep; per collocation tile one LDS slot [SPLIT*KS KiB of A fragments | 1 KiB coefficients]
 // filled one tile ahead by global_load_lds; one barrier per tile; SIMD partner waves (w, w+4) run half a
@@ -17,6 +23,7 @@
 namespace scasml {
 
 typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void split3(float v, uint32_t &h, uint32_t &m, uint32_t &l) {
     h = __float_as_uint(v) & 0xFFFF0000u;
@@ -28,15 +35,22 @@ __device__ __forceinline__ void split3(float v, uint32_t &h, uint32_t &m, uint32
 
 union Frag {
     s16x8 v;
+    h16x8 h;
     uint32_t u[4];
     float4 f;
 };
 
+__device__ __forceinline__ uint32_t pack_h2(float a, float b) {   // two fp16 (RNE) in one dword, a low
+    const _Float16 ha = (_Float16)a, hb = (_Float16)b;
+    return (uint32_t)__builtin_bit_cast(unsigned short, ha) | ((uint32_t)__builtin_bit_cast(unsigned short, hb) << 16);
+}
+
 // KS = kp / 16 K-steps of the 32x32x16 MFMA; half-wave h covers k in [h*8*KS, (h+1)*8*KS)
-template <int KS, int SPLIT, bool PF>
+template <int KS, int SPLIT, bool PF, bool F16>
 __device__ __forceinline__ void gp_mfma_tile_bf16(const float4 *lds_a, const s16x8 (&xb)[SPLIT][KS], f32x16 &acc, int lane) {
+    f32x16 acc2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int r = 0; r < 16; ++r) acc[r] = acc2[r] = 0.0f;
     // A fragments ping-pong between two register sets selected by the (compile-time) parity of the
     // step: the ds_reads of step s+1 are issued before the MFMAs of step s, with no register copies.
     Frag a[PF ? 2 : 1][SPLIT];
@@ -56,6 +70,16 @@ __device__ __forceinline__ void gp_mfma_tile_bf16(const float4 *lds_a, const s16
 #pragma unroll
             for (int pl = 0; pl < SPLIT; ++pl) a[0][pl].f = lds_a[(pl * KS + s) * 64 + lane];
         }
+        if constexpr (F16) {   // plane 0 = h, plane 1 = 2^11 * l
+            Frag b0, b1;
+            b0.v = xb[0][s];
+            b1.v = xb[1][s];
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cur][1].h, b0.h, acc2, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cur][0].h, b1.h, acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cur][0].h, b0.h, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            continue;
+        }
         // small terms first; plane 0 = hi, 1 = mid, 2 = lo
         if (SPLIT == 3) {
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][2].v, xb[0][s], acc, 0, 0, 0);
@@ -67,15 +91,20 @@ __device__ __forceinline__ void gp_mfma_tile_bf16(const float4 *lds_a, const s16
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0].v, xb[0][s], acc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (F16) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = fmaf(acc2[r], 0x1p-11f, acc[r]);
+    }
 }
 
 // WPB waves per workgroup (one workgroup per CU): 8 -> 2 waves/SIMD (<= 256 VGPRs, register prefetch
 // of LDS operands), 12 -> 3 waves/SIMD (<= 168 VGPRs, no register prefetch: a single wave issues a VALU
 // instruction only every ~7 cycles, so SIMD-level VALU throughput -- the epilogue -- scales with the
 // number of resident waves until the matrix pipe becomes the limit).
-template <int KS, int SPLIT, int WPB>
+template <int KS, int SPLIT, int WPB, bool F16>
 __global__ __launch_bounds__(WPB * 64, WPB / 4) void gp_eval_bf16_kernel(const GpArgs g) {
     constexpr bool PF = WPB <= 8;
+    static_assert(WPB == 8 || WPB == 12 || WPB == 16, "waves per workgroup");
     constexpr int STAGE = SPLIT * KS * 256 + 512;       // floats per LDS slot (A fragments + 32 rows x 16 coefficients)
     extern __shared__ __attribute__((aligned(16))) float lds[];   // 3 slots
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -87,7 +116,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void gp_eval_bf16_kernel(const G
     // stage one collocation tile: 1 KiB chunks, chunk c < SPLIT*KS = A fragment (plane, step), last = coefficients
     auto stage = [&](int tile, int slot) {
         float *dst = lds + slot * STAGE;
-        const float *src = reinterpret_cast<const float *>(g.colloc_bf16) + (int64_t)tile * 3 * KS * 256;
+        const float *src = reinterpret_cast<const float *>(F16 ? g.colloc_f16 : g.colloc_bf16) + (int64_t)tile * (F16 ? 2 : 3) * KS * 256;
         for (int c = wv; c < SPLIT * KS; c += WPB)
             __builtin_amdgcn_global_load_lds(src + c * 256 + lane * 4, dst + c * 256, 16, 0, 0);
         if (wv == ((SPLIT * KS) % WPB))
@@ -123,9 +152,16 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void gp_eval_bf16_kernel(const G
             Frag fh, fm, fl;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {   // element 2c in the low half-word, 2c+1 in the high one
-                fh.u[c] = (hb[2 * c] >> 16) | hb[2 * c + 1];
-                fm.u[c] = (mb[2 * c] >> 16) | mb[2 * c + 1];
-                fl.u[c] = (lb[2 * c] >> 16) | lb[2 * c + 1];
+                if constexpr (F16) {
+                    const float h0 = (float)(_Float16)e[2 * c], h1 = (float)(_Float16)e[2 * c + 1];
+                    fh.u[c] = pack_h2(e[2 * c], e[2 * c + 1]);
+                    fm.u[c] = pack_h2((e[2 * c] - h0) * 2048.0f, (e[2 * c + 1] - h1) * 2048.0f);
+                    fl.u[c] = 0;
+                } else {
+                    fh.u[c] = (hb[2 * c] >> 16) | hb[2 * c + 1];
+                    fm.u[c] = (mb[2 * c] >> 16) | mb[2 * c + 1];
+                    fl.u[c] = (lb[2 * c] >> 16) | lb[2 * c + 1];
+                }
             }
             xb[0][s] = fh.v;
             xb[1][s] = fm.v;
@@ -158,7 +194,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void gp_eval_bf16_kernel(const G
     if (!late) {
         for (int jt = 0; jt < n_tiles; ++jt) {
             if (jt + 1 < n_tiles && !(g.dbg & 8)) stage(jt + 1, (jt + 1) % 3);
-            if (!(g.dbg & 1)) gp_mfma_tile_bf16<KS, SPLIT, PF>(a_of(jt % 3), xb, acc[0], lane);
+            if (!(g.dbg & 1)) gp_mfma_tile_bf16<KS, SPLIT, PF, F16>(a_of(jt % 3), xb, acc[0], lane);
             if (!(g.dbg & 2)) gp_epilogue_tile<1, true, PF>(view(jt % 3), acc, c, half, nx, sx, tx, au, at, ad, al);
             __syncthreads();
         }
@@ -166,7 +202,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void gp_eval_bf16_kernel(const G
         for (int jt = 0; jt < n_tiles; ++jt) {
             if (jt + 1 < n_tiles && !(g.dbg & 8)) stage(jt + 1, (jt + 1) % 3);
             if (jt > 0 && !(g.dbg & 2)) gp_epilogue_tile<1, true, PF>(view((jt - 1) % 3), acc, c, half, nx, sx, tx, au, at, ad, al);
-            if (!(g.dbg & 1)) gp_mfma_tile_bf16<KS, SPLIT, PF>(a_of(jt % 3), xb, acc[0], lane);
+            if (!(g.dbg & 1)) gp_mfma_tile_bf16<KS, SPLIT, PF, F16>(a_of(jt % 3), xb, acc[0], lane);
             __syncthreads();
         }
         gp_epilogue_tile<1, true, PF>(view((n_tiles - 1) % 3), acc, c, half, nx, sx, tx, au, at, ad, al);
@@ -185,16 +221,17 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void gp_eval_bf16_kernel(const G
     }
 }
 
-template <int KS, int SPLIT>
+template <int KS, int SPLIT, bool F16>
 static int launch_one(const GpArgs &g, hipStream_t s) {
-    // three waves per SIMD while the bf16 planes of the point tile (SPLIT*4*KS VGPRs) leave room under 168
-    constexpr int WPB = (SPLIT * 4 * KS <= 96) ? 12 : 8;
+    // three waves per SIMD while the 16-bit planes of the point tile (SPLIT*4*KS VGPRs) leave room under 168
+    constexpr int REGS = SPLIT * 4 * KS + (F16 ? 16 : 0);       // point-tile planes + second accumulator
+    constexpr int WPB = REGS <= 72 ? 16 : (REGS <= 96 ? 12 : 8);
     const int64_t waves = (g.n_inf + 31) / 32;
     const int64_t blocks = (waves + WPB - 1) / WPB;
     if (blocks > 0x7FFFFFFF) return fail(SCASML_ERR_UNSUPPORTED, "gp_eval: too many points");
     constexpr size_t lds_bytes = 3 * (SPLIT * KS * 256 + 512) * sizeof(float);
     static_assert(lds_bytes <= 160 * 1024, "LDS slots exceed 160 KiB");
-    auto kern = gp_eval_bf16_kernel<KS, SPLIT, WPB>;
+    auto kern = gp_eval_bf16_kernel<KS, SPLIT, WPB, F16>;
     if (lds_bytes > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
             return fail(SCASML_ERR_HIP, "gp_eval: cannot reserve %zu bytes of LDS", lds_bytes);
@@ -203,11 +240,11 @@ static int launch_one(const GpArgs &g, hipStream_t s) {
     return check_launch("gp_eval(bf16) launch");
 }
 
-template <int SPLIT>
+template <int SPLIT, bool F16>
 static int launch_split(const GpArgs &g, hipStream_t s) {
     switch (g.kp / 16) {
 #define SCASML_CASE(K) \
-    case K: return launch_one<K, SPLIT>(g, s);
+    case K: return launch_one<K, SPLIT, F16>(g, s);
         SCASML_CASE(1) SCASML_CASE(2) SCASML_CASE(3) SCASML_CASE(4) SCASML_CASE(5) SCASML_CASE(6) SCASML_CASE(7) SCASML_CASE(8)
         SCASML_CASE(9) SCASML_CASE(10) SCASML_CASE(11) SCASML_CASE(12) SCASML_CASE(13) SCASML_CASE(14) SCASML_CASE(15) SCASML_CASE(16)
 #undef SCASML_CASE
@@ -216,7 +253,8 @@ static int launch_split(const GpArgs &g, hipStream_t s) {
 }
 
 int launch_gp_eval_bf16(const GpArgs &g, int split, hipStream_t s) {
-    return split == 3 ? launch_split<3>(g, s) : launch_split<2>(g, s);
+    if (split == 22) return launch_split<2, true>(g, s);
+    return split == 3 ? launch_split<3, false>(g, s) : launch_split<2, false>(g, s);
 }
 
 }  // namespace scasml

@@ -42,8 +42,9 @@ class GP(object):
         self.nugget = 1e-2                                   # :26
         self.right_vector = None
         # arithmetic of x.y in the fused evaluation: 3 = three bf16 planes on the bf16 matrix cores
-        # (products exact to fp32), 2 = two planes (~2^-17 per product), 0 = fp32-input MFMA
-        self.eval_split = int(os.environ.get("SCASML_GP_SPLIT", "3"))
+        # (products exact to fp32), 22 = two fp16 planes (22-bit products, half the MFMAs), 2 = two bf16
+        # planes (~2^-16 per product), 0 = fp32-input MFMA
+        self.eval_split = int(os.environ.get("SCASML_GP_SPLIT", "22"))
 
     # ------------------------------------------------------------------ device helpers
     def _points_device(self, x):
@@ -212,7 +213,7 @@ class GP(object):
         self._n_pad = _round_up(self.N_domain + self.N_boundary, _lib.GP_TILE)
         self._colloc = torch.empty((self._n_pad, kp), dtype=torch.float32, device="cuda")
         self._frag = torch.empty((self._n_pad * kp,), dtype=torch.float32, device="cuda")
-        self._bf16 = torch.empty((3 * self._n_pad * kp,), dtype=torch.int16, device="cuda")
+        self._bf16 = torch.empty((5 * self._n_pad * kp,), dtype=torch.int16, device="cuda")
         self._coef = torch.empty((self._n_pad, 16), dtype=torch.float32, device="cuda")
         rv = rv.contiguous()
         _lib.check(lib.scasml_gp_pack(self.d, 1.0 / float(self.sigma) ** 2, _lib.ptr(self._xd), self.N_domain,

@@ -112,9 +112,10 @@ def test_evaluation_arithmetic_modes_agree():
     mag = (np.abs(ora._features("I", X)) @ np.abs(ora.right_vector))[:, 0] + 1e-3
     want = ora.predict(X)[:, 0]
     err = {}
-    for split in (0, 2, 3):
+    for split in (0, 2, 3, 22):
         gp.eval_split = split
         err[split] = np.max(np.abs(gp.predict(X)[:, 0] - want) / mag)
     assert err[3] <= 2e-6 and err[0] <= 2e-6, err
     assert err[3] <= 2 * err[0] + 2e-7, err            # fp32-exact products
+    assert err[22] <= 4e-6, err                         # 22-bit products
     assert err[2] <= 1e-4, err
