@@ -101,9 +101,11 @@ __device__ __forceinline__ void gp_mfma_tile_bf16(const float4 *lds_a, const s16
 // of LDS operands), 12 -> 3 waves/SIMD (<= 168 VGPRs, no register prefetch: a single wave issues a VALU
 // instruction only every ~7 cycles, so SIMD-level VALU throughput -- the epilogue -- scales with the
 // number of resident waves until the matrix pipe becomes the limit).
-template <int KS, int SPLIT, int WPB, bool F16>
-__global__ __launch_bounds__(WPB * 64, WPB / 4) void gp_eval_bf16_kernel(const GpArgs g) {
-    constexpr bool PF = WPB <= 8;
+// BPC = workgroups meant to be co-resident per CU (occupancy = WPB/4 * BPC waves per SIMD): with two
+// 8-wave workgroups per CU one workgroup's point-row prologue and final stores overlap the other's sweep.
+template <int KS, int SPLIT, int WPB, bool F16, int BPC>
+__global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(const GpArgs g) {
+    constexpr bool PF = WPB * BPC <= 8;
     static_assert(WPB == 8 || WPB == 12 || WPB == 16, "waves per workgroup");
     constexpr int STAGE = SPLIT * KS * 256 + 512;       // floats per LDS slot (A fragments + 32 rows x 16 coefficients)
     extern __shared__ __attribute__((aligned(16))) float lds[];   // 3 slots
@@ -225,13 +227,15 @@ template <int KS, int SPLIT, bool F16>
 static int launch_one(const GpArgs &g, hipStream_t s) {
     // three waves per SIMD while the 16-bit planes of the point tile (SPLIT*4*KS VGPRs) leave room under 168
     constexpr int REGS = SPLIT * 4 * KS + (F16 ? 16 : 0);       // point-tile planes + second accumulator
-    constexpr int WPB = REGS <= 72 ? 16 : (REGS <= 96 ? 12 : 8);
+    constexpr int WPS = REGS <= 72 ? 4 : (REGS <= 96 ? 3 : 2);  // waves per SIMD the VGPR budget allows
+    constexpr int BPC = WPS == 4 ? 2 : 1;
+    constexpr int WPB = WPS * 4 / BPC;
     const int64_t waves = (g.n_inf + 31) / 32;
     const int64_t blocks = (waves + WPB - 1) / WPB;
     if (blocks > 0x7FFFFFFF) return fail(SCASML_ERR_UNSUPPORTED, "gp_eval: too many points");
     constexpr size_t lds_bytes = 3 * (SPLIT * KS * 256 + 512) * sizeof(float);
     static_assert(lds_bytes <= 160 * 1024, "LDS slots exceed 160 KiB");
-    auto kern = gp_eval_bf16_kernel<KS, SPLIT, WPB, F16>;
+    auto kern = gp_eval_bf16_kernel<KS, SPLIT, WPB, F16, BPC>;
     if (lds_bytes > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
             return fail(SCASML_ERR_HIP, "gp_eval: cannot reserve %zu bytes of LDS", lds_bytes);
