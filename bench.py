@@ -34,7 +34,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--d", type=int, default=100)
     ap.add_argument("--level", type=int, default=3, help="n = rho")
-    ap.add_argument("--batch", type=int, default=1 << 14, help="evaluation points per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="evaluation points per GPU (default 2^14; 2^20 for --solver mlp)")
+    ap.add_argument("--solver", choices=["scasml", "mlp"], default="scasml")
+    ap.add_argument("--variant", choices=["quad", "fh"], default="quad", help="quadrature (MLP/ScaSML) or full history")
+    ap.add_argument("--M", type=int, default=3, help="sample base of the full-history solvers")
     ap.add_argument("--train-domain", type=int, default=1000)
     ap.add_argument("--train-boundary", type=int, default=200)
     ap.add_argument("--cpu-sample", type=int, default=64, help="roots of the same workload timed on the CPU oracle")
@@ -42,6 +45,38 @@ def parse():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development only: all ranks share cuda:0 and rendezvous over gloo (a 1-GPU box cannot host RCCL ranks)")
     return ap.parse_args()
+
+
+def cpu_baseline(args, eq, gp, eng, n, par, x_t, x_dev, x_dom, x_bdy, steps_exec, B):
+    """Time the oracle restatement (NumPy float64) on a bounded sample of the same workload, same inputs and
+    Philox streams, and report the GPU-vs-CPU difference on that sample."""
+    from oracle.equation import GradDependentNonlinear
+    from oracle.gp import OracleGP
+    from oracle.mlp import PicardOracle
+    d = args.d
+    oeq = GradDependentNonlinear(d + 1)
+    ogp = None
+    if gp is not None:
+        ogp = OracleGP(oeq)
+        ogp.x_t_domain = np.asarray(x_dom, dtype=np.float64)     # same trained surrogate as the GPU run
+        ogp.x_t_boundary = np.asarray(x_bdy, dtype=np.float64)
+        ogp.N_domain, ogp.N_boundary = len(x_dom), len(x_bdy)
+        ogp.right_vector = gp.right_vector
+    ns = min(args.cpu_sample if gp is not None else 4096 * args.cpu_sample, B)   # ~10-20 s of CPU work either way
+    ora = PicardOracle(oeq, args.variant, gp=ogp, seed=0, stream=99)
+    t0 = time.perf_counter()
+    uz_cpu = ora.uz_solve(n, par, x_t[:ns])
+    t_cpu = time.perf_counter() - t0
+    uz_gpu, _, _ = eng.solve(n, par, x_dev[:ns], stream_id=99)
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count()
+    return {"value": round(ns * steps_exec / t_cpu, 1), "unit": "path-steps/s", "cores": threads, "kind": "port",
+            "sample": "%d of the %d roots, same inputs and Philox streams, NumPy float64 oracle (oracle/mlp.py%s), %.1f s"
+                      % (ns, B, " + oracle/gp.py" if gp is not None else "", t_cpu),
+            "max_abs_diff_gpu_vs_cpu": float(np.nanmax(np.abs(uz_gpu.cpu().numpy() - uz_cpu)))}
 
 
 def main():
@@ -67,9 +102,14 @@ def main():
     from scasml_gp_amd import tables
     from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
     from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
+    from scasml_gp_amd.solvers.MLP import MLP
+    from scasml_gp_amd.solvers.MLP_full_history import MLP_full_history
     from scasml_gp_amd.solvers.ScaSML import ScaSML
+    from scasml_gp_amd.solvers.ScaSML_full_history import ScaSML_full_history
 
-    d, n, B = args.d, args.level, args.batch
+    d, n = args.d, args.level
+    B = args.batch if args.batch else ((1 << 20) if args.solver == "mlp" else (1 << 14))
+    par = n if args.variant == "quad" else args.M            # rho = n, or the full-history sample base M
     eq = Grad_Dependent_Nonlinear(d + 1)
     eq.geometry()
 
@@ -80,24 +120,28 @@ def main():
     x_dom, x_bdy = eq.generate_data(args.train_domain, args.train_boundary)
     xt_h = np.concatenate(eq.generate_test_data(1000, 200)).astype(np.float32)   # harness test set
     np.random.set_state(state)
-    gp = GP_Grad_Dependent_Nonlinear(eq)
-    t0 = time.time()
-    gp.GPsolver(x_dom, x_bdy, GN_steps=20)
-    torch.cuda.synchronize()
-    t_train = time.time() - t0
-    solver = ScaSML(eq, gp, seed=0)
+    gp, t_train = None, 0.0
+    if args.solver == "scasml":
+        gp = GP_Grad_Dependent_Nonlinear(eq)
+        t0 = time.time()
+        gp.GPsolver(x_dom, x_bdy, GN_steps=20)
+        torch.cuda.synchronize()
+        t_train = time.time() - t0
+        solver = (ScaSML if args.variant == "quad" else ScaSML_full_history)(eq, gp, seed=0)
+    else:
+        solver = (MLP if args.variant == "quad" else MLP_full_history)(eq, seed=0)
 
     # synthetic inputs: x ~ U[-0.5, 0.5]^d, t ~ U[0, 0.5), resident in HBM before timing
     g = np.random.default_rng(1234 + rank)
     x_t = np.concatenate([g.uniform(-0.5, 0.5, (B, d)), g.uniform(0.0, 0.5, (B, 1))], axis=1).astype(np.float32)
     x_dev = torch.from_numpy(x_t).cuda()
     eng = solver._engine
-    plan = eng.plan(n, n)
+    plan = eng.plan(n, par)
     steps_exec = tables.executed_path_steps(plan)
-    steps_ref = tables.reference_path_steps("quad", n, n, float(eq.T))
+    steps_ref = tables.reference_path_steps(args.variant, n, par, float(eq.T))
 
     def one_step():
-        out, uhat, _ = eng.solve(n, n, x_dev, root0=rank * B)
+        out, uhat, _ = eng.solve(n, par, x_dev, root0=rank * B)
         return out, uhat
 
     for _ in range(args.warmup):
@@ -129,9 +173,9 @@ def main():
     # ---- accuracy on the harness protocol (untimed): 1000 + 200 test points ---------------------
     from oracle.equation import rel_l2                       # metric definition only (tests/SimpleUniform.py:134-136)
     exact = eq.exact_solution(xt_h)
-    u_gpu = solver.u_solve(n, n, xt_h)
+    u_gpu = solver.u_solve(n, par, xt_h) if args.variant == "quad" else solver.u_solve(n, None, xt_h, args.M)
     rel_gpu = rel_l2(u_gpu, exact)
-    rel_gp = rel_l2(gp.predict(xt_h), exact)
+    rel_gp = rel_l2(gp.predict(xt_h), exact) if gp is not None else None
 
     # ---- roofline of the dominant kernel (fused GP evaluation, MFMA-bound) ----------------------
     n_colloc = args.train_domain + args.train_boundary
@@ -152,6 +196,16 @@ def main():
         except Exception:
             traffic = None
     roofline = None
+    if kernel_ms.get("picard_mlp"):
+        # plain MLP: the whole recursion is one kernel with no HBM traffic between the root row and the result;
+        # priced with the materialised-state model of SURVEY.md 8(d) (16*d bytes per path-step) for comparability
+        ms = kernel_ms["picard_mlp"]
+        gbs = B * steps_exec * 16.0 * d / (ms * 1e-3) / 1e9
+        roofline = {"kernel": "picard_tree_kernel (MODE_MLP)", "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": 2.0 * B * (d + 1) * 4,
+                    "avg_launch_ms": round(ms, 4),
+                    "note": "algorithmic bytes of the materialised model; the fused kernel keeps all path state in VGPRs, "
+                            "its real traffic is the root rows in and out, and it is Philox/ALU-bound"}
     if gp_ms:
         ach = flops / (gp_ms * 1e-3) / 1e12
         split = int(gp.eval_split)
@@ -179,46 +233,28 @@ def main():
     # ---- CPU baseline: the oracle restatement on a bounded sample of the same workload ----------
     cpu = None
     if not args.no_cpu_baseline and world == 1:
-        from oracle.equation import GradDependentNonlinear
-        from oracle.gp import OracleGP
-        from oracle.mlp import PicardOracle
-        oeq = GradDependentNonlinear(d + 1)
-        ogp = OracleGP(oeq)
-        ogp.x_t_domain = np.asarray(x_dom, dtype=np.float64)     # same trained surrogate as the GPU run
-        ogp.x_t_boundary = np.asarray(x_bdy, dtype=np.float64)
-        ogp.N_domain, ogp.N_boundary = len(x_dom), len(x_bdy)
-        ogp.right_vector = gp.right_vector
-        ns = min(args.cpu_sample, B)
-        ora = PicardOracle(oeq, "quad", gp=ogp, seed=0, stream=99)
-        t0 = time.perf_counter()
-        uz_cpu = ora.uz_solve(n, n, x_t[:ns])
-        t_cpu = time.perf_counter() - t0
-        uz_gpu, _, _ = eng.solve(n, n, x_dev[:ns], stream_id=99)
-        try:
-            from threadpoolctl import threadpool_info
-            threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-        except Exception:
-            threads = os.cpu_count()
-        cpu = {"value": round(ns * steps_exec / t_cpu, 1), "unit": "path-steps/s", "cores": threads, "kind": "port",
-               "sample": "%d of the %d roots, same inputs and Philox streams, NumPy float64 oracle (oracle/mlp.py + oracle/gp.py), %.1f s"
-                         % (ns, B, t_cpu),
-               "max_abs_diff_gpu_vs_cpu": float(np.abs(uz_gpu.cpu().numpy() - uz_cpu).max())}
+        cpu = cpu_baseline(args, eq, gp, eng, n, par, x_t, x_dev, x_dom, x_bdy, steps_exec, B)
 
+    name = {("scasml", "quad"): "solvers.ScaSML (GP + Picard correction) n=rho=%d" % n,
+            ("scasml", "fh"): "solvers.ScaSML_full_history n=%d M=%d" % (n, args.M),
+            ("mlp", "quad"): "solvers.MLP n=rho=%d" % n,
+            ("mlp", "fh"): "solvers.MLP_full_history n=%d M=%d" % (n, args.M)}[(args.solver, args.variant)]
     value = world * B * steps_exec * args.steps / elapsed
     line = {
         "metric": "Euler-Maruyama path-steps/sec + L2 rel-error, Grad_Dependent_Nonlinear d=%d n=%d" % (d, n),
         "value": round(value, 1), "unit": "path-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "Grad_Dependent_Nonlinear d=%d, solvers.ScaSML (GP + Picard correction) n=rho=%d, B=%d roots/GPU "
-                               "(BASELINE.json configs[2])" % (d, n, B),
-                   "roots_per_gpu": B, "gp_collocation": "%d+%d" % (args.train_domain, args.train_boundary),
+        "config": {"workload": "Grad_Dependent_Nonlinear d=%d, %s, B=%d roots/GPU%s" % (
+                       d, name, B, " (BASELINE.json configs[2])" if (args.solver, args.variant, d, n) == ("scasml", "quad", 100, 3) else ""),
+                   "roots_per_gpu": B, "gp_collocation": ("%d+%d" % (args.train_domain, args.train_boundary)) if gp is not None else None,
                    "path_steps_per_root": steps_exec, "path_steps_per_root_reference_count": steps_ref,
                    "gp_point_evals_per_root": ppr, "sharding": "roots across ranks, no collective",
                    "note": "value counts only EXECUTED path-steps (the reference's discarded n=0 terminal draws are not "
                            "performed); with the reference's own count the same run is value_reference_count"},
         "value_reference_count": round(world * B * steps_ref * args.steps / elapsed, 1),
-        "l2_rel_error": {"scasml_gpu": round(rel_gpu, 5), "gp_only": round(rel_gp, 5), "points": "1000+200 harness set",
+        "l2_rel_error": {"solver_gpu": round(rel_gpu, 5), "gp_only": round(rel_gp, 5) if rel_gp is not None else None,
+                         "points": "1000+200 harness set",
                          "logged_reference_d20": "0.069 (results/.../20d/RepeatedExperiment.log:21)"},
         "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
         "gp_train_s": round(t_train, 2),
