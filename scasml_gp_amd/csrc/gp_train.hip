@@ -1,6 +1,6 @@
 // Training side of the PDE-constrained GP (models/GP.py:182-268, 430-444, 487-604): the
 // 25-block derivative-feature Gram matrix in closed form, a blocked right-looking Cholesky of
-// K + nugget*I (the reference factors by SVD, models/GP.py:260-267; for symmetric PSD K the
+// K + nugget*I (trailing updates on the FP64 matrix cores, v_mfma_f64_16x16x4_f64) (the reference factors by SVD, models/GP.py:260-267; for symmetric PSD K the
 // product L L^T is the same matrix) and blocked triangular solves.  Everything here is float64,
 // as the reference's x64 SVD is.  Matrix order M must be a multiple of 32; the host pads with an
 // identity block (chol([[A,0],[0,I]]) = [[L,0],[0,I]]).
@@ -110,34 +110,67 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int64_t M, i
     for (int j = 0; j < NB; ++j) A[r * M + k0 + j] = x[j];
 }
 
-// (3) trailing update, lower triangle only: C[ti][tj] -= P[ti] * P[tj]^T, 32x32 tile per block
+// ---- C(64x64) -= A(64x32) * B(32x64) on the FP64 matrix cores -------------------------------------
+// v_mfma_f64_16x16x4_f64: lane l supplies A[row = l&15][k = l>>4] and B[k = l>>4][col = l&15]; the four
+// results of a lane are C[row = (l>>4) + 4*i][col = l&15], i = 0..3 (cdna_hip_programming.md section 3: the
+// f64 C/D map differs from the f32 one).  Four waves per workgroup, each owning a 32x32 quadrant = 2x2
+// MFMA tiles; operands come from LDS panels with a padded leading dimension.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+constexpr int TB = 64;           // output tile edge
+constexpr int LDP = NB + 1;      // LDS leading dimension of a [64][NB] panel (A rows / B^T rows)
+
+__device__ __forceinline__ void mfma_tile_update(const double (*As)[LDP], const double (*Bt)[LDP], double *C, int64_t ldc,
+                                                 int rows, int cols) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wr = (wv >> 1) * 32, wc = (wv & 1) * 32;   // quadrant origin
+    const int l15 = lane & 15, l4 = lane >> 4;
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k0 = 0; k0 < NB; k0 += 4) {
+        double a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = As[wr + 16 * i + l15][k0 + l4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = Bt[wc + 16 * j + l15][k0 + l4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = wr + 16 * i + l4 + 4 * e, c = wc + 16 * j + l15;
+                if (r < rows && c < cols) C[(int64_t)r * ldc + c] -= acc[i][j][e];
+            }
+}
+
+// (3) trailing update, lower triangle only: C[ti][tj] -= P[ti] * P[tj]^T, 64x64 tile per workgroup
 __global__ __launch_bounds__(256) void chol_update_kernel(double *A, int64_t M, int64_t k0) {
-    const int64_t nt = (M - k0 - NB) / NB;
-    // linear lower-triangular tile index -> (ti, tj), tj <= ti
-    const int64_t t = blockIdx.x;
+    const int64_t rest = M - k0 - NB;
+    const int64_t nt = (rest + TB - 1) / TB;
+    const int64_t t = blockIdx.x;   // linear lower-triangular tile index -> (ti, tj), tj <= ti
     int64_t ti = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     while (ti * (ti + 1) / 2 > t) --ti;
     const int64_t tj = t - ti * (ti + 1) / 2;
     if (ti >= nt) return;
-    __shared__ double Pi[NB][NB + 1], Pj[NB][NB + 1];
-    const int64_t r0 = k0 + NB + ti * NB, c0 = k0 + NB + tj * NB;
-    for (int idx = threadIdx.x; idx < NB * NB; idx += blockDim.x) {
+    __shared__ double Pi[TB][LDP], Pj[TB][LDP];
+    const int64_t r0 = k0 + NB + ti * TB, c0 = k0 + NB + tj * TB;
+    for (int idx = threadIdx.x; idx < TB * NB; idx += blockDim.x) {
         const int rr = idx / NB, cc = idx % NB;
-        Pi[rr][cc] = A[(r0 + rr) * M + k0 + cc];
-        Pj[rr][cc] = A[(c0 + rr) * M + k0 + cc];
+        Pi[rr][cc] = r0 + rr < M ? A[(r0 + rr) * M + k0 + cc] : 0.0;
+        Pj[rr][cc] = c0 + rr < M ? A[(c0 + rr) * M + k0 + cc] : 0.0;
     }
     __syncthreads();
-    const int c = threadIdx.x % NB, rb = threadIdx.x / NB;  // 8 row groups of 4 rows
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        const double b = Pj[c][k];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = fma(Pi[rb * 4 + e][k], b, acc[e]);
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) A[(r0 + rb * 4 + e) * M + c0 + c] -= acc[e];
+    mfma_tile_update(Pi, Pj, A + r0 * M + c0, M, (int)((M - r0) < TB ? (M - r0) : TB), (int)((M - c0) < TB ? (M - c0) : TB));
 }
 
 // ---------------------------------------------------------------------------------- TRSM
@@ -173,31 +206,22 @@ __global__ __launch_bounds__(256) void trsm_diag_kernel(const double *L, int64_t
     for (int j = 0; j < NB; ++j) B[(k0 + j) * nrhs + col] = x[j];
 }
 
-// off-diagonal update with the freshly solved block row X_k (NB x nrhs):
-//   TRANS == 0:  B[r, :] -= L[r, k0:k0+NB] * X_k          for row blocks r > k
-//   TRANS == 1:  B[r, :] -= L[k0:k0+NB, r]^T * X_k        for row blocks r < k
+// off-diagonal update with the freshly solved block row X_k (NB x nrhs), 64x64 tile per workgroup:
+//   TRANS == 0:  B[r, :] -= L[r, k0:k0+NB] * X_k          for rows r >= k0 + NB
+//   TRANS == 1:  B[r, :] -= L[k0:k0+NB, r]^T * X_k        for rows r < k0
 template <int TRANS>
 __global__ __launch_bounds__(256) void trsm_update_kernel(const double *L, int64_t M, double *B, int64_t nrhs, int64_t k0) {
-    __shared__ double Lt[NB][NB + 1], Xk[NB][NB + 1];
-    const int64_t rblk = TRANS == 0 ? k0 / NB + 1 + blockIdx.y : blockIdx.y;
-    const int64_t r0 = rblk * NB, c0 = (int64_t)blockIdx.x * NB;
-    for (int idx = threadIdx.x; idx < NB * NB; idx += blockDim.x) {
+    __shared__ double Ls[TB][LDP], Xt[TB][LDP];
+    const int64_t rbase = TRANS == 0 ? k0 + NB : 0, rend = TRANS == 0 ? M : k0;
+    const int64_t r0 = rbase + (int64_t)blockIdx.y * TB, c0 = (int64_t)blockIdx.x * TB;
+    for (int idx = threadIdx.x; idx < TB * NB; idx += blockDim.x) {
         const int rr = idx / NB, cc = idx % NB;
-        Lt[rr][cc] = TRANS == 0 ? L[(r0 + rr) * M + k0 + cc] : L[(k0 + cc) * M + r0 + rr];
-        Xk[rr][cc] = c0 + cc < nrhs ? B[(k0 + rr) * nrhs + c0 + cc] : 0.0;
+        Ls[rr][cc] = r0 + rr < rend ? (TRANS == 0 ? L[(r0 + rr) * M + k0 + cc] : L[(k0 + cc) * M + r0 + rr]) : 0.0;
+        Xt[rr][cc] = c0 + rr < nrhs ? B[(k0 + cc) * nrhs + c0 + rr] : 0.0;   // Xt[col][k]
     }
     __syncthreads();
-    const int c = threadIdx.x % NB, rb = threadIdx.x / NB;
-    if (c0 + c >= nrhs) return;
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        const double b = Xk[k][c];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = fma(Lt[rb * 4 + e][k], b, acc[e]);
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) B[(r0 + rb * 4 + e) * nrhs + c0 + c] -= acc[e];
+    const int64_t rows = rend - r0, cols = nrhs - c0;
+    mfma_tile_update(Ls, Xt, B + r0 * nrhs + c0, nrhs, (int)(rows < TB ? rows : TB), (int)(cols < TB ? cols : TB));
 }
 
 __global__ void add_diag_kernel(double *A, int64_t M, double v) {
@@ -237,7 +261,7 @@ extern "C" int scasml_cholesky(double *A, int64_t M, double nugget, int32_t *inf
         const int64_t rest = M - k0 - NB;
         if (rest <= 0) break;
         hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)((rest + 255) / 256)), dim3(256), 0, s, A, M, k0);
-        const int64_t nt = rest / NB;
+        const int64_t nt = (rest + TB - 1) / TB;
         hipLaunchKernelGGL(chol_update_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, s, A, M, k0);
     }
     hipLaunchKernelGGL(zero_upper_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)M), dim3(256), 0, s, A, M);
@@ -250,18 +274,18 @@ extern "C" int scasml_trsm_lower(const double *L, int64_t M, double *Bmat, int64
     if (M % NB) return fail(SCASML_ERR_UNSUPPORTED, "trsm: M=%lld is not a multiple of %d", (long long)M, NB);
     if (M > 65535 * (int64_t)NB) return fail(SCASML_ERR_UNSUPPORTED, "trsm: M too large for this build");
     hipStream_t s = (hipStream_t)stream;
-    const unsigned cb = (unsigned)((nrhs + 255) / 256), ct = (unsigned)((nrhs + NB - 1) / NB);
+    const unsigned cb = (unsigned)((nrhs + 255) / 256), ct = (unsigned)((nrhs + TB - 1) / TB);
     const int64_t nblk = M / NB;
     if (trans == 0) {
         for (int64_t k = 0; k < nblk; ++k) {
             hipLaunchKernelGGL(trsm_diag_kernel<0>, dim3(cb), dim3(256), 0, s, L, M, Bmat, nrhs, k * NB);
             if (k + 1 < nblk)
-                hipLaunchKernelGGL(trsm_update_kernel<0>, dim3(ct, (unsigned)(nblk - k - 1)), dim3(256), 0, s, L, M, Bmat, nrhs, k * NB);
+                hipLaunchKernelGGL(trsm_update_kernel<0>, dim3(ct, (unsigned)(((nblk - k - 1) * NB + TB - 1) / TB)), dim3(256), 0, s, L, M, Bmat, nrhs, k * NB);
         }
     } else {
         for (int64_t k = nblk - 1; k >= 0; --k) {
             hipLaunchKernelGGL(trsm_diag_kernel<1>, dim3(cb), dim3(256), 0, s, L, M, Bmat, nrhs, k * NB);
-            if (k > 0) hipLaunchKernelGGL(trsm_update_kernel<1>, dim3(ct, (unsigned)k), dim3(256), 0, s, L, M, Bmat, nrhs, k * NB);
+            if (k > 0) hipLaunchKernelGGL(trsm_update_kernel<1>, dim3(ct, (unsigned)((k * NB + TB - 1) / TB)), dim3(256), 0, s, L, M, Bmat, nrhs, k * NB);
         }
     }
     return check_launch("trsm launch");

@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""Staged large-collocation configuration (BASELINE.json configs[4]): GP fit and ScaSML
+solve with N collocation points at dimension d.  Prints timings; checks the fit against the oracle when
+--check (small N only)."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--d", type=int, default=250)
+    ap.add_argument("--n-dom", type=int, default=8333)
+    ap.add_argument("--n-bdy", type=int, default=1667)
+    ap.add_argument("--roots", type=int, default=1024)
+    ap.add_argument("--level", type=int, default=3)
+    ap.add_argument("--gn-steps", type=int, default=20)
+    args = ap.parse_args()
+    import torch
+    from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
+    from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
+    from scasml_gp_amd.solvers.ScaSML import ScaSML
+    np.random.seed(1234)
+    eq = Grad_Dependent_Nonlinear(args.d + 1)
+    gp = GP_Grad_Dependent_Nonlinear(eq)
+    dom, bdy = eq.generate_data(args.n_dom, args.n_bdy)
+    M = 4 * args.n_dom + args.n_bdy
+    print("d=%d N=%d+%d M=%d (K is %.1f GB float64)" % (args.d, args.n_dom, args.n_bdy, M, M * M * 8 / 1e9), flush=True)
+    t0 = time.time()
+    gp.GPsolver(dom, bdy, GN_steps=args.gn_steps)
+    torch.cuda.synchronize()
+    print("GP fit: %.2f s, %d Newton steps, loss %.4g -> %.4g" % (time.time() - t0, len(gp.loss_history) - 1,
+                                                                   gp.loss_history[0], gp.loss_history[-1]), flush=True)
+    xt = np.concatenate(eq.generate_test_data(args.roots - args.roots // 6, args.roots // 6)).astype(np.float32)
+    exact = eq.exact_solution(xt)
+    rel = lambda s: float(np.linalg.norm(np.asarray(s, np.float64) - exact) / np.linalg.norm(exact))
+    xd = torch.from_numpy(xt).cuda()
+    for name, fn in (("GP.predict", lambda: gp.predict(xd)), ("ScaSML.u_solve n=rho=%d" % args.level,
+                                                              lambda: ScaSML(eq, gp).u_solve(args.level, args.level, xd))):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        out = fn()
+        torch.cuda.synchronize()
+        print("%s on %d points: %.2f ms, rel-L2 %.4f" % (name, len(xt), 1e3 * (time.time() - t0), rel(out.cpu().numpy())), flush=True)
+
+
+if __name__ == "__main__":
+    main()
