@@ -43,6 +43,12 @@ __device__ __forceinline__ float4 fma4(float s, float4 a, float4 b) {  // s*a + 
 __device__ __forceinline__ float4 add4(float4 a, float s) { return make_float4(a.x + s, a.y + s, a.z + s, a.w + s); }
 __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 __device__ __forceinline__ float clip1(float v, float c) { return v < -c ? -c : (v > c ? c : v); }  // keeps NaN (jnp.clip)
+// Hardware reciprocal / square root / exp2 (<= 1 ulp) for the arithmetic that is NOT part of the bit-exact
+// RNG specification: the IEEE-correct expansions cost ~10 VALU instructions each and these kernels are
+// VALU-bound; the parity tolerance (1e-4 relative) is five orders of magnitude above the difference.
+__device__ __forceinline__ float rcp_fast(float v) { return __builtin_amdgcn_rcpf(v); }
+__device__ __forceinline__ float sqrt_fast(float v) { return __builtin_amdgcn_sqrtf(v); }
+__device__ __forceinline__ float exp_fast(float v) { return __builtin_amdgcn_exp2f(v * 1.44269504088896341f); }
 
 template <int VAR, int MODE>
 struct Walker {
@@ -84,7 +90,7 @@ struct Walker {
     // equations/equations.py:248-261 at time T; ScaSML.py:61-63 subtracts the surrogate
     __device__ __forceinline__ float g_terminal(float4 XT, uint32_t site) const {
         const float s = a.T + dim_sum(XT);
-        float g = 1.0f - 1.0f / (1.0f + expf(s));
+        float g = 1.0f - rcp_fast(1.0f + exp_fast(s));
         if constexpr (MODE == SCASML_MODE_ACCUMULATE) g -= gp_at(site).x;
         return g;
     }
@@ -105,7 +111,7 @@ struct Walker {
         const scasml_term &tm = a.plan.term[N][L];
         const int q = tm.q, mc = tm.mc;
         const uint32_t s_l = (uint32_t)tm.sites_l, s_lm = (uint32_t)tm.sites_lm1;
-        const float inv_mc = 1.0f / (float)mc;
+        const float inv_mc = rcp_fast((float)mc);
         for (int m = 0; m < mc; ++m) {
             if (!owned(TOP)) {
                 o += (uint32_t)q * (1u + s_l + s_lm);
@@ -121,22 +127,22 @@ struct Walker {
                 float dplus, dminus;
                 if constexpr (VAR == 0) {                        // MLP.py:219-225
                     const float dk = tau * tm.dfrac[k];
-                    const float sdk = sqrtf(dk);
+                    const float sdk = sqrt_fast(dk);
                     W = fma4(sdk, xi, W);
                     X = fma4(a.sigma * sdk, xi, add4(X, a.mu * dk));
                     tk = fmaf(tau, tm.cfrac[k], t);
                     wk = tau * tm.wfrac[k];
                     wvec = W;
-                    dplus = 1.0f / fmaf(tau, tm.dplus[k], 1e-6f);   // MLP.py:249 (stale) / ScaSML.py:253
-                    dminus = 1.0f / fmaf(tau, tm.cfrac[k], 1e-6f);  // MLP.py:270
+                    dplus = rcp_fast(fmaf(tau, tm.dplus[k], 1e-6f));   // MLP.py:249 (stale) / ScaSML.py:253
+                    dminus = rcp_fast(fmaf(tau, tm.cfrac[k], 1e-6f));  // MLP.py:270
                 } else {                                         // MLP_full_history.py:133-145
                     const float D = uniform_tau(site, root, a.stream, a.k0, a.k1) * tau;
-                    const float sD = sqrtf(D);
+                    const float sD = sqrt_fast(D);
                     X = fma4(a.sigma * sD, xi, add4(x, a.mu * D));
                     tk = t + D;
                     wk = tau;
                     wvec = xi;
-                    dplus = dminus = 1.0f / sqrtf(D + 1e-6f);     // :158-159
+                    dplus = dminus = __builtin_amdgcn_rsqf(D + 1e-6f);     // :158-159
                 }
                 if constexpr (MODE == SCASML_MODE_GENERATE) emit_point(X, tk, site);
                 float4 gp = f4(0.0f);
@@ -178,7 +184,7 @@ struct Walker {
         } else {
             const float tau = a.T - t;
             const int mg = a.plan.mg[N];
-            const float drift = a.mu * tau, vol = a.sigma * sqrtf(tau);
+            const float drift = a.mu * tau, vol = a.sigma * sqrt_fast(tau);
             float su = 0.0f;
             float4 sz = f4(0.0f);
             for (int m = 0; m < mg; ++m) {                       // MLP.py:175-202
@@ -194,9 +200,9 @@ struct Walker {
                     sz = fma4(g, nrm, sz);
                 }
             }
-            const float inv_mg = 1.0f / (float)mg;
+            const float inv_mg = rcp_fast((float)mg);
             float u = su * inv_mg;
-            const float zs = inv_mg / (VAR == 0 ? tau + 1e-6f : tau);   // MLP.py:201 / MLP_full_history.py:122
+            const float zs = inv_mg * rcp_fast(VAR == 0 ? tau + 1e-6f : tau);   // MLP.py:201 / MLP_full_history.py:122
             float4 z = make_float4(sz.x * zs, sz.y * zs, sz.z * zs, sz.w * zs);
             uint32_t o = (uint32_t)mg;
             level<N, 0, TOP>(x, t, tau, base, o, u, z);
