@@ -27,7 +27,7 @@ extern "C" {
 #define SCASML_ABI_VERSION 1
 #define SCASML_MAX_LEVEL 4   /* Picard level n <= 4 (kernels are instantiated per level)      */
 #define SCASML_MAX_Q 6       /* quadrature nodes per rule <= 6 (rho <= 5, solvers/MLP.py:132)  */
-#define SCASML_MAX_DIM 254   /* spatial dimension d <= 254 (one 4-dim quad per lane, +t, +1 spare column) */
+#define SCASML_MAX_DIM 253   /* spatial dimension d <= 253 (one 4-dim quad per lane, +t, +2 spare columns) */
 #define SCASML_GP_TILE 32     /* collocation points per MFMA tile; n_pad is a multiple of it    */
 
 enum { SCASML_ERR_ARG = -1, SCASML_ERR_UNSUPPORTED = -2, SCASML_ERR_HIP = -3 };
@@ -90,8 +90,8 @@ size_t scasml_sizeof(int which);
 
 /* Rows of the point buffer / GP-value buffer per root: sites[n] + 1 (the root itself last). */
 int64_t scasml_points_per_root(const scasml_plan *plan_h);
-/* Padded row length (floats) of a point row: round_up(d + 2, 16): X, t, one spare column the GP
- * evaluation uses for a folded constant, zero pad to a whole bf16 MFMA K-step. */
+/* Padded row length (floats) of a point row: round_up(d + 3, 16): X, t, two spare columns the GP
+ * evaluation uses for folded constants, zero pad to a whole 16-bit MFMA K-step. */
 int32_t scasml_point_stride(int32_t d);
 
 /*
@@ -125,7 +125,7 @@ typedef struct {
     int32_t d;
     int32_t n_dom, n_bdy;        /* N_Omega, N_dOmega                                        */
     int32_t n_pad;               /* (n_dom + n_bdy) rounded up to 32                         */
-    int32_t kp;                  /* point stride = round_up(d+2, 16)                         */
+    int32_t kp;                  /* point stride = round_up(d+3, 16)                         */
     int32_t split;               /* x.y arithmetic: 0 = fp32 MFMA; 3 / 2 = bf16 MFMA on 3 (fp32-exact) / 2 bf16 planes;
                                     22 = fp16 MFMA on two fp16 planes (22-bit products, 3 MFMAs per K-step) */
     float a;                     /* 1/sigma_k^2, sigma_k = 0.25*sqrt(d) (models/GP.py:25)    */
@@ -133,6 +133,8 @@ typedef struct {
     const float *colloc;         /* n_pad x kp   collocation points, domain first, zero pad  */
     const float *colloc_frag;    /* the same, in fp32 MFMA A-fragment order [tile][kp/8][64][4] */
     const uint16_t *colloc_bf16; /* 5*n_pad*kp halfwords: 3 truncated-bf16 planes [tile][plane][kp/16][64][8], then 2 fp16 planes */
+    int32_t colloc_is_f16;       /* 1 if every collocation coordinate is exactly representable in fp16 (the reference's
+                                    deepxde float16 points are): split = 22 then needs 2 instead of 3 MFMAs per K-step */
     const float *coef;           /* n_pad x 16   per-row constants (|y|^2, a*sum y, a*t_y, c0, cL, ct, cS, 0, a*ct, ...) */
 } scasml_gp_model;
 

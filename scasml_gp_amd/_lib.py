@@ -5,7 +5,7 @@ import os
 
 MAX_LEVEL = 4
 MAX_Q = 6
-MAX_DIM = 254
+MAX_DIM = 253
 GP_TILE = 32
 ABI_VERSION = 1
 
@@ -37,7 +37,8 @@ class Plan(C.Structure):
 class GpModel(C.Structure):
     _fields_ = [("d", C.c_int32), ("n_dom", C.c_int32), ("n_bdy", C.c_int32), ("n_pad", C.c_int32),
                 ("kp", C.c_int32), ("split", C.c_int32), ("a", C.c_float), ("sigma_eq", C.c_float),
-                ("colloc", C.c_void_p), ("colloc_frag", C.c_void_p), ("colloc_bf16", C.c_void_p), ("coef", C.c_void_p)]
+                ("colloc", C.c_void_p), ("colloc_frag", C.c_void_p), ("colloc_bf16", C.c_void_p), ("colloc_is_f16", C.c_int32),
+                ("coef", C.c_void_p)]
 
 
 _STRUCTS = (Problem, Rng, Term, Plan, GpModel)

@@ -18,6 +18,7 @@ struct GpArgs {
     int64_t n_inf;
     int32_t n_pad, kp, d;
     float a, sigma;
+    int32_t colloc_is_f16;
     int32_t dbg;   // ablation switches (SCASML_GP_DBG, development only): 1 skip MFMA, 2 skip epilogue, 4 no stagger, 8 stage once
 };
 

@@ -277,10 +277,16 @@ __global__ void gp_pack_kernel(int d, float a, const float *x_dom, int n_dom, co
         bf[((int64_t)tile * 3 + 0) * ks * 512 + e] = (uint16_t)(hb >> 16);
         bf[((int64_t)tile * 3 + 1) * ks * 512 + e] = (uint16_t)(mb >> 16);
         bf[((int64_t)tile * 3 + 2) * ks * 512 + e] = (uint16_t)(lb >> 16);
-        // fp16 planes (h, 2^11 * l) of the same folded operand, stored behind the bf16 planes
+        // fp16 planes (h, 2^11 * l), stored behind the bf16 planes.  Here the -2 a^2 fold sits on the POINT side
+        // (gp_eval_bf16.hip): the planes hold y itself, and a^2 |y|^2 as h in column d+1 and 2^11*l in column
+        // d+2 of plane 0, met by the constants 1 and 2^-11 in the point row.  If y is exactly fp16 (float16
+        // collocation points, as in the reference protocol) plane 1 is identically zero and is never read.
         uint16_t *hf = bf + (int64_t)3 * n_pad * kp;
-        const _Float16 fh = (_Float16)vf;
-        const _Float16 fl = (_Float16)((vf - (float)fh) * 2048.0f);
+        const float ay = a * a * ny_full;
+        const _Float16 ayh = (_Float16)ay;
+        const float vg = k <= d ? v : (k == d + 1 ? (float)ayh : (k == d + 2 ? (ay - (float)ayh) * 2048.0f : 0.0f));
+        const _Float16 fh = (_Float16)vg;
+        const _Float16 fl = k <= d ? (_Float16)((vg - (float)fh) * 2048.0f) : (_Float16)0.0f;
         hf[((int64_t)tile * 2 + 0) * ks * 512 + e] = __builtin_bit_cast(unsigned short, fh);
         hf[((int64_t)tile * 2 + 1) * ks * 512 + e] = __builtin_bit_cast(unsigned short, fl);
         ny = fmaf(v, v, ny);
@@ -367,6 +373,7 @@ extern "C" int scasml_gp_eval(const scasml_gp_model *m, const float *points, int
     g.colloc_frag = m->colloc_frag;
     g.colloc_bf16 = m->colloc_bf16;
     g.colloc_f16 = m->colloc_bf16 ? m->colloc_bf16 + (int64_t)3 * m->n_pad * m->kp : nullptr;
+    g.colloc_is_f16 = m->colloc_is_f16;
     g.coef = m->coef;
     g.out4 = reinterpret_cast<float4 *>(out4);
     g.lap = lap;

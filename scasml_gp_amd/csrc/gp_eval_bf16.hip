@@ -11,8 +11,11 @@
 // MODE 22 ("fp16x2"): two fp16 planes  v = h + 2^-11 * l'  (h = fp16(v), l' = fp16(2^11 (v - h)); 11 + 11
 // mantissa bits, products exact in the fp32 MFMA accumulator).  h*h goes to one accumulator, the cross
 // terms h*l' + l'*h to a second one that enters as 2^-11 * acc2 (l'*l' ~ 2^-22 is dropped): 3 MFMAs per
-// K-step instead of 6, product accuracy ~2^-22 instead of 2^-24.  Planes are stored in the same buffer and
-// fragment order as the bf16 planes (plane 0 = h, plane 1 = l').
+// K-step instead of 6, product accuracy ~2^-22 instead of 2^-24.  In this mode the -2 a^2 fold sits on the
+// point side (B = planes of -2 a^2 x, constants 1 and 2^-11 in two spare columns) and the collocation planes
+// hold y itself plus a^2 |y|^2 as (h, l') in those two columns; when every collocation coordinate is
+// exactly fp16 -- the reference's deepxde float16 arrays are -- plane l'_y is zero, so the l'_y * h_x MFMA
+// and the staging of that plane are dropped (YEXACT): 2 MFMAs per K-step.
 //
 // Structure (same as gp_eval.hip): workgroup of 8 waves, 32 points per wave held in VGPRs as bf16 planes
 // for the whole sweep; per collocation tile one LDS slot [SPLIT*KS KiB of A fragments | 1 KiB coefficients]
@@ -46,17 +49,18 @@ __device__ __forceinline__ uint32_t pack_h2(float a, float b) {   // two fp16 (R
 }
 
 // KS = kp / 16 K-steps of the 32x32x16 MFMA; half-wave h covers k in [h*8*KS, (h+1)*8*KS)
-template <int KS, int SPLIT, bool PF, bool F16>
+template <int KS, int SPLIT, bool PF, bool F16, bool YEXACT>
 __device__ __forceinline__ void gp_mfma_tile_bf16(const float4 *lds_a, const s16x8 (&xb)[SPLIT][KS], f32x16 &acc, int lane) {
     f32x16 acc2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = acc2[r] = 0.0f;
     // A fragments ping-pong between two register sets selected by the (compile-time) parity of the
     // step: the ds_reads of step s+1 are issued before the MFMAs of step s, with no register copies.
+    constexpr int NPL = YEXACT ? 1 : SPLIT;      // A planes actually staged and read
     Frag a[PF ? 2 : 1][SPLIT];
     if constexpr (PF) {
 #pragma unroll
-        for (int pl = 0; pl < SPLIT; ++pl) a[0][pl].f = lds_a[(pl * KS) * 64 + lane];
+        for (int pl = 0; pl < NPL; ++pl) a[0][pl].f = lds_a[(pl * KS) * 64 + lane];
     }
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -64,17 +68,17 @@ __device__ __forceinline__ void gp_mfma_tile_bf16(const float4 *lds_a, const s16
         if constexpr (PF) {
             if (s + 1 < KS) {
 #pragma unroll
-                for (int pl = 0; pl < SPLIT; ++pl) a[nxt][pl].f = lds_a[(pl * KS + s + 1) * 64 + lane];
+                for (int pl = 0; pl < NPL; ++pl) a[nxt][pl].f = lds_a[(pl * KS + s + 1) * 64 + lane];
             }
         } else {
 #pragma unroll
-            for (int pl = 0; pl < SPLIT; ++pl) a[0][pl].f = lds_a[(pl * KS + s) * 64 + lane];
+            for (int pl = 0; pl < NPL; ++pl) a[0][pl].f = lds_a[(pl * KS + s) * 64 + lane];
         }
         if constexpr (F16) {   // plane 0 = h, plane 1 = 2^11 * l
             Frag b0, b1;
             b0.v = xb[0][s];
             b1.v = xb[1][s];
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cur][1].h, b0.h, acc2, 0, 0, 0);
+            if constexpr (!YEXACT) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cur][1].h, b0.h, acc2, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cur][0].h, b1.h, acc2, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cur][0].h, b0.h, acc, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -103,11 +107,12 @@ __device__ __forceinline__ void gp_mfma_tile_bf16(const float4 *lds_a, const s16
 // number of resident waves until the matrix pipe becomes the limit).
 // BPC = workgroups meant to be co-resident per CU (occupancy = WPB/4 * BPC waves per SIMD): with two
 // 8-wave workgroups per CU one workgroup's point-row prologue and final stores overlap the other's sweep.
-template <int KS, int SPLIT, int WPB, bool F16, int BPC>
+template <int KS, int SPLIT, int WPB, bool F16, int BPC, bool YEXACT>
 __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(const GpArgs g) {
+    constexpr int NPL = YEXACT ? 1 : SPLIT;          // A planes staged per tile
     constexpr bool PF = WPB * BPC <= 8;
     static_assert(WPB == 8 || WPB == 12 || WPB == 16, "waves per workgroup");
-    constexpr int STAGE = SPLIT * KS * 256 + 512;       // floats per LDS slot (A fragments + 32 rows x 16 coefficients)
+    constexpr int STAGE = NPL * KS * 256 + 512;         // floats per LDS slot (A fragments + 32 rows x 16 coefficients)
     extern __shared__ __attribute__((aligned(16))) float lds[];   // 3 slots
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int col = lane & 31, half = lane >> 5;
@@ -119,12 +124,12 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
     auto stage = [&](int tile, int slot) {
         float *dst = lds + slot * STAGE;
         const float *src = reinterpret_cast<const float *>(F16 ? g.colloc_f16 : g.colloc_bf16) + (int64_t)tile * (F16 ? 2 : 3) * KS * 256;
-        for (int c = wv; c < SPLIT * KS; c += WPB)
+        for (int c = wv; c < NPL * KS; c += WPB)
             __builtin_amdgcn_global_load_lds(src + c * 256 + lane * 4, dst + c * 256, 16, 0, 0);
-        if (wv == ((SPLIT * KS) % WPB))
-            __builtin_amdgcn_global_load_lds(g.coef + (int64_t)tile * 512 + lane * 4, dst + SPLIT * KS * 256, 16, 0, 0);
-        if (wv == ((SPLIT * KS + 1) % WPB))
-            __builtin_amdgcn_global_load_lds(g.coef + (int64_t)tile * 512 + 256 + lane * 4, dst + SPLIT * KS * 256 + 256, 16, 0, 0);
+        if (wv == ((NPL * KS) % WPB))
+            __builtin_amdgcn_global_load_lds(g.coef + (int64_t)tile * 512 + lane * 4, dst + NPL * KS * 256, 16, 0, 0);
+        if (wv == ((NPL * KS + 1) % WPB))
+            __builtin_amdgcn_global_load_lds(g.coef + (int64_t)tile * 512 + 256 + lane * 4, dst + NPL * KS * 256 + 256, 16, 0, 0);
     };
     stage(0, 0);
 
@@ -140,24 +145,31 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const float4 q0 = src[2 * s], q1 = src[2 * s + 1];
-            float e[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-            uint32_t hb[8], mb[8], lb[8];
+            const float e[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            float t[8];          // the MFMA operand: x itself (bf16 modes) or the folded -2 a^2 x (fp16 mode), plus constants
+            const float fold = F16 ? -2.0f * g.a * g.a : 1.0f;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const int k = kbase + 8 * s + c;
                 pn = fmaf(e[c], e[c], pn);
                 ps += k < g.d ? e[c] : 0.0f;
                 pt += k == g.d ? e[c] : 0.0f;
-                if (k == g.d + 1) e[c] = 1.0f;   // the constant column that picks up a^2 |y|^2 (gp_pack_kernel)
-                split3(e[c], hb[c], mb[c], lb[c]);
+                // spare columns: d+1 meets a^2|y|^2 (bf16 modes: the whole value; fp16 mode: its h part), d+2 its 2^11*l part
+                const float spare = k == g.d + 1 ? 1.0f : ((F16 && k == g.d + 2) ? 0x1p-11f : 0.0f);
+                t[c] = k <= g.d ? fold * e[c] : spare;
+            }
+            uint32_t hb[8], mb[8], lb[8];
+            if constexpr (!F16) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) split3(t[c], hb[c], mb[c], lb[c]);
             }
             Frag fh, fm, fl;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {   // element 2c in the low half-word, 2c+1 in the high one
                 if constexpr (F16) {
-                    const float h0 = (float)(_Float16)e[2 * c], h1 = (float)(_Float16)e[2 * c + 1];
-                    fh.u[c] = pack_h2(e[2 * c], e[2 * c + 1]);
-                    fm.u[c] = pack_h2((e[2 * c] - h0) * 2048.0f, (e[2 * c + 1] - h1) * 2048.0f);
+                    const float h0 = (float)(_Float16)t[2 * c], h1 = (float)(_Float16)t[2 * c + 1];
+                    fh.u[c] = pack_h2(t[2 * c], t[2 * c + 1]);
+                    fm.u[c] = pack_h2((t[2 * c] - h0) * 2048.0f, (t[2 * c + 1] - h1) * 2048.0f);
                     fl.u[c] = 0;
                 } else {
                     fh.u[c] = (hb[2 * c] >> 16) | hb[2 * c + 1];
@@ -189,14 +201,14 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
     auto a_of = [&](int slot) { return reinterpret_cast<const float4 *>(lds + slot * STAGE); };
     auto view = [&](int slot) {
         const float *b = lds + slot * STAGE;
-        return GpStageView{reinterpret_cast<const float4 *>(b), b + SPLIT * KS * 256};
+        return GpStageView{reinterpret_cast<const float4 *>(b), b + NPL * KS * 256};
     };
     f32x16 acc[1];
     __syncthreads();  // tile 0 has landed (the barrier drains the LDS-DMA)
     if (!late) {
         for (int jt = 0; jt < n_tiles; ++jt) {
             if (jt + 1 < n_tiles && !(g.dbg & 8)) stage(jt + 1, (jt + 1) % 3);
-            if (!(g.dbg & 1)) gp_mfma_tile_bf16<KS, SPLIT, PF, F16>(a_of(jt % 3), xb, acc[0], lane);
+            if (!(g.dbg & 1)) gp_mfma_tile_bf16<KS, SPLIT, PF, F16, YEXACT>(a_of(jt % 3), xb, acc[0], lane);
             if (!(g.dbg & 2)) gp_epilogue_tile<1, true, PF>(view(jt % 3), acc, c, half, nx, sx, tx, au, at, ad, al);
             __syncthreads();
         }
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
         for (int jt = 0; jt < n_tiles; ++jt) {
             if (jt + 1 < n_tiles && !(g.dbg & 8)) stage(jt + 1, (jt + 1) % 3);
             if (jt > 0 && !(g.dbg & 2)) gp_epilogue_tile<1, true, PF>(view((jt - 1) % 3), acc, c, half, nx, sx, tx, au, at, ad, al);
-            if (!(g.dbg & 1)) gp_mfma_tile_bf16<KS, SPLIT, PF, F16>(a_of(jt % 3), xb, acc[0], lane);
+            if (!(g.dbg & 1)) gp_mfma_tile_bf16<KS, SPLIT, PF, F16, YEXACT>(a_of(jt % 3), xb, acc[0], lane);
             __syncthreads();
         }
         gp_epilogue_tile<1, true, PF>(view((n_tiles - 1) % 3), acc, c, half, nx, sx, tx, au, at, ad, al);
@@ -223,7 +235,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
     }
 }
 
-template <int KS, int SPLIT, bool F16>
+template <int KS, int SPLIT, bool F16, bool YEXACT>
 static int launch_one(const GpArgs &g, hipStream_t s) {
     // three waves per SIMD while the 16-bit planes of the point tile (SPLIT*4*KS VGPRs) leave room under 168
     constexpr int REGS = SPLIT * 4 * KS + (F16 ? 16 : 0);       // point-tile planes + second accumulator
@@ -233,9 +245,9 @@ static int launch_one(const GpArgs &g, hipStream_t s) {
     const int64_t waves = (g.n_inf + 31) / 32;
     const int64_t blocks = (waves + WPB - 1) / WPB;
     if (blocks > 0x7FFFFFFF) return fail(SCASML_ERR_UNSUPPORTED, "gp_eval: too many points");
-    constexpr size_t lds_bytes = 3 * (SPLIT * KS * 256 + 512) * sizeof(float);
+    constexpr size_t lds_bytes = 3 * ((YEXACT ? 1 : SPLIT) * KS * 256 + 512) * sizeof(float);
     static_assert(lds_bytes <= 160 * 1024, "LDS slots exceed 160 KiB");
-    auto kern = gp_eval_bf16_kernel<KS, SPLIT, WPB, F16, BPC>;
+    auto kern = gp_eval_bf16_kernel<KS, SPLIT, WPB, F16, BPC, YEXACT>;
     if (lds_bytes > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
             return fail(SCASML_ERR_HIP, "gp_eval: cannot reserve %zu bytes of LDS", lds_bytes);
@@ -244,11 +256,11 @@ static int launch_one(const GpArgs &g, hipStream_t s) {
     return check_launch("gp_eval(bf16) launch");
 }
 
-template <int SPLIT, bool F16>
+template <int SPLIT, bool F16, bool YEXACT>
 static int launch_split(const GpArgs &g, hipStream_t s) {
     switch (g.kp / 16) {
 #define SCASML_CASE(K) \
-    case K: return launch_one<K, SPLIT, F16>(g, s);
+    case K: return launch_one<K, SPLIT, F16, YEXACT>(g, s);
         SCASML_CASE(1) SCASML_CASE(2) SCASML_CASE(3) SCASML_CASE(4) SCASML_CASE(5) SCASML_CASE(6) SCASML_CASE(7) SCASML_CASE(8)
         SCASML_CASE(9) SCASML_CASE(10) SCASML_CASE(11) SCASML_CASE(12) SCASML_CASE(13) SCASML_CASE(14) SCASML_CASE(15) SCASML_CASE(16)
 #undef SCASML_CASE
@@ -257,8 +269,8 @@ static int launch_split(const GpArgs &g, hipStream_t s) {
 }
 
 int launch_gp_eval_bf16(const GpArgs &g, int split, hipStream_t s) {
-    if (split == 22) return launch_split<2, true>(g, s);
-    return split == 3 ? launch_split<3, false>(g, s) : launch_split<2, false>(g, s);
+    if (split == 22) return g.colloc_is_f16 ? launch_split<2, true, true>(g, s) : launch_split<2, true, false>(g, s);
+    return split == 3 ? launch_split<3, false, false>(g, s) : launch_split<2, false, false>(g, s);
 }
 
 }  // namespace scasml

@@ -71,6 +71,7 @@ class GP(object):
         m.sigma_eq = float(self.equation.sigma())
         m.colloc, m.colloc_frag, m.coef = self._colloc.data_ptr(), self._frag.data_ptr(), self._coef.data_ptr()
         m.colloc_bf16 = self._bf16.data_ptr()
+        m.colloc_is_f16 = int(self._colloc_is_f16)
         return m
 
     def _eval_device(self, pts):
@@ -216,6 +217,8 @@ class GP(object):
         self._bf16 = torch.empty((5 * self._n_pad * kp,), dtype=torch.int16, device="cuda")
         self._coef = torch.empty((self._n_pad, 16), dtype=torch.float32, device="cuda")
         rv = rv.contiguous()
+        # collocation points that are exactly fp16 (the reference's deepxde float16 arrays are) need one plane
+        self._colloc_is_f16 = bool((self._xd.half().float() == self._xd).all()) and bool((self._xb.half().float() == self._xb).all())
         _lib.check(lib.scasml_gp_pack(self.d, 1.0 / float(self.sigma) ** 2, _lib.ptr(self._xd), self.N_domain,
                                       _lib.ptr(self._xb), self.N_boundary, _lib.ptr(rv), _lib.ptr(self._colloc),
                                       _lib.ptr(self._frag), _lib.ptr(self._bf16), _lib.ptr(self._coef), _lib.stream_ptr()), "gp_pack")

@@ -69,14 +69,18 @@ def test_training_matches_oracle(d, nd, nb):
     assert np.allclose(sol_dom, want_dom, atol=2e-5)
 
 
+@pytest.mark.parametrize("f16_colloc", [False, True])
 @pytest.mark.parametrize("d,nd,nb,n_inf", [(4, 30, 10, 100), (20, 120, 40, 1000), (100, 50, 14, 77), (250, 40, 8, 40), (63, 31, 1, 65)])
-def test_fused_evaluation_and_gradient_match_oracle(d, nd, nb, n_inf):
+def test_fused_evaluation_and_gradient_match_oracle(d, nd, nb, n_inf, f16_colloc):
     """float32 MFMA + float32 epilogue vs float64: errors scale with sum_j |kappa_j c_j|, so the
     tolerance is relative to that magnitude (1e-5) rather than to the (cancelling) result."""
     import torch
     gp, ora, dom, bdy = _setup(d, nd, nb, seed=3)
+    if f16_colloc:      # float16 collocation points (the reference's deepxde arrays): the 2-MFMA fast path
+        dom, bdy = dom.astype(np.float16).astype(np.float32), bdy.astype(np.float16).astype(np.float32)
     ora.GPsolver(dom, bdy, GN_steps=10)
     gp.load_right_vector(dom, bdy, ora.right_vector)
+    assert gp._colloc_is_f16 == f16_colloc
     X = np.random.default_rng(4).uniform(-0.6, 0.6, (n_inf, d + 1)).astype(np.float32)
     X[:, -1] = np.abs(X[:, -1])
     mag = (np.abs(ora._features("I", X)) @ np.abs(ora.right_vector))[:, 0] + 1e-3
