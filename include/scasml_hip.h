@@ -101,9 +101,11 @@ int32_t scasml_point_stride(int32_t d);
  * Philox normals, Euler-Maruyama stepping, the recursive quadrature, f and g
  * (equations/equations.py:248-304), clipping.
  *   x_t      : B x (d+1) evaluation points.
- *   points   : MODE_GENERATE out: B x points_per_root x point_stride  (X, t, zero pad).
- *   gp_vals  : MODE_ACCUMULATE in: B x points_per_root x 4 = (u_hat, div_x u_hat, eps_PDE, 0)
- *              from scasml_gp_eval on `points`.
+ *   points   : MODE_GENERATE out: points_per_root x B x point_stride, SITE-major (row = site*B + root): the 32
+ *              rows a wavefront of scasml_gp_eval takes are one tree site of 32 roots, so per-site work
+ *              selection there is wave-uniform.  Row content (X, t, zero pad).
+ *   gp_vals  : MODE_ACCUMULATE in: points_per_root x B x 4 = (u_hat, div_x u_hat, eps_PDE, dt u_hat), same row
+ *              order, from scasml_gp_eval on `points`.
  *   out_uz   : B x (1+d): (u, z) clipped [MLP, ACCUMULATE]; un-clipped partial sums if world > 1.
  *   out_uhat : B: u_hat at the root [ACCUMULATE] (ScaSML.py:303), may be NULL.
  */
@@ -157,6 +159,17 @@ int scasml_gp_pack(int32_t d, float a, const float *x_dom, int32_t n_dom, const 
  */
 int scasml_gp_eval(const scasml_gp_model *gp_h, const float *points, int64_t n_inf,
                    float *out4, float *lap, void *stream);
+
+/* Same, for the site-major point buffer of scasml_picard_tree: rows [s*rows_per_site, (s+1)*rows_per_site) are
+ * tree site s; site_u_only[s] != 0 (device bytes, from scasml_plan_site_kinds) marks sites where only u_hat is
+ * consumed (terminal-time points, ScaSML.py:61; the root, ScaSML.py:303) -- their rows get u_hat only
+ * (div, eps, dt = 0), which halves the epilogue work there. */
+int scasml_gp_eval_sites(const scasml_gp_model *gp_h, const float *points, int64_t n_inf, int64_t rows_per_site,
+                         const uint8_t *site_u_only, float *out4, void *stream);
+
+/* Host helper: fill kinds_h[0 .. points_per_root) with 1 for sites whose GP value is used as u_hat only
+ * (terminal samples and the trailing root row), 0 for Euler-Maruyama sites (u_hat, div, eps_PDE needed). */
+int scasml_plan_site_kinds(const scasml_plan *plan_h, uint8_t *kinds_h);
 
 /* Full gradient of the posterior mean, n_inf x (d+1), time last: GP.compute_gradient (:673-687). */
 int scasml_gp_gradient(const scasml_gp_model *gp_h, const float *points, int64_t n_inf,

@@ -19,6 +19,8 @@ struct GpArgs {
     int32_t n_pad, kp, d;
     float a, sigma;
     int32_t colloc_is_f16;
+    const uint8_t *site_u_only;   // per tree site: only u_hat needed (null = every row needs everything)
+    int64_t rows_per_site;
     int32_t dbg;   // ablation switches (SCASML_GP_DBG, development only): 1 skip MFMA, 2 skip epilogue, 4 no stagger, 8 stage once
 };
 
@@ -45,13 +47,13 @@ constexpr int kCoefRow = 16;
 // extra K column a^2 |y|^2 against a constant 1 in the point row), and nx[] holds a^2 |x|^2 - a d, so
 // L0 = acc + nx = a^2 r2 - a d costs one add and kappa one fma + exp2; every row constant that would
 // cost a multiply per element is precomputed.  19 VALU per (collocation, point) pair.
-template <int PT, bool FOLD = false, bool PF = true>
+template <int PT, bool FOLD = false, bool PF = true, bool UONLY = false>
 __device__ __forceinline__ void gp_epilogue_tile(const GpStageView &st, const f32x16 (&acc)[PT], const GpConsts &c, int half,
                                                  const float (&nx)[PT], const float (&sx)[PT], const float (&tx)[PT],
                                                  float (&au)[PT], float (&at)[PT], float (&ad)[PT], float (&al)[PT]) {
     // C row = (r&3) + 8*(r>>2) + 4*half: one per-lane base (depends on the half-wave), compile-time row offsets
     const float4 *cb = reinterpret_cast<const float4 *>(__builtin_assume_aligned(st.coef + 4 * kCoefRow * half, 16));
-    constexpr int NQ = FOLD ? 3 : 4;                     // float4 reads per row
+    constexpr int NQ = UONLY ? 2 : (FOLD ? 3 : 4);       // float4 reads per row (u_hat alone needs sy, ty, c0, cL, ct, cS)
     // PF: rows ping-pong between two register sets (the reads of row r+1 are issued before row r is
     // consumed); without PF one set is used and the other resident waves cover the LDS latency.  One
     // row (PT independent chains) per scheduling region keeps the VGPR budget flat.
@@ -81,7 +83,13 @@ __device__ __forceinline__ void gp_epilogue_tile(const GpStageView &st, const f3
         for (int p = 0; p < PT; ++p) {
             const float pp = tx[p] - vty;                  // a * r_t
             const float ss = sx[p] - vsy;                  // a * S
-            if constexpr (FOLD) {
+            if constexpr (UONLY) {                           // terminal-time points and the root: u_hat only, 10 VALU
+                static_assert(FOLD, "u-only epilogue is written for the folded form");
+                const float L0 = acc[p][r] + nx[p];
+                const float kap = __builtin_amdgcn_exp2f(fmaf(L0, c.k1, c.k2));
+                const float L = fmaf(-pp, pp, L0);
+                au[p] = fmaf(kap, fmaf(vcS, ss, fmaf(vct, pp, fmaf(vcL, L, vc0))), au[p]);
+            } else if constexpr (FOLD) {
                 const float act = q[cur][1].z, c2 = q[cur][1].w;
                 const float c3 = q[cur][2].x, c4 = q[cur][2].y, c5 = q[cur][2].z, c6 = q[cur][2].w;
                 const float L0 = acc[p][r] + nx[p];        // a^2 r2 - a d

@@ -363,8 +363,8 @@ extern "C" int scasml_gp_pack(int32_t d, float a, const float *x_dom, int32_t n_
     return check_launch("gp_pack launch");
 }
 
-extern "C" int scasml_gp_eval(const scasml_gp_model *m, const float *points, int64_t n_inf, float *out4, float *lap,
-                              void *stream) {
+static int gp_eval_impl(const scasml_gp_model *m, const float *points, int64_t n_inf, float *out4, float *lap,
+                        int64_t rows_per_site, const uint8_t *site_u_only, void *stream) {
     if (n_inf == 0) return 0;
     if (int rc = check_model(m, "gp_eval")) return rc;
     if (n_inf < 0 || !points || !out4) return fail(SCASML_ERR_ARG, "gp_eval: bad argument");
@@ -374,6 +374,8 @@ extern "C" int scasml_gp_eval(const scasml_gp_model *m, const float *points, int
     g.colloc_bf16 = m->colloc_bf16;
     g.colloc_f16 = m->colloc_bf16 ? m->colloc_bf16 + (int64_t)3 * m->n_pad * m->kp : nullptr;
     g.colloc_is_f16 = m->colloc_is_f16;
+    g.site_u_only = site_u_only;
+    g.rows_per_site = rows_per_site;
     g.coef = m->coef;
     g.out4 = reinterpret_cast<float4 *>(out4);
     g.lap = lap;
@@ -403,6 +405,17 @@ extern "C" int scasml_gp_eval(const scasml_gp_model *m, const float *points, int
     }
 #undef SCASML_EVAL_CASE
     return fail(SCASML_ERR_UNSUPPORTED, "gp_eval: kp=%d", m->kp);
+}
+
+extern "C" int scasml_gp_eval(const scasml_gp_model *m, const float *points, int64_t n_inf, float *out4, float *lap,
+                              void *stream) {
+    return gp_eval_impl(m, points, n_inf, out4, lap, 0, nullptr, stream);
+}
+
+extern "C" int scasml_gp_eval_sites(const scasml_gp_model *m, const float *points, int64_t n_inf, int64_t rows_per_site,
+                                    const uint8_t *site_u_only, float *out4, void *stream) {
+    if (site_u_only && rows_per_site < 1) return fail(SCASML_ERR_ARG, "gp_eval_sites: rows_per_site must be positive");
+    return gp_eval_impl(m, points, n_inf, out4, nullptr, rows_per_site, site_u_only, stream);
 }
 
 extern "C" int scasml_gp_gradient(const scasml_gp_model *m, const float *points, int64_t n_inf, float *grad, void *stream) {

@@ -21,6 +21,8 @@
 // for the whole sweep; per collocation tile one LDS slot [SPLIT*KS KiB of A fragments | 1 KiB coefficients]
 // filled one tile ahead by global_load_lds; one barrier per tile; SIMD partner waves (w, w+4) run half a
 // tile apart so one's VALU epilogue overlaps the other's MFMAs.  The epilogue is gp_common.hpp's.
+#include <type_traits>
+
 #include "gp_common.hpp"
 
 namespace scasml {
@@ -203,24 +205,40 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
         const float *b = lds + slot * STAGE;
         return GpStageView{reinterpret_cast<const float4 *>(b), b + NPL * KS * 256};
     };
-    f32x16 acc[1];
-    __syncthreads();  // tile 0 has landed (the barrier drains the LDS-DMA)
-    if (!late) {
-        for (int jt = 0; jt < n_tiles; ++jt) {
-            if (jt + 1 < n_tiles && !(g.dbg & 8)) stage(jt + 1, (jt + 1) % 3);
-            if (!(g.dbg & 1)) gp_mfma_tile_bf16<KS, SPLIT, PF, F16, YEXACT>(a_of(jt % 3), xb, acc[0], lane);
-            if (!(g.dbg & 2)) gp_epilogue_tile<1, true, PF>(view(jt % 3), acc, c, half, nx, sx, tx, au, at, ad, al);
-            __syncthreads();
-        }
-    } else {
-        for (int jt = 0; jt < n_tiles; ++jt) {
-            if (jt + 1 < n_tiles && !(g.dbg & 8)) stage(jt + 1, (jt + 1) % 3);
-            if (jt > 0 && !(g.dbg & 2)) gp_epilogue_tile<1, true, PF>(view((jt - 1) % 3), acc, c, half, nx, sx, tx, au, at, ad, al);
-            if (!(g.dbg & 1)) gp_mfma_tile_bf16<KS, SPLIT, PF, F16, YEXACT>(a_of(jt % 3), xb, acc[0], lane);
-            __syncthreads();
-        }
-        gp_epilogue_tile<1, true, PF>(view((n_tiles - 1) % 3), acc, c, half, nx, sx, tx, au, at, ad, al);
+    // site-major buffers: all 32 rows of this wave belong to one or two neighbouring tree sites; if only
+    // u_hat is consumed there (terminal-time points, the root) the epilogue drops the dt / div / Lap sums
+    bool uonly = false;
+    if (g.site_u_only && g.rows_per_site >= 32) {
+        const int64_t last = p0 + 31 < g.n_inf ? p0 + 31 : g.n_inf - 1;
+        const int64_t s0 = p0 < g.n_inf ? p0 / g.rows_per_site : 0, s1 = last / g.rows_per_site;
+        uonly = g.site_u_only[s0] && g.site_u_only[s1];
     }
+    uonly = __builtin_amdgcn_readfirstlane((int)uonly) != 0;
+    f32x16 acc[1];
+    // the whole sweep is instantiated twice (full / u-only epilogue) and the wave-uniform choice is made once,
+    // outside the tile loops: a branch inside them costs registers (the allocator then spills the point tile)
+    auto sweep = [&](auto uo) {
+        constexpr bool UO = decltype(uo)::value;
+        if (!late) {
+            for (int jt = 0; jt < n_tiles; ++jt) {
+                if (jt + 1 < n_tiles && !(g.dbg & 8)) stage(jt + 1, (jt + 1) % 3);
+                if (!(g.dbg & 1)) gp_mfma_tile_bf16<KS, SPLIT, PF, F16, YEXACT>(a_of(jt % 3), xb, acc[0], lane);
+                if (!(g.dbg & 2)) gp_epilogue_tile<1, true, PF, UO>(view(jt % 3), acc, c, half, nx, sx, tx, au, at, ad, al);
+                __syncthreads();
+            }
+        } else {
+            for (int jt = 0; jt < n_tiles; ++jt) {
+                if (jt + 1 < n_tiles && !(g.dbg & 8)) stage(jt + 1, (jt + 1) % 3);
+                if (jt > 0 && !(g.dbg & 2)) gp_epilogue_tile<1, true, PF, UO>(view((jt - 1) % 3), acc, c, half, nx, sx, tx, au, at, ad, al);
+                if (!(g.dbg & 1)) gp_mfma_tile_bf16<KS, SPLIT, PF, F16, YEXACT>(a_of(jt % 3), xb, acc[0], lane);
+                __syncthreads();
+            }
+            gp_epilogue_tile<1, true, PF, UO>(view((n_tiles - 1) % 3), acc, c, half, nx, sx, tx, au, at, ad, al);
+        }
+    };
+    __syncthreads();  // tile 0 has landed (the barrier drains the LDS-DMA)
+    if (uonly) sweep(std::true_type{});
+    else sweep(std::false_type{});
 
     const float s2 = g.sigma * g.sigma;
     const float u = au[0] + __shfl_xor(au[0], 32);

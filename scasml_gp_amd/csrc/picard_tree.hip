@@ -56,7 +56,7 @@ struct Walker {
     float4 mask;       // 1 on this lane's live spatial dims, 0 on padding
     uint32_t gl;       // lane index inside the root's group = Philox quad index
     uint32_t root;     // global root index (Philox counter word 2)
-    int64_t row0;      // first row of this root in points / gpv
+    int64_t local;     // this root's index inside the call's batch: row of site s = s * B + local
     int unit;          // running unit index of the ROOT call (sample sharding)
 
     __device__ __forceinline__ float group_sum(float v) const {
@@ -77,9 +77,9 @@ struct Walker {
         v.y = dim0 + 1 < a.d ? X.y : (dim0 + 1 == a.d ? t : 0.0f);
         v.z = dim0 + 2 < a.d ? X.z : (dim0 + 2 == a.d ? t : 0.0f);
         v.w = dim0 + 3 < a.d ? X.w : (dim0 + 3 == a.d ? t : 0.0f);
-        *reinterpret_cast<float4 *>(a.points + (row0 + site) * a.kp + dim0) = v;
+        *reinterpret_cast<float4 *>(a.points + ((int64_t)site * a.B + local) * a.kp + dim0) = v;
     }
-    __device__ __forceinline__ float4 gp_at(uint32_t site) const { return a.gpv[row0 + site]; }
+    __device__ __forceinline__ float4 gp_at(uint32_t site) const { return a.gpv[(int64_t)site * a.B + local]; }
     __device__ __forceinline__ bool owned(bool top) {
         if (!top || a.world == 1) return true;
         const bool mine = (unit % a.world) == a.rank;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void picard_tree_kernel(const TreeArgs a) {
     Walker<VAR, MODE> w{a};
     w.gl = (uint32_t)(lane & (a.G - 1));
     w.root = a.root0 + (uint32_t)local;
-    w.row0 = local * a.ppr;
+    w.local = local;
     w.unit = 0;
     const int dim0 = 4 * (int)w.gl;
     w.mask = make_float4(dim0 + 0 < a.d ? 1.0f : 0.0f, dim0 + 1 < a.d ? 1.0f : 0.0f,
@@ -311,6 +311,31 @@ using namespace scasml;
 extern "C" int64_t scasml_points_per_root(const scasml_plan *plan_h) {
     if (!plan_h || plan_h->n < 0 || plan_h->n > SCASML_MAX_LEVEL) return -1;
     return (int64_t)plan_h->sites[plan_h->n] + 1;
+}
+
+// Site kinds in the kernels' enumeration order (terminal samples first, then per level / path / node the
+// Euler-Maruyama site followed by its child subtrees): 1 = only u_hat of the surrogate is consumed there.
+static void site_kinds_rec(const scasml_plan *p, int n, uint8_t *&out) {
+    if (n == 0) return;
+    for (int m = 0; m < p->mg[n]; ++m) *out++ = 1;
+    for (int l = 0; l < n; ++l) {
+        const scasml_term &t = p->term[n][l];
+        for (int m = 0; m < t.mc; ++m)
+            for (int k = 0; k < t.q; ++k) {
+                *out++ = 0;
+                site_kinds_rec(p, l, out);
+                if (l > 0) site_kinds_rec(p, l - 1, out);
+            }
+    }
+}
+
+extern "C" int scasml_plan_site_kinds(const scasml_plan *plan_h, uint8_t *kinds_h) {
+    if (!plan_h || !kinds_h || plan_h->n < 0 || plan_h->n > SCASML_MAX_LEVEL) return fail(SCASML_ERR_ARG, "plan_site_kinds: bad argument");
+    uint8_t *w = kinds_h;
+    site_kinds_rec(plan_h, plan_h->n, w);
+    if (w - kinds_h != plan_h->sites[plan_h->n]) return fail(SCASML_ERR_ARG, "plan_site_kinds: plan.sites is inconsistent with its terms");
+    *w = 1;   // the root row
+    return 0;
 }
 
 extern "C" int32_t scasml_point_stride(int32_t d) { return (d + 3 + 15) / 16 * 16; }

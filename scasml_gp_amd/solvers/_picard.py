@@ -30,10 +30,11 @@ class PicardEngine:
         self.profile = False           # bench.py: bracket every launch with HIP events on the launch stream
         self._events = []
         self._plans = {}
+        self._kinds = {}
 
     def __getstate__(self):               # deep-copyable (tests/ComputingBudget.py:138): drop caches and events
         st = dict(self.__dict__)
-        st["_plans"], st["_events"] = {}, []
+        st["_plans"], st["_events"], st["_kinds"] = {}, [], {}
         return st
 
     def _timed(self, name, fn):
@@ -63,6 +64,18 @@ class PicardEngine:
             self._plans[key] = tables.build_plan(self.variant, n, par, float(self.equation.T),
                                                  stale_delta_t=self.gp is None)
         return self._plans[key]
+
+    def site_kinds(self, n, par):
+        """Device byte per tree site: 1 where only u_hat of the surrogate is consumed (scasml_plan_site_kinds)."""
+        key = (n, par)
+        if key not in self._kinds:
+            torch = _lib.require_gpu()
+            plan = self.plan(n, par)
+            ppr = int(_lib.load().scasml_points_per_root(C.byref(plan)))
+            host = np.zeros(ppr, dtype=np.uint8)
+            _lib.check(_lib.load().scasml_plan_site_kinds(C.byref(plan), host.ctypes.data_as(C.c_void_p)), "plan_site_kinds")
+            self._kinds[key] = torch.from_numpy(host).cuda()
+        return self._kinds[key]
 
     def problem(self):
         eq = self.equation
@@ -100,6 +113,7 @@ class PicardEngine:
         if world > 1:
             pts.zero_()                    # rows of un-owned units are never written
         vals = torch.empty((chunk * ppr, 4), dtype=torch.float32, device="cuda")
+        kinds = self.site_kinds(n, par) if n > 0 else None
         for b0 in range(0, B, chunk):
             nb = min(chunk, B - b0)
             rng_c = _lib.Rng(rng.seed, rng.stream, root0 + b0, rank, world)
@@ -109,8 +123,8 @@ class PicardEngine:
                 _lib.check(self._timed("picard_generate", lambda: lib.scasml_picard_tree(
                     C.byref(prob), C.byref(plan), _lib.MODE_GENERATE, _lib.ptr(xc), nb, rng_c,
                     _lib.ptr(pts), None, None, None, s)), "picard_tree(generate)")
-                _lib.check(self._timed("gp_eval", lambda: lib.scasml_gp_eval(
-                    C.byref(model), _lib.ptr(pts), nb * ppr, _lib.ptr(vals), None, s)), "gp_eval")
+                _lib.check(self._timed("gp_eval", lambda: lib.scasml_gp_eval_sites(
+                    C.byref(model), _lib.ptr(pts), nb * ppr, nb, _lib.ptr(kinds), _lib.ptr(vals), s)), "gp_eval")
                 _lib.check(self._timed("picard_accumulate", lambda: lib.scasml_picard_tree(
                     C.byref(prob), C.byref(plan), _lib.MODE_ACCUMULATE, _lib.ptr(xc), nb, rng_c,
                     None, _lib.ptr(vals), _lib.ptr(ob), _lib.ptr(ub), s)), "picard_tree(accumulate)")

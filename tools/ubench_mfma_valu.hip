@@ -85,9 +85,48 @@ float run(float *out, int threads, int iters) {
     return ms;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// VALU-only: 32 scalar v_fma_f32 per iteration vs 16 packed v_pk_fma_f32 (same flops)
+template <int PACKED>
+__global__ __launch_bounds__(1024) void kv(float *out, int iters, float a, float b) {
+    f32x2 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = (f32x2){threadIdx.x * 1e-3f + i, threadIdx.x * 2e-3f - i};
+    const f32x2 a2 = {a, a * 1.0001f}, b2 = {b, b * 0.5f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (PACKED) {
+                v[i] = __builtin_elementwise_fma(v[i], a2, b2);
+            } else {
+                v[i].x = __builtin_fmaf(v[i].x, a2.x, b2.x);
+                v[i].y = __builtin_fmaf(v[i].y, a2.y, b2.y);
+            }
+        }
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += v[i].x + v[i].y;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int PACKED>
+float runv(float *out, int threads, int iters) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(kv<PACKED>, dim3(256), dim3(threads), 0, 0, out, 100, 1.0001f, 1e-6f);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kv<PACKED>, dim3(256), dim3(threads), 0, 0, out, iters, 1.0001f, 1e-6f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms;
+}
+
 int main() {
     float *out;
-    hipMalloc(&out, 256 * 768 * 4);
+    hipMalloc(&out, 256 * 1024 * 4);
     const int it = 200000;
     printf("one wave per SIMD (256 threads/block, 1 block/CU)\n");
     printf("  0 mfma_f32 only      : %.3f ms\n", run<0>(out, 256, it));
@@ -106,5 +145,8 @@ int main() {
     printf("three waves per SIMD (768 threads/block)\n");
     printf("  1 valu only                : %.3f ms\n", run<1>(out, 768, it));
     printf("  7 bf16 mfma wave || 2 valu waves per SIMD : %.3f ms\n", run<7>(out, 768, it));
+    printf("VALU only, 32 flops-pairs per iteration: scalar v_fma_f32 x32 vs packed v_pk_fma_f32 x16\n");
+    for (int th = 256; th <= 1024; th *= 2)
+        printf("  %d waves/SIMD: scalar %.3f ms   packed %.3f ms\n", th / 256, runv<0>(out, th, it), runv<1>(out, th, it));
     return 0;
 }
