@@ -47,6 +47,13 @@ def parse():
     return ap.parse_args()
 
 
+def rel_l2(sol, exact):
+    """tests/SimpleUniform.py:110-136: NaN-masked ||sol - exact||_2 / ||exact||_2."""
+    sol, exact = np.asarray(sol, dtype=np.float64).ravel(), np.asarray(exact, dtype=np.float64).ravel()
+    m = ~(np.isnan(sol) | np.isnan(exact))
+    return float(np.linalg.norm(sol[m] - exact[m]) / np.linalg.norm(exact[m]))
+
+
 def cpu_baseline(args, eq, gp, eng, n, par, x_t, x_dev, x_dom, x_bdy, steps_exec, B):
     """Time the oracle restatement (NumPy float64) on a bounded sample of the same workload, same inputs and
     Philox streams, and report the GPU-vs-CPU difference on that sample."""
@@ -171,7 +178,6 @@ def main():
         return
 
     # ---- accuracy on the harness protocol (untimed): 1000 + 200 test points ---------------------
-    from oracle.equation import rel_l2                       # metric definition only (tests/SimpleUniform.py:134-136)
     exact = eq.exact_solution(xt_h)
     u_gpu = solver.u_solve(n, par, xt_h) if args.variant == "quad" else solver.u_solve(n, None, xt_h, args.M)
     rel_gpu = rel_l2(u_gpu, exact)
