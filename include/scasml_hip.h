@@ -104,6 +104,7 @@ int32_t scasml_point_stride(int32_t d);
  *   points   : MODE_GENERATE out: points_per_root x B x point_stride, SITE-major (row = site*B + root): the 32
  *              rows a wavefront of scasml_gp_eval takes are one tree site of 32 roots, so per-site work
  *              selection there is wave-uniform.  Row content (X, t, zero pad).
+ *              MODE_ACCUMULATE in: the same buffer (Euler-Maruyama states are read back, not recomputed).
  *   gp_vals  : MODE_ACCUMULATE in: points_per_root x B x 4 = (u_hat, div_x u_hat, eps_PDE, dt u_hat), same row
  *              order, from scasml_gp_eval on `points`.
  *   out_uz   : B x (1+d): (u, z) clipped [MLP, ACCUMULATE]; un-clipped partial sums if world > 1.

@@ -41,6 +41,7 @@ __device__ __forceinline__ float4 fma4(float s, float4 a, float4 b) {  // s*a + 
     return make_float4(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z), fmaf(s, a.w, b.w));
 }
 __device__ __forceinline__ float4 add4(float4 a, float s) { return make_float4(a.x + s, a.y + s, a.z + s, a.w + s); }
+__device__ __forceinline__ float4 f4_scale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
 __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 __device__ __forceinline__ float clip1(float v, float c) { return v < -c ? -c : (v > c ? c : v); }  // keeps NaN (jnp.clip)
 // Hardware reciprocal / square root / exp2 (<= 1 ulp) for the arithmetic that is NOT part of the bit-exact
@@ -80,6 +81,9 @@ struct Walker {
         *reinterpret_cast<float4 *>(a.points + ((int64_t)site * a.B + local) * a.kp + dim0) = v;
     }
     __device__ __forceinline__ float4 gp_at(uint32_t site) const { return a.gpv[(int64_t)site * a.B + local]; }
+    __device__ __forceinline__ float4 load_point(uint32_t site) const {   // this lane's four dims of a stored tree point
+        return *reinterpret_cast<const float4 *>(a.points + ((int64_t)site * a.B + local) * a.kp + 4 * (int)gl);
+    }
     __device__ __forceinline__ bool owned(bool top) {
         if (!top || a.world == 1) return true;
         const bool mine = (unit % a.world) == a.rank;
@@ -121,11 +125,23 @@ struct Walker {
             for (int k = 0; k < q; ++k) {
                 const uint32_t site = base + o;
                 o += 1;
-                const float4 xi = normals(site);
                 float tk, wk;
                 float4 wvec;  // the vector multiplying y in the z estimator
                 float dplus, dminus;
-                if constexpr (VAR == 0) {                        // MLP.py:219-225
+                if constexpr (VAR == 0 && MODE == SCASML_MODE_ACCUMULATE) {
+                    // The pass that emitted the points already produced X_k, bit for bit; read it back instead
+                    // of replaying Philox + Box-Muller, and recover W_k = (X_k - x - mu (t_k - t)) / sigma (one
+                    // rounding of a difference of O(1) numbers divided by sigma: ~1e-6 relative).
+                    const float ck = tau * tm.cfrac[k];
+                    X = load_point(site);
+                    W = mul4(fma4(1.0f / a.sigma, add4(X, -a.mu * ck), f4_scale(x, -1.0f / a.sigma)), mask);
+                    tk = t + ck;
+                    wk = tau * tm.wfrac[k];
+                    wvec = W;
+                    dplus = rcp_fast(fmaf(tau, tm.dplus[k], 1e-6f));
+                    dminus = rcp_fast(fmaf(tau, tm.cfrac[k], 1e-6f));
+                } else if constexpr (VAR == 0) {                 // MLP.py:219-225
+                    const float4 xi = normals(site);
                     const float dk = tau * tm.dfrac[k];
                     const float sdk = sqrt_fast(dk);
                     W = fma4(sdk, xi, W);
@@ -136,6 +152,7 @@ struct Walker {
                     dplus = rcp_fast(fmaf(tau, tm.dplus[k], 1e-6f));   // MLP.py:249 (stale) / ScaSML.py:253
                     dminus = rcp_fast(fmaf(tau, tm.cfrac[k], 1e-6f));  // MLP.py:270
                 } else {                                         // MLP_full_history.py:133-145
+                    const float4 xi = normals(site);
                     const float D = uniform_tau(site, root, a.stream, a.k0, a.k1) * tau;
                     const float sD = sqrt_fast(D);
                     X = fma4(a.sigma * sD, xi, add4(x, a.mu * D));
@@ -356,7 +373,8 @@ extern "C" int scasml_picard_tree(const scasml_problem *prob, const scasml_plan 
         return fail(SCASML_ERR_UNSUPPORTED, "picard_tree: level n=%d outside 0..%d", plan->n, SCASML_MAX_LEVEL);
     if (rng.world < 1 || rng.rank < 0 || rng.rank >= rng.world) return fail(SCASML_ERR_ARG, "picard_tree: bad rank/world");
     if (mode == SCASML_MODE_GENERATE && !points) return fail(SCASML_ERR_ARG, "picard_tree: GENERATE needs points");
-    if (mode == SCASML_MODE_ACCUMULATE && !gp_vals) return fail(SCASML_ERR_ARG, "picard_tree: ACCUMULATE needs gp_vals");
+    if (mode == SCASML_MODE_ACCUMULATE && (!gp_vals || !points))
+        return fail(SCASML_ERR_ARG, "picard_tree: ACCUMULATE needs gp_vals and the points emitted by GENERATE");
     if (mode != SCASML_MODE_GENERATE && !out_uz) return fail(SCASML_ERR_ARG, "picard_tree: out_uz is null");
     for (int np = 1; np <= plan->n; ++np)
         for (int l = 0; l < np; ++l) {

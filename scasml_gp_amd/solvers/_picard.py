@@ -127,7 +127,7 @@ class PicardEngine:
                     C.byref(model), _lib.ptr(pts), nb * ppr, nb, _lib.ptr(kinds), _lib.ptr(vals), s)), "gp_eval")
                 _lib.check(self._timed("picard_accumulate", lambda: lib.scasml_picard_tree(
                     C.byref(prob), C.byref(plan), _lib.MODE_ACCUMULATE, _lib.ptr(xc), nb, rng_c,
-                    None, _lib.ptr(vals), _lib.ptr(ob), _lib.ptr(ub), s)), "picard_tree(accumulate)")
+                    _lib.ptr(pts), _lib.ptr(vals), _lib.ptr(ob), _lib.ptr(ub), s)), "picard_tree(accumulate)")
             else:                          # n == 0: zeros (ScaSML.py:217-219); u_hat still needed by u_solve
                 out[b0:b0 + nb].zero_()
                 uhat[b0:b0 + nb] = self.gp._predict_device(xc)[:, 0]
