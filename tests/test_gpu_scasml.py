@@ -84,3 +84,56 @@ def test_untrained_gp_fails_loudly():
     eq = Grad_Dependent_Nonlinear(11)
     with pytest.raises(_lib.ScasmlError):
         ScaSML(eq, GP_Grad_Dependent_Nonlinear(eq)).u_solve(1, 1, np.zeros((2, 11), dtype=np.float32))
+
+
+def test_terminal_time_rows_float16_inputs_and_deepcopy():
+    """t = T rows (tau = 0: every step degenerates, z saturates at the clip), float16 input arrays as the
+    reference harness passes (experiment_run.py:30), and a deep-copied solver (tests/ComputingBudget.py:138)."""
+    import copy
+    hip, ora, _ = _setup(20, 60, 20, "quad", seed=4)
+    xt = _test_points(20, 40, 34)
+    xt[::5, -1] = 0.5
+    got, want = hip.uz_solve(2, 2, xt), ora.uz_solve(2, 2, xt)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    m = ~np.isnan(want)
+    assert np.all(np.abs(got[m] - want[m]) <= ATOL + RTOL * np.abs(want[m])), np.abs(got[m] - want[m]).max()
+    x16 = xt.astype(np.float16)
+    hip._engine.calls = 0
+    a = hip.u_solve(2, 2, x16)
+    hip._engine.calls = 0
+    b = hip.u_solve(2, 2, x16.astype(np.float32))
+    assert a.dtype == np.float32 and np.array_equal(a, b)
+    clone = copy.deepcopy(hip)
+    clone._engine.calls = hip._engine.calls = 0
+    assert np.array_equal(clone.uz_solve(2, 2, xt), hip.uz_solve(2, 2, xt))
+    assert clone.GP is not hip.GP and clone.evaluation_counter == hip.evaluation_counter
+
+
+def test_reference_evaluation_counter_for_scasml():
+    from scasml_gp_amd import tables
+    hip, _, _ = _setup(6, 30, 10, "quad", seed=2)
+    xt = _test_points(6, 8, 35)
+    hip.u_solve(2, 2, xt)
+    assert hip.evaluation_counter == tables.reference_evaluation_count("quad", 2, 2, True)
+
+
+@pytest.mark.parametrize("d", [250, 253])
+def test_large_dimension_scasml(d):
+    hip, ora, _ = _setup(d, 40, 8, "quad", seed=8)
+    xt = _test_points(d, 5, 36)
+    got, want = hip.uz_solve(2, 2, xt), ora.uz_solve(2, 2, xt)
+    assert np.all(np.abs(got - want) <= ATOL + RTOL * np.abs(want)), np.abs(got - want).max()
+
+
+def test_sample_sharded_scasml_partials():
+    """Monte-Carlo sample sharding of the ScaSML root call: the partial sums of world = 2 add up to the
+    unsharded result (un-owned rows of the point buffer are zero and their GP values unused)."""
+    import torch
+    hip, ora, _ = _setup(20, 60, 20, "quad", seed=6)
+    xt = _test_points(20, 24, 37)
+    eng = hip._engine
+    full, _, _ = eng.solve(3, 3, xt, stream_id=0)
+    parts = [eng.solve(3, 3, xt, rank=r, world=2, stream_id=0)[0] for r in range(2)]
+    for r in range(2):
+        assert np.allclose(parts[r].cpu().numpy(), ora.uz_solve(3, 3, xt, rank=r, world=2), atol=2e-4, rtol=2e-4)
+    assert torch.allclose(eng.finalize_partials(parts[0] + parts[1]), full, atol=1e-4, rtol=1e-4)
