@@ -50,6 +50,19 @@ __device__ __forceinline__ uint32_t pack_h2(float a, float b) {   // two fp16 (R
     return (uint32_t)__builtin_bit_cast(unsigned short, ha) | ((uint32_t)__builtin_bit_cast(unsigned short, hb) << 16);
 }
 
+// One 16-byte-per-lane LDS-DMA (global_load_lds_dwordx4) issued from inline asm.  hipcc models the builtin
+// form as an LDS write and puts `s_waitcnt vmcnt(0)` in front of the next ds_read, i.e. it drains the DMA the
+// moment it was issued; an asm statement is opaque to that pass, so completion is counted by hand (counted
+// vmcnt + raw s_barrier in `rendezvous`).  M0 carries the wave-uniform LDS byte address and is saved/restored
+// inside the same statement (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void glds16_asm(const float *gsrc_lane, uint32_t lds_byte_addr_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc_lane), "s"(lds_byte_addr_uniform)
+                 : "memory");
+}
+
 // KS = kp / 16 K-steps of the 32x32x16 MFMA; half-wave h covers k in [h*8*KS, (h+1)*8*KS)
 template <int KS, int SPLIT, bool PF, bool F16, bool YEXACT>
 __device__ __forceinline__ void gp_mfma_tile_bf16(const float4 *lds_a, const s16x8 (&xb)[SPLIT][KS], f32x16 &acc, int lane) {
@@ -115,25 +128,46 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
     constexpr bool PF = WPB * BPC <= 8;
     static_assert(WPB == 8 || WPB == 12 || WPB == 16, "waves per workgroup");
     constexpr int STAGE = NPL * KS * 256 + 512;         // floats per LDS slot (A fragments + 32 rows x 16 coefficients)
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // 3 slots
+    constexpr int NSLOT = (4 * STAGE * 4 * BPC <= 144 * 1024) ? 4 : 3;
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // NSLOT slots
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int col = lane & 31, half = lane >> 5;
     const bool late = (__builtin_amdgcn_readfirstlane(wv) >> 2) == 1 && !(g.dbg & 4);    // scalar, wave-uniform role
     const int64_t p0 = ((int64_t)blockIdx.x * WPB + wv) * 32;
     const int n_tiles = g.n_pad / 32;
 
-    // stage one collocation tile: 1 KiB chunks, chunk c < SPLIT*KS = A fragment (plane, step), last = coefficients
+    // stage one collocation tile: NCHUNK 1-KiB chunks (A fragments (plane, step), then the two coefficient KiB).
+    // Every wave issues exactly CPW global_load_lds per tile (surplus slots repeat the last chunk: same bytes
+    // to the same place), so a counted s_waitcnt vmcnt(CPW) means "everything but the newest tile has landed".
+    constexpr int NCHUNK = NPL * KS + 2;
+    constexpr int CPW = (NCHUNK + WPB - 1) / WPB;
+    // low 32 bits of a flat pointer into the LDS aperture = the LDS byte address
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
     auto stage = [&](int tile, int slot) {
-        float *dst = lds + slot * STAGE;
-        const float *src = reinterpret_cast<const float *>(F16 ? g.colloc_f16 : g.colloc_bf16) + (int64_t)tile * (F16 ? 2 : 3) * KS * 256;
-        for (int c = wv; c < NPL * KS; c += WPB)
-            __builtin_amdgcn_global_load_lds(src + c * 256 + lane * 4, dst + c * 256, 16, 0, 0);
-        if (wv == ((NPL * KS) % WPB))
-            __builtin_amdgcn_global_load_lds(g.coef + (int64_t)tile * 512 + lane * 4, dst + NPL * KS * 256, 16, 0, 0);
-        if (wv == ((NPL * KS + 1) % WPB))
-            __builtin_amdgcn_global_load_lds(g.coef + (int64_t)tile * 512 + 256 + lane * 4, dst + NPL * KS * 256 + 256, 16, 0, 0);
+        const uint32_t dst = lds_base + (uint32_t)(slot * STAGE) * 4u;
+        const float *srcA = reinterpret_cast<const float *>(F16 ? g.colloc_f16 : g.colloc_bf16) + (int64_t)tile * (F16 ? 2 : 3) * KS * 256;
+        const float *srcC = g.coef + (int64_t)tile * 512 - (int64_t)NPL * KS * 256;   // chunk c >= NPL*KS -> coef + (c - NPL*KS) KiB
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) {
+            int c = wv + i * WPB;
+            c = c < NCHUNK ? c : NCHUNK - 1;
+            const float *src = c < NPL * KS ? srcA : srcC;
+            glds16_asm(src + c * 256 + lane * 4, (uint32_t)__builtin_amdgcn_readfirstlane((int)(dst + (uint32_t)c * 1024u)));
+        }
+    };
+    // NSLOT = 4: tiles are fetched TWO ahead and the per-tile rendezvous is a raw s_barrier behind a counted
+    // vmcnt, so the newest tile's DMA stays in flight across the barrier (__syncthreads() would drain it:
+    // vmcnt(0)); NSLOT = 3 (slots too big for four): one tile ahead, full drain.
+    auto rendezvous = [&](bool newest_may_fly) {
+        if (NSLOT == 4 && newest_may_fly) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CPW) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
     };
     stage(0, 0);
+    if (NSLOT == 4 && n_tiles > 1) stage(1, 1);
 
     // ---- this wave's 32 points: fp32 row halves -> |x|^2, a*sum x, a*t, and the bf16 planes ------
     s16x8 xb[SPLIT][KS];
@@ -219,24 +253,25 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
     // outside the tile loops: a branch inside them costs registers (the allocator then spills the point tile)
     auto sweep = [&](auto uo) {
         constexpr bool UO = decltype(uo)::value;
+        constexpr int AHEAD = NSLOT == 4 ? 2 : 1;
         if (!late) {
             for (int jt = 0; jt < n_tiles; ++jt) {
-                if (jt + 1 < n_tiles && !(g.dbg & 8)) stage(jt + 1, (jt + 1) % 3);
-                if (!(g.dbg & 1)) gp_mfma_tile_bf16<KS, SPLIT, PF, F16, YEXACT>(a_of(jt % 3), xb, acc[0], lane);
-                if (!(g.dbg & 2)) gp_epilogue_tile<1, true, PF, UO>(view(jt % 3), acc, c, half, nx, sx, tx, au, at, ad, al);
-                __syncthreads();
+                if (jt + AHEAD < n_tiles && !(g.dbg & 8)) stage(jt + AHEAD, (jt + AHEAD) % NSLOT);
+                if (!(g.dbg & 1)) gp_mfma_tile_bf16<KS, SPLIT, PF, F16, YEXACT>(a_of(jt % NSLOT), xb, acc[0], lane);
+                if (!(g.dbg & 2)) gp_epilogue_tile<1, true, PF, UO>(view(jt % NSLOT), acc, c, half, nx, sx, tx, au, at, ad, al);
+                rendezvous(jt + AHEAD < n_tiles);
             }
         } else {
             for (int jt = 0; jt < n_tiles; ++jt) {
-                if (jt + 1 < n_tiles && !(g.dbg & 8)) stage(jt + 1, (jt + 1) % 3);
-                if (jt > 0 && !(g.dbg & 2)) gp_epilogue_tile<1, true, PF, UO>(view((jt - 1) % 3), acc, c, half, nx, sx, tx, au, at, ad, al);
-                if (!(g.dbg & 1)) gp_mfma_tile_bf16<KS, SPLIT, PF, F16, YEXACT>(a_of(jt % 3), xb, acc[0], lane);
-                __syncthreads();
+                if (jt + AHEAD < n_tiles && !(g.dbg & 8)) stage(jt + AHEAD, (jt + AHEAD) % NSLOT);
+                if (jt > 0 && !(g.dbg & 2)) gp_epilogue_tile<1, true, PF, UO>(view((jt - 1) % NSLOT), acc, c, half, nx, sx, tx, au, at, ad, al);
+                if (!(g.dbg & 1)) gp_mfma_tile_bf16<KS, SPLIT, PF, F16, YEXACT>(a_of(jt % NSLOT), xb, acc[0], lane);
+                rendezvous(jt + AHEAD < n_tiles);
             }
-            gp_epilogue_tile<1, true, PF, UO>(view((n_tiles - 1) % 3), acc, c, half, nx, sx, tx, au, at, ad, al);
+            gp_epilogue_tile<1, true, PF, UO>(view((n_tiles - 1) % NSLOT), acc, c, half, nx, sx, tx, au, at, ad, al);
         }
     };
-    __syncthreads();  // tile 0 has landed (the barrier drains the LDS-DMA)
+    rendezvous(n_tiles > 1);  // tile 0 has landed (tile 1 may still be in flight)
     if (uonly) sweep(std::true_type{});
     else sweep(std::false_type{});
 
@@ -263,7 +298,8 @@ static int launch_one(const GpArgs &g, hipStream_t s) {
     const int64_t waves = (g.n_inf + 31) / 32;
     const int64_t blocks = (waves + WPB - 1) / WPB;
     if (blocks > 0x7FFFFFFF) return fail(SCASML_ERR_UNSUPPORTED, "gp_eval: too many points");
-    constexpr size_t lds_bytes = 3 * ((YEXACT ? 1 : SPLIT) * KS * 256 + 512) * sizeof(float);
+    constexpr size_t stage_bytes = ((YEXACT ? 1 : SPLIT) * KS * 256 + 512) * sizeof(float);
+    constexpr size_t lds_bytes = ((4 * stage_bytes * BPC <= 144 * 1024) ? 4 : 3) * stage_bytes;
     static_assert(lds_bytes <= 160 * 1024, "LDS slots exceed 160 KiB");
     auto kern = gp_eval_bf16_kernel<KS, SPLIT, WPB, F16, BPC, YEXACT>;
     if (lds_bytes > 64 * 1024) {
