@@ -224,6 +224,64 @@ __global__ __launch_bounds__(256) void trsm_update_kernel(const double *L, int64
     mfma_tile_update(Ls, Xt, B + r0 * nrhs + c0, nrhs, (int)(rows < TB ? rows : TB), (int)(cols < TB ? cols : TB));
 }
 
+// ---------------------------------------------------------------------------------- Newton system
+// Unknowns sol = [z1, z3, z5] (values of u, Lap u, div u at the N domain points); feature vector
+// b(sol) = [z1, g, z3, F(sol), z5] with F = -s2 z1 z5 + (1/d + s2/2) z5 - (s2/2) z3 (models/GP.py:430-444, 705-719).
+__global__ void gp_newton_b_kernel(int d, double s2, const double *sol, const double *bdy_g, int N, int Nb, double *b) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int M = 4 * N + Nb;
+    if (i >= M) return;
+    double v;
+    if (i < N) v = sol[i];
+    else if (i < N + Nb) v = bdy_g[i - N];
+    else if (i < 2 * N + Nb) v = sol[N + (i - N - Nb)];
+    else if (i < 3 * N + Nb) {
+        const int k = i - 2 * N - Nb;
+        const double z1 = sol[k], z3 = sol[N + k], z5 = sol[2 * N + k];
+        v = -s2 * z1 * z5 + (1.0 / d + 0.5 * s2) * z5 - 0.5 * s2 * z3;
+    } else v = sol[2 * N + (i - 3 * N - Nb)];
+    b[i] = v;
+}
+
+// y = A x for a dense row-major M x M float64 matrix: one wavefront per row
+__global__ __launch_bounds__(256) void gemv_kernel(const double *A, int64_t M, int64_t lda, const double *x, double *y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    double acc = 0.0;
+    for (int64_t k = lane; k < M; k += 64) acc = fma(A[row * lda + k], x[k], acc);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) y[row] = acc;
+}
+
+// Gradient and full Hessian of J(sol) = b^T A b (A = K_p^-1 symmetric), written into a zero-padded
+// (ldh x ldh) buffer whose padding is the identity (ready for scasml_cholesky):
+//   dF/dz1 = -s2 z5, dF/dz3 = -s2/2, dF/dz5 = -s2 z1 + (1/d + s2/2)  (cf. models/GP.py:722-743)
+//   grad_i = 2 (Ab[r_i] + dF_i Ab[r4_i]),
+//   H_ij   = 2 (A[r_i,r_j] + dF_i A[r4_i,r_j] + A[r_i,r4_j] dF_j + dF_i A[r4_i,r4_j] dF_j)
+//            + 2 (-s2) Ab[r4_i] on the (z1_i, z5_i) / (z5_i, z1_i) pairs          (second derivative of F).
+__global__ void gp_newton_system_kernel(int d, double s2, const double *A, int64_t lda, int N, int Nb, const double *sol,
+                                        const double *Ab, double *grad, double *H, int64_t ldh) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= ldh || j >= ldh) return;
+    const int n3 = 3 * N;
+    if (i >= n3 || j >= n3) {
+        H[i * ldh + j] = i == j ? 1.0 : 0.0;
+        return;
+    }
+    const int bi = (int)(i / N), ii = (int)(i % N), bj = (int)(j / N), jj = (int)(j % N);
+    const int64_t off[3] = {0, (int64_t)N + Nb, (int64_t)3 * N + Nb};
+    const int64_t ri = off[bi] + ii, rj = off[bj] + jj, r4i = 2 * (int64_t)N + Nb + ii, r4j = 2 * (int64_t)N + Nb + jj;
+    const double c5 = 1.0 / d + 0.5 * s2;
+    const double dFi = bi == 0 ? -s2 * sol[2 * N + ii] : (bi == 1 ? -0.5 * s2 : -s2 * sol[ii] + c5);
+    const double dFj = bj == 0 ? -s2 * sol[2 * N + jj] : (bj == 1 ? -0.5 * s2 : -s2 * sol[jj] + c5);
+    double h = 2.0 * (A[ri * lda + rj] + dFi * A[r4i * lda + rj] + A[ri * lda + r4j] * dFj + dFi * A[r4i * lda + r4j] * dFj);
+    if (ii == jj && ((bi == 0 && bj == 2) || (bi == 2 && bj == 0))) h += 2.0 * (-s2) * Ab[r4i];
+    H[i * ldh + j] = h;
+    if (j == 0) grad[i] = 2.0 * (Ab[ri] + dFi * Ab[r4i]);
+}
+
 __global__ void add_diag_kernel(double *A, int64_t M, double v) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < M) A[i * M + i] += v;
@@ -289,4 +347,32 @@ extern "C" int scasml_trsm_lower(const double *L, int64_t M, double *Bmat, int64
         }
     }
     return check_launch("trsm launch");
+}
+
+extern "C" int scasml_gp_newton_b(int32_t eq_id, int32_t d, double sigma, const double *sol, const double *bdy_g, int32_t n_dom,
+                                  int32_t n_bdy, double *b, void *stream) {
+    if (eq_id != SCASML_EQ_GRAD_DEPENDENT_NONLINEAR) return fail(SCASML_ERR_UNSUPPORTED, "gp_newton_b: unknown equation id %d", eq_id);
+    if (!sol || !b || n_dom < 1 || n_bdy < 0 || (n_bdy > 0 && !bdy_g)) return fail(SCASML_ERR_ARG, "gp_newton_b: bad argument");
+    const int M = 4 * n_dom + n_bdy;
+    hipLaunchKernelGGL(gp_newton_b_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, d, sigma * sigma, sol, bdy_g, n_dom, n_bdy, b);
+    return check_launch("gp_newton_b launch");
+}
+
+extern "C" int scasml_gemv(const double *A, int64_t M, int64_t lda, const double *x, double *y, void *stream) {
+    if (!A || !x || !y || M < 1 || lda < M) return fail(SCASML_ERR_ARG, "gemv: bad argument");
+    hipLaunchKernelGGL(gemv_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, A, M, lda, x, y);
+    return check_launch("gemv launch");
+}
+
+extern "C" int scasml_gp_newton_system(int32_t eq_id, int32_t d, double sigma, const double *A, int64_t lda, int32_t n_dom,
+                                       int32_t n_bdy, const double *sol, const double *Ab, double *grad, double *H, int64_t ldh,
+                                       void *stream) {
+    if (eq_id != SCASML_EQ_GRAD_DEPENDENT_NONLINEAR) return fail(SCASML_ERR_UNSUPPORTED, "gp_newton_system: unknown equation id %d", eq_id);
+    if (!A || !sol || !Ab || !grad || !H || n_dom < 1 || ldh < 3 * (int64_t)n_dom || lda < 4 * (int64_t)n_dom + n_bdy)
+        return fail(SCASML_ERR_ARG, "gp_newton_system: bad argument");
+    const unsigned gx = (unsigned)((ldh + 15) / 16);
+    if (gx > 65535) return fail(SCASML_ERR_UNSUPPORTED, "gp_newton_system: system too large for this build");
+    hipLaunchKernelGGL(gp_newton_system_kernel, dim3(gx, gx), dim3(16, 16), 0, (hipStream_t)stream, d, sigma * sigma, A, lda, n_dom,
+                       n_bdy, sol, Ab, grad, H, ldh);
+    return check_launch("gp_newton_system launch");
 }

@@ -5,10 +5,9 @@ What runs where:
 * Gram K(phi,phi) in closed form (25 blocks, float64) ............ scasml_gp_gram      (:182-258)
 * Cholesky of K + nugget*I (replaces the SVD factor, :260-267) ... scasml_cholesky
 * K_p^{-1} by two blocked triangular solves, Newton step solves .. scasml_trsm_lower  (:439,533,599)
-* the Newton iteration itself (:487-604) is host-orchestrated torch float64 glue on the device:
-  with A = K_p^{-1} explicit, gradient and Hessian of  b(sol)^T A b(sol)  are block-wise
-  elementwise expressions (b is affine except for the product z1*z5 in F, :705-719), so no
-  autodiff and no per-iteration GEMM is needed.
+* the Newton iteration (:487-604): with A = K_p^{-1} explicit, gradient and Hessian of b(sol)^T A b(sol)
+  are block-wise elementwise expressions (b is affine except for the product z1*z5 in F, :705-719), so
+  no autodiff and no per-iteration GEMM is needed ........... scasml_gp_newton_b / _gemv / _gp_newton_system
 * predict / compute_gradient / compute_PDE_loss (:653-687, 746-769) .. scasml_gp_eval, scasml_gp_gradient
 
 Deviations from the reference, all documented in DESIGN.md: exact Laplacian features instead of
@@ -126,14 +125,11 @@ class GP(object):
         """dF/dz1, dF/dz3, dF/dz5 (diagonals) and the z1-z5 cross second derivative of F."""
         raise NotImplementedError
 
-    def _solve_spd(self, H, rhs, damping):
-        """(H + damping*I)^-1 rhs with the library's Cholesky + triangular solves; None if not SPD."""
+    def _chol_solve_padded(self, Hp, rhs, n, damping):
+        """(H + damping*I)^-1 rhs on an identity-padded system (in place Cholesky + two triangular solves); None if not SPD."""
         torch = _lib.require_gpu()
         lib = _lib.load()
-        n = H.shape[0]
-        npad = _round_up(n, 32)
-        Hp = torch.eye(npad, dtype=torch.float64, device="cuda")
-        Hp[:n, :n] = H
+        npad = Hp.shape[0]
         info = torch.zeros(1, dtype=torch.int32, device="cuda")
         s = _lib.stream_ptr()
         _lib.check(lib.scasml_cholesky(_lib.ptr(Hp), npad, float(damping), _lib.ptr(info), s), "cholesky(newton)")
@@ -146,66 +142,57 @@ class GP(object):
         return b[:n, 0]
 
     def GPsolver(self, x_t_domain, x_t_boundary, GN_steps=20):
-        '''Newton's method on b(sol)^T K_p^-1 b(sol) (models/GP.py:487-604); returns predict(x_domain).'''
+        '''Newton's method on b(sol)^T K_p^-1 b(sol) (models/GP.py:487-604); returns predict(x_domain).
+
+        Host code only sequences kernels and reads two scalars per step (loss, gradient norm): Gram, Cholesky,
+        K_p^-1 (two blocked triangular solves on the identity), b(sol), A b, gradient + Hessian assembly and the
+        Newton solve all run in libscasml_hip (scasml_gp_gram / _cholesky / _trsm_lower / _gp_newton_b / _gemv /
+        _gp_newton_system).'''
         torch = _lib.require_gpu()
         lib = _lib.load()
+        if getattr(self.equation, "eq_id", None) is None:
+            raise NotImplementedError("no HIP Newton kernels for equation %s" % type(self.equation).__name__)
         self.kernel_phi_phi(x_t_domain, x_t_boundary)
         N, Nb, M = self.N_domain, self.N_boundary, self.phi_dim
         L = self._L_pad
         Mp = L.shape[0]
         s = _lib.stream_ptr()
-        # A = K_p^-1 = L^-T L^-1 by two blocked triangular solves on the identity
-        A = torch.eye(Mp, dtype=torch.float64, device="cuda")
+        eq_id, d, sig = int(self.equation.eq_id), int(self.d), float(self.equation.sigma())
+        A = torch.eye(Mp, dtype=torch.float64, device="cuda")          # -> K_p^-1 = L^-T L^-1
         _lib.check(lib.scasml_trsm_lower(_lib.ptr(L), Mp, _lib.ptr(A), Mp, 0, s), "trsm")
         _lib.check(lib.scasml_trsm_lower(_lib.ptr(L), Mp, _lib.ptr(A), Mp, 1, s), "trsm^T")
-        A = A[:M, :M]
-        A = 0.5 * (A + A.T)
-        rhs_f = torch.as_tensor(np.asarray(self.rhs_f(self.x_t_domain), dtype=np.float64), device="cuda")
-        bdy_g = torch.as_tensor(np.asarray(self.bdy_g(self.x_t_boundary), dtype=np.float64), device="cuda")
-        r1, r3, r4, r5 = slice(0, N), slice(N + Nb, 2 * N + Nb), slice(2 * N + Nb, 3 * N + Nb), slice(3 * N + Nb, M)
-        rows = (r1, r3, r5)
+        bdy_g = torch.as_tensor(np.asarray(self.bdy_g(self.x_t_boundary), dtype=np.float64), device="cuda").contiguous()
         sol = torch.zeros(3 * N, dtype=torch.float64, device="cuda")
-        damping = 1e-4                                             # :490
-        idx = torch.arange(N, device="cuda")
+        b = torch.empty(M, dtype=torch.float64, device="cuda")
+        Ab = torch.empty(M, dtype=torch.float64, device="cuda")
+        grad = torch.empty(3 * N, dtype=torch.float64, device="cuda")
+        npad = _round_up(3 * N, 32)
+        H = torch.empty((npad, npad), dtype=torch.float64, device="cuda")
+        damping = 1e-4                                                  # models/GP.py:490
 
-        def bvec(sol_):
-            return torch.cat([sol_[:N], bdy_g, sol_[N:2 * N], self.time_der_rep(sol_, rhs_f), sol_[2 * N:]])
+        def residual(sol_):
+            _lib.check(lib.scasml_gp_newton_b(eq_id, d, sig, _lib.ptr(sol_), _lib.ptr(bdy_g), N, Nb, _lib.ptr(b), s), "gp_newton_b")
+            _lib.check(lib.scasml_gemv(_lib.ptr(A), M, Mp, _lib.ptr(b), _lib.ptr(Ab), s), "gemv")
+            return float(torch.dot(b, Ab))                              # loss = b^T A b, :430-444
 
-        def loss(sol_):
-            b = bvec(sol_)
-            return float(b @ (A @ b))                              # :430-444
-
-        hist = [loss(sol)]
-        for _ in range(GN_steps):                                  # :515-588
-            b = bvec(sol)
-            Ab = A @ b
-            dF, cross = self._newton_terms(sol)
-            grad = 2.0 * torch.cat([Ab[rows[i]] + dF[i] * Ab[r4] for i in range(3)])
-            if float(torch.linalg.vector_norm(grad)) < 1e-5:       # :521
+        hist = [residual(sol)]
+        for _ in range(GN_steps):                                       # :515-588
+            _lib.check(lib.scasml_gp_newton_system(eq_id, d, sig, _lib.ptr(A), Mp, N, Nb, _lib.ptr(sol), _lib.ptr(Ab),
+                                                   _lib.ptr(grad), _lib.ptr(H), npad, s), "gp_newton_system")
+            if float(torch.linalg.vector_norm(grad)) < 1e-5:            # :521
                 break
-            H = torch.empty((3 * N, 3 * N), dtype=torch.float64, device="cuda")
-            for i in range(3):
-                for j in range(3):
-                    H[i * N:(i + 1) * N, j * N:(j + 1) * N] = 2.0 * (
-                        A[rows[i], rows[j]] + dF[i][:, None] * A[r4, rows[j]] + A[rows[i], r4] * dF[j][None, :]
-                        + dF[i][:, None] * A[r4, r4] * dF[j][None, :])
-            Hgn = H.clone()
-            H[idx, 2 * N + idx] += 2.0 * cross * Ab[r4]            # second-order term of hessian(loss), :511
-            H[2 * N + idx, idx] += 2.0 * cross * Ab[r4]
-            step = self._solve_spd(H, -grad, damping)              # :529-533
-            if step is None:                                       # not SPD: Gauss-Newton part (always PSD)
-                step = self._solve_spd(Hgn, -grad, damping)
+            step = self._chol_solve_padded(H, -grad, 3 * N, damping)   # :529-533 (H is overwritten by its factor)
             if step is None:
                 raise ValueError("Newton system is not positive definite")
-            sol = sol + step                                       # alpha = 1, :541,573
-            hist.append(loss(sol))
+            sol = sol + step                                            # alpha = 1, :541,573
+            hist.append(residual(sol))
         self.loss_history = hist
-        z = bvec(sol)                                              # :593-598
-        rv = A @ z                                                 # :599
-        self.right_vector = rv.cpu().numpy()[:, None]              # :600
+        rv = torch.empty(M, dtype=torch.float64, device="cuda")
+        _lib.check(lib.scasml_gemv(_lib.ptr(A), M, Mp, _lib.ptr(b), _lib.ptr(rv), s), "gemv")   # right_vector = K_p^-1 z, :593-600
+        self.right_vector = rv.cpu().numpy()[:, None]
         self._sol = sol
         self._pack(rv)
-        return self.predict(x_t_domain)                            # :602
+        return self.predict(x_t_domain)                                 # :602
 
     def _pack(self, rv):
         torch = _lib.require_gpu()
