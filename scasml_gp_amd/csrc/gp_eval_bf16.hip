@@ -164,7 +164,11 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        // the raw barrier builtin has no memory semantics for the compiler (unlike __syncthreads()): the two
+        // "memory"-clobbering statements around it keep every LDS read on its own side; this wave's own reads
+        // of the slot about to be refilled have completed because their results were consumed above
         __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     };
     stage(0, 0);
     if (NSLOT == 4 && n_tiles > 1) stage(1, 1);
