@@ -62,6 +62,24 @@ def main():
             out["effective_clock_ghz"] = cyc / (out["avg_ms_kernel_trace"] * 1e-3) / 1e9
         json.dump(out, open(os.path.join(HERE, tag + "_gp_eval_pmc.json"), "w"), indent=1)
         print(json.dumps(out, indent=1))
+        # the two Picard-tree passes of the same step (bench-size launches = the largest grid of each kernel)
+        pic = {}
+        for name in sorted({k[0] for k in groups if "picard_tree_kernel" in k[0]}):
+            big_p = max((k for k in groups if k[0] == name), key=lambda k: k[1])
+            ent = {"grid_threads": big_p[1], "avg_ms_kernel_trace": sum(groups[big_p]) / len(groups[big_p])}
+            cnt = {}
+            for d in pmc_dirs:
+                for r in csv.DictReader(open(one(os.path.join(d, "*", "*_counter_collection.csv")))):
+                    if r["Kernel_Name"] == name and int(r["Grid_Size"]) == big_p[1]:
+                        cnt.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            cnt = {k: sum(v) / len(v) for k, v in cnt.items()}
+            if "FETCH_SIZE" in cnt and "WRITE_SIZE" in cnt:
+                ent["hbm_bytes_per_launch"] = 2.0 * cnt["FETCH_SIZE"] * 1024 + cnt["WRITE_SIZE"] * 1024
+                ent["hbm_gb_per_s"] = ent["hbm_bytes_per_launch"] / (ent["avg_ms_kernel_trace"] * 1e-3) / 1e9
+                ent["hbm_frac_of_8tbs"] = ent["hbm_gb_per_s"] / 8000.0
+            ent["counters_avg_per_launch"] = cnt
+            pic[name] = ent
+        json.dump(pic, open(os.path.join(HERE, tag + "_picard_pmc.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
