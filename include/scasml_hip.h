@@ -164,13 +164,16 @@ int scasml_gp_eval(const scasml_gp_model *gp_h, const float *points, int64_t n_i
 /* Same, for the site-major point buffer of scasml_picard_tree: rows [s*rows_per_site, (s+1)*rows_per_site) are
  * tree site s; site_u_only[s] != 0 (device bytes, from scasml_plan_site_kinds) marks sites where only u_hat is
  * consumed (terminal-time points, ScaSML.py:61; the root, ScaSML.py:303) -- their rows get u_hat only
- * (div, eps, dt = 0), which halves the epilogue work there. */
+ * (div, eps, dt = 0), which halves the epilogue work there; site_u_only[s] == 2 marks sites to skip. */
 int scasml_gp_eval_sites(const scasml_gp_model *gp_h, const float *points, int64_t n_inf, int64_t rows_per_site,
                          const uint8_t *site_u_only, float *out4, void *stream);
 
 /* Host helper: fill kinds_h[0 .. points_per_root) with 1 for sites whose GP value is used as u_hat only
- * (terminal samples and the trailing root row), 0 for Euler-Maruyama sites (u_hat, div, eps_PDE needed). */
-int scasml_plan_site_kinds(const scasml_plan *plan_h, uint8_t *kinds_h);
+ * (terminal samples and the trailing root row), 0 for Euler-Maruyama sites (u_hat, div, eps_PDE needed) and
+ * 2 for sites of root-call units this rank does not own under Monte-Carlo sample sharding (unit % world !=
+ * rank, as in scasml_rng): scasml_picard_tree neither writes nor reads those rows and scasml_gp_eval_sites
+ * skips workgroups that lie entirely inside them.  world = 1: no site is skipped. */
+int scasml_plan_site_kinds(const scasml_plan *plan_h, int32_t rank, int32_t world, uint8_t *kinds_h);
 
 /* Full gradient of the posterior mean, n_inf x (d+1), time last: GP.compute_gradient (:673-687). */
 int scasml_gp_gradient(const scasml_gp_model *gp_h, const float *points, int64_t n_inf,

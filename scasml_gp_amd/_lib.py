@@ -60,7 +60,7 @@ SIGNATURES = {
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "scasml_gp_eval": (C.c_int, [C.POINTER(GpModel), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "scasml_gp_eval_sites": (C.c_int, [C.POINTER(GpModel), C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "scasml_plan_site_kinds": (C.c_int, [C.POINTER(Plan), C.c_void_p]),
+    "scasml_plan_site_kinds": (C.c_int, [C.POINTER(Plan), C.c_int32, C.c_int32, C.c_void_p]),
     "scasml_gp_gradient": (C.c_int, [C.POINTER(GpModel), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "scasml_gp_gram": (C.c_int, [C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "scasml_gp_newton_b": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),

@@ -346,12 +346,27 @@ static void site_kinds_rec(const scasml_plan *p, int n, uint8_t *&out) {
     }
 }
 
-extern "C" int scasml_plan_site_kinds(const scasml_plan *plan_h, uint8_t *kinds_h) {
+extern "C" int scasml_plan_site_kinds(const scasml_plan *plan_h, int32_t rank, int32_t world, uint8_t *kinds_h) {
     if (!plan_h || !kinds_h || plan_h->n < 0 || plan_h->n > SCASML_MAX_LEVEL) return fail(SCASML_ERR_ARG, "plan_site_kinds: bad argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(SCASML_ERR_ARG, "plan_site_kinds: bad rank/world");
     uint8_t *w = kinds_h;
     site_kinds_rec(plan_h, plan_h->n, w);
     if (w - kinds_h != plan_h->sites[plan_h->n]) return fail(SCASML_ERR_ARG, "plan_site_kinds: plan.sites is inconsistent with its terms");
-    *w = 1;   // the root row
+    *w = 1;   // the root row (every rank evaluates it)
+    if (world > 1 && plan_h->n > 0) {   // units of the ROOT call, dealt exactly as Walker::owned() does
+        const int n = plan_h->n;
+        int unit = 0;
+        int64_t o = 0;
+        for (int m = 0; m < plan_h->mg[n]; ++m, ++unit, ++o)
+            if (unit % world != rank) kinds_h[o] = 2;
+        for (int l = 0; l < n; ++l) {
+            const scasml_term &t = plan_h->term[n][l];
+            const int64_t span = (int64_t)t.q * (1 + t.sites_l + t.sites_lm1);
+            for (int m = 0; m < t.mc; ++m, ++unit, o += span)
+                if (unit % world != rank)
+                    for (int64_t k = 0; k < span; ++k) kinds_h[o + k] = 2;
+        }
+    }
     return 0;
 }
 

@@ -65,15 +65,16 @@ class PicardEngine:
                                                  stale_delta_t=self.gp is None)
         return self._plans[key]
 
-    def site_kinds(self, n, par):
-        """Device byte per tree site: 1 where only u_hat of the surrogate is consumed (scasml_plan_site_kinds)."""
-        key = (n, par)
+    def site_kinds(self, n, par, rank=0, world=1):
+        """Device byte per tree site: 1 where only u_hat of the surrogate is consumed, 2 where the site belongs
+        to a root-call unit another rank owns (scasml_plan_site_kinds)."""
+        key = (n, par, rank, world)
         if key not in self._kinds:
             torch = _lib.require_gpu()
             plan = self.plan(n, par)
             ppr = int(_lib.load().scasml_points_per_root(C.byref(plan)))
             host = np.zeros(ppr, dtype=np.uint8)
-            _lib.check(_lib.load().scasml_plan_site_kinds(C.byref(plan), host.ctypes.data_as(C.c_void_p)), "plan_site_kinds")
+            _lib.check(_lib.load().scasml_plan_site_kinds(C.byref(plan), rank, world, host.ctypes.data_as(C.c_void_p)), "plan_site_kinds")
             self._kinds[key] = torch.from_numpy(host).cuda()
         return self._kinds[key]
 
@@ -113,7 +114,7 @@ class PicardEngine:
         if world > 1:
             pts.zero_()                    # rows of un-owned units are never written
         vals = torch.empty((chunk * ppr, 4), dtype=torch.float32, device="cuda")
-        kinds = self.site_kinds(n, par) if n > 0 else None
+        kinds = self.site_kinds(n, par, rank, world) if n > 0 else None
         for b0 in range(0, B, chunk):
             nb = min(chunk, B - b0)
             rng_c = _lib.Rng(rng.seed, rng.stream, root0 + b0, rank, world)

@@ -129,3 +129,26 @@ def test_equation_surface_and_sampler():
     assert np.allclose(eq.f(dom, u, z), ora.f(dom, u, z)) and eq.mu() == ora.mu()
     with pytest.raises(NotImplementedError):
         Equation(3).f(None, None, None)
+
+
+@pytest.mark.parametrize("variant,n,par,world", [("quad", 3, 3, 3), ("quad", 2, 2, 2), ("fh", 3, 3, 8), ("quad", 3, 3, 1)])
+def test_site_kinds_partition_the_tree_under_sample_sharding(lib, variant, n, par, world):
+    """scasml_plan_site_kinds: 1 = u_hat-only site, 0 = Euler-Maruyama site, 2 = owned by another rank; over the
+    ranks every site is owned exactly once and the root row by everyone."""
+    from oracle.mlp import site_count
+    from oracle.tables import approx_parameters
+    plan = tables.build_plan(variant, n, par, 0.5, False)
+    ppr = lib.scasml_points_per_root(C.byref(plan))
+    owners = np.zeros(ppr, dtype=int)
+    base = None
+    for r in range(world):
+        k = np.zeros(ppr, dtype=np.uint8)
+        assert lib.scasml_plan_site_kinds(C.byref(plan), r, world, k.ctypes.data_as(C.c_void_p)) == 0
+        owners += k != 2
+        if world == 1:
+            base = k
+    assert (owners[:-1] == 1).all() and owners[-1] == world
+    if base is not None:
+        tab = approx_parameters(par) if variant == "quad" else None
+        assert ppr == site_count(variant, n, par, tab) + 1 and base[-1] == 1 and set(base) <= {0, 1}
+    assert lib.scasml_plan_site_kinds(C.byref(plan), world, world, np.zeros(ppr, dtype=np.uint8).ctypes.data_as(C.c_void_p)) == -1
