@@ -41,6 +41,10 @@ def parse():
     ap.add_argument("--train-domain", type=int, default=1000)
     ap.add_argument("--train-boundary", type=int, default=200)
     ap.add_argument("--cpu-sample", type=int, default=64, help="roots of the same workload timed on the CPU oracle")
+    ap.add_argument("--shard", choices=["roots", "samples"], default="roots",
+                    help="roots: each rank its own B roots, no collective (weak scaling, default); samples: every rank the same "
+                         "B roots and 1/world of the Monte-Carlo units of the root call, ONE all-reduce of the partial estimators "
+                         "(strong scaling; BASELINE.json north_star)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development only: all ranks share cuda:0 and rendezvous over gloo (a 1-GPU box cannot host RCCL ranks)")
@@ -139,7 +143,7 @@ def main():
         solver = (MLP if args.variant == "quad" else MLP_full_history)(eq, seed=0)
 
     # synthetic inputs: x ~ U[-0.5, 0.5]^d, t ~ U[0, 0.5), resident in HBM before timing
-    g = np.random.default_rng(1234 + rank)
+    g = np.random.default_rng(1234 + (rank if args.shard == "roots" else 0))
     x_t = np.concatenate([g.uniform(-0.5, 0.5, (B, d)), g.uniform(0.0, 0.5, (B, 1))], axis=1).astype(np.float32)
     x_dev = torch.from_numpy(x_t).cuda()
     eng = solver._engine
@@ -147,7 +151,20 @@ def main():
     steps_exec = tables.executed_path_steps(plan)
     steps_ref = tables.reference_path_steps(args.variant, n, par, float(eq.T))
 
+    from scasml_gp_amd import parallel
+
     def one_step():
+        if args.shard == "samples" and world > 1:
+            sid = eng.calls
+            eng.calls += 1
+            out, uhat, _ = eng.solve(n, par, x_dev, rank=rank, world=world, stream_id=sid)
+            if args.rehearse_on_one_gpu:                     # gloo reduces host tensors
+                host = out.cpu()
+                parallel.allreduce_partial_sums(host)
+                out.copy_(host)
+            else:
+                parallel.allreduce_partial_sums(out)         # the single RCCL all-reduce of the path
+            return eng.finalize_partials(out), uhat
         out, uhat, _ = eng.solve(n, par, x_dev, root0=rank * B)
         return out, uhat
 
@@ -245,20 +262,24 @@ def main():
             ("scasml", "fh"): "solvers.ScaSML_full_history n=%d M=%d" % (n, args.M),
             ("mlp", "quad"): "solvers.MLP n=rho=%d" % n,
             ("mlp", "fh"): "solvers.MLP_full_history n=%d M=%d" % (n, args.M)}[(args.solver, args.variant)]
-    value = world * B * steps_exec * args.steps / elapsed
+    work_ranks = world if args.shard == "roots" else 1       # samples: all ranks share the same B roots
+    value = work_ranks * B * steps_exec * args.steps / elapsed
     line = {
         "metric": "Euler-Maruyama path-steps/sec + L2 rel-error, Grad_Dependent_Nonlinear d=%d n=%d" % (d, n),
         "value": round(value, 1), "unit": "path-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak" if args.shard == "roots" else "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "Grad_Dependent_Nonlinear d=%d, %s, B=%d roots/GPU%s" % (
                        d, name, B, " (BASELINE.json configs[2])" if (args.solver, args.variant, d, n) == ("scasml", "quad", 100, 3) else ""),
                    "roots_per_gpu": B, "gp_collocation": ("%d+%d" % (args.train_domain, args.train_boundary)) if gp is not None else None,
                    "path_steps_per_root": steps_exec, "path_steps_per_root_reference_count": steps_ref,
-                   "gp_point_evals_per_root": ppr, "sharding": "roots across ranks, no collective",
+                   "gp_point_evals_per_root": ppr,
+                   "sharding": "roots across ranks, no collective" if args.shard == "roots" else
+                               "Monte-Carlo units of the root call across ranks, one all-reduce of (B, 1+d) partial sums",
                    "note": "value counts only EXECUTED path-steps (the reference's discarded n=0 terminal draws are not "
                            "performed); with the reference's own count the same run is value_reference_count"},
-        "value_reference_count": round(world * B * steps_ref * args.steps / elapsed, 1),
+        "value_reference_count": round(work_ranks * B * steps_ref * args.steps / elapsed, 1),
         "l2_rel_error": {"solver_gpu": round(rel_gpu, 5), "gp_only": round(rel_gp, 5) if rel_gp is not None else None,
                          "points": "1000+200 harness set",
                          "logged_reference_d20": "0.069 (results/.../20d/RepeatedExperiment.log:21)"},
