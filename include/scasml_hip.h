@@ -25,7 +25,7 @@ extern "C" {
 #endif
 
 #define SCASML_ABI_VERSION 1
-#define SCASML_MAX_LEVEL 4   /* Picard level n <= 4 (kernels are instantiated per level)      */
+#define SCASML_MAX_LEVEL 5   /* Picard level n <= 5 (kernels are instantiated per level)      */
 #define SCASML_MAX_Q 6       /* quadrature nodes per rule <= 6 (rho <= 5, solvers/MLP.py:132)  */
 #define SCASML_MAX_DIM 253   /* spatial dimension d <= 253 (one 4-dim quad per lane, +t, +2 spare columns) */
 #define SCASML_GP_TILE 32     /* collocation points per MFMA tile; n_pad is a multiple of it    */

@@ -3,7 +3,7 @@ is missing -- the product has no CPU path."""
 import ctypes as C
 import os
 
-MAX_LEVEL = 4
+MAX_LEVEL = 5
 MAX_Q = 6
 MAX_DIM = 253
 GP_TILE = 32

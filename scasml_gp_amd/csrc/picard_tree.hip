@@ -288,6 +288,7 @@ static int launch_level(const TreeArgs &a, int n, dim3 grid, hipStream_t s) {
         case 2: hipLaunchKernelGGL((picard_tree_kernel<VAR, MODE, 2>), grid, dim3(256), 0, s, a); break;
         case 3: hipLaunchKernelGGL((picard_tree_kernel<VAR, MODE, 3>), grid, dim3(256), 0, s, a); break;
         case 4: hipLaunchKernelGGL((picard_tree_kernel<VAR, MODE, 4>), grid, dim3(256), 0, s, a); break;
+        case 5: hipLaunchKernelGGL((picard_tree_kernel<VAR, MODE, 5>), grid, dim3(256), 0, s, a); break;
         default: return fail(SCASML_ERR_UNSUPPORTED, "picard_tree: level n=%d outside 1..%d", n, SCASML_MAX_LEVEL);
     }
     return check_launch("picard_tree launch");
