@@ -121,10 +121,6 @@ class GP(object):
     def time_der_rep(self, sol, rhs_f):
         raise NotImplementedError
 
-    def _newton_terms(self, sol):
-        """dF/dz1, dF/dz3, dF/dz5 (diagonals) and the z1-z5 cross second derivative of F."""
-        raise NotImplementedError
-
     def _chol_solve_padded(self, Hp, rhs, n, damping):
         """(H + damping*I)^-1 rhs on an identity-padded system (in place Cholesky + two triangular solves); None if not SPD."""
         torch = _lib.require_gpu()
@@ -257,12 +253,6 @@ class GP_Grad_Dependent_Nonlinear(GP):
         N, d, s = self.N_domain, self.d, self.equation.sigma()
         z1, z3, z5 = sol[:N], sol[N:2 * N], sol[2 * N:]
         return -s ** 2 * z1 * z5 + (1 / d + s ** 2 / 2) * z5 - (s ** 2 / 2) * z3 + rhs_f
-
-    def _newton_terms(self, sol):
-        N, d, s = self.N_domain, self.d, self.equation.sigma()
-        z1, z5 = sol[:N], sol[2 * N:]
-        dF = (-s ** 2 * z5, -(s ** 2 / 2) * sol.new_ones(N), -s ** 2 * z1 + (1 / d + s ** 2 / 2))   # cf. :722-743
-        return dF, -s ** 2
 
     def compute_PDE_loss(self, x_t_infer):
         '''dt u + (sigma^2 u - 1/d - sigma^2/2) div u + sigma^2/2 Lap u  (models/GP.py:746-769)'''

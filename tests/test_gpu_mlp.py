@@ -112,3 +112,19 @@ def test_maximum_dimension_and_single_root():
         hip.uz_solve(1, 1, np.zeros((2, 7), dtype=np.float32))
     with pytest.raises(ValueError):                            # level beyond the instantiated kernels
         hip.uz_solve(6, 6, xt)
+
+
+def test_harness_error_band_against_exact_solution():
+    """tests/RepeatedExperiment.py protocol on the HIP path: 1000+200 test points, n = rho = 2.  The plain MLP
+    must land in the band the oracle pins (0.10 .. logged 0.1576: independent draws are no worse than the
+    reference's key-reusing ones) and the deeper level n = rho = 3 must not be worse than n = rho = 2."""
+    from oracle.equation import GradDependentNonlinear, rel_l2
+    from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
+    from scasml_gp_amd.solvers.MLP import MLP
+    eq = Grad_Dependent_Nonlinear(21)
+    np.random.seed(42)
+    xt = np.concatenate(eq.generate_test_data(1000, 200))
+    exact = GradDependentNonlinear(21).exact_solution(xt)
+    e2 = np.mean([rel_l2(MLP(eq, seed=s).u_solve(2, 2, xt), exact) for s in range(3)])
+    e3 = np.mean([rel_l2(MLP(eq, seed=s).u_solve(3, 3, xt), exact) for s in range(3)])
+    assert 0.10 < e2 < 0.1576 and e3 < e2 + 0.01, (e2, e3)
