@@ -193,18 +193,24 @@ int scasml_cholesky(double *A, int64_t M, double nugget, int32_t *info_dev, void
  * float64: the solves of models/GP.py:439, 533, 599. */
 int scasml_trsm_lower(const double *L, int64_t M, double *Bmat, int64_t nrhs, int trans, void *stream);
 
+/* A = (L L^T)^-1 from the lower Cholesky factor L (M x M float64, M a multiple of 32; A is overwritten, any
+ * content): the K_p^-1 that GPsolver's loss, gradient and Hessian need (models/GP.py:439, 599).  Uses the
+ * triangular structure of L^-1 and the symmetry of the result (about a third of two general solves). */
+int scasml_cholesky_inverse(const double *L, int64_t M, double *A, void *stream);
+
 /* Newton iteration on J(sol) = b(sol)^T K_p^-1 b(sol), sol = [z1, z3, z5] (3*n_dom), float64: the pieces of
  * GP.GPsolver's loop (models/GP.py:510-588) that the reference obtains by autodiff of loss_function (:430-444).
  *   scasml_gp_newton_b       b = [z1, g, z3, F(sol), z5]  (4*n_dom + n_bdy), F = time_der_rep (:705-719)
  *   scasml_gemv              y = A x, A row-major M x M with leading dimension lda (A b, and right_vector = A z, :599)
  *   scasml_gp_newton_system  grad (3*n_dom) and the full Hessian, written into an ldh x ldh buffer whose padding
- *                            beyond 3*n_dom is the identity (ldh a multiple of 32: ready for scasml_cholesky) */
+ *                            beyond 3*n_dom is the identity (ldh a multiple of 32: ready for scasml_cholesky);
+ *                            gauss_newton != 0 omits the second-derivative term of F (always positive semidefinite) */
 int scasml_gp_newton_b(int32_t eq_id, int32_t d, double sigma, const double *sol, const double *bdy_g, int32_t n_dom,
                        int32_t n_bdy, double *b, void *stream);
 int scasml_gemv(const double *A, int64_t M, int64_t lda, const double *x, double *y, void *stream);
 int scasml_gp_newton_system(int32_t eq_id, int32_t d, double sigma, const double *A, int64_t lda, int32_t n_dom,
                             int32_t n_bdy, const double *sol, const double *Ab, double *grad, double *H, int64_t ldh,
-                            void *stream);
+                            int gauss_newton, void *stream);
 
 #ifdef __cplusplus
 }

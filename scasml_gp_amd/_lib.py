@@ -66,8 +66,9 @@ SIGNATURES = {
     "scasml_gp_newton_b": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "scasml_gemv": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "scasml_gp_newton_system": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
-                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "scasml_cholesky": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_void_p]),
+    "scasml_cholesky_inverse": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "scasml_trsm_lower": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
 }
 

@@ -176,12 +176,13 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double *A, int64_t M, 
 // ---------------------------------------------------------------------------------- TRSM
 // diagonal-block solve: one thread per right-hand-side column
 template <int TRANS>
-__global__ __launch_bounds__(256) void trsm_diag_kernel(const double *L, int64_t M, double *B, int64_t nrhs, int64_t k0) {
+__global__ __launch_bounds__(256) void trsm_diag_kernel(const double *L, int64_t M, double *B, int64_t nrhs, int64_t k0,
+                                                        int64_t col_limit) {
     __shared__ double Lk[NB][NB + 1];
     for (int idx = threadIdx.x; idx < NB * NB; idx += blockDim.x) Lk[idx / NB][idx % NB] = L[(k0 + idx / NB) * M + k0 + idx % NB];
     __syncthreads();
     const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= nrhs) return;
+    if (col >= col_limit) return;   // col_limit <= nrhs: columns beyond it are known zero / not needed
     double x[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) x[j] = B[(k0 + j) * nrhs + col];
@@ -209,11 +210,13 @@ __global__ __launch_bounds__(256) void trsm_diag_kernel(const double *L, int64_t
 // off-diagonal update with the freshly solved block row X_k (NB x nrhs), 64x64 tile per workgroup:
 //   TRANS == 0:  B[r, :] -= L[r, k0:k0+NB] * X_k          for rows r >= k0 + NB
 //   TRANS == 1:  B[r, :] -= L[k0:k0+NB, r]^T * X_k        for rows r < k0
+// tri != 0: only tiles on or below the block diagonal (c0 < r0 + TB) are updated -- the lower triangle of a symmetric result
 template <int TRANS>
-__global__ __launch_bounds__(256) void trsm_update_kernel(const double *L, int64_t M, double *B, int64_t nrhs, int64_t k0) {
+__global__ __launch_bounds__(256) void trsm_update_kernel(const double *L, int64_t M, double *B, int64_t nrhs, int64_t k0, int tri) {
     __shared__ double Ls[TB][LDP], Xt[TB][LDP];
     const int64_t rbase = TRANS == 0 ? k0 + NB : 0, rend = TRANS == 0 ? M : k0;
     const int64_t r0 = rbase + (int64_t)blockIdx.y * TB, c0 = (int64_t)blockIdx.x * TB;
+    if (tri && c0 >= r0 + TB) return;   // block-uniform
     for (int idx = threadIdx.x; idx < TB * NB; idx += blockDim.x) {
         const int rr = idx / NB, cc = idx % NB;
         Ls[rr][cc] = r0 + rr < rend ? (TRANS == 0 ? L[(r0 + rr) * M + k0 + cc] : L[(k0 + cc) * M + r0 + rr]) : 0.0;
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const double *A, int64_t M, i
 //   H_ij   = 2 (A[r_i,r_j] + dF_i A[r4_i,r_j] + A[r_i,r4_j] dF_j + dF_i A[r4_i,r4_j] dF_j)
 //            + 2 (-s2) Ab[r4_i] on the (z1_i, z5_i) / (z5_i, z1_i) pairs          (second derivative of F).
 __global__ void gp_newton_system_kernel(int d, double s2, const double *A, int64_t lda, int N, int Nb, const double *sol,
-                                        const double *Ab, double *grad, double *H, int64_t ldh) {
+                                        const double *Ab, double *grad, double *H, int64_t ldh, int gauss_newton) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t i = (int64_t)blockIdx.y * blockDim.y + threadIdx.y;
     if (i >= ldh || j >= ldh) return;
@@ -277,7 +280,7 @@ __global__ void gp_newton_system_kernel(int d, double s2, const double *A, int64
     const double dFi = bi == 0 ? -s2 * sol[2 * N + ii] : (bi == 1 ? -0.5 * s2 : -s2 * sol[ii] + c5);
     const double dFj = bj == 0 ? -s2 * sol[2 * N + jj] : (bj == 1 ? -0.5 * s2 : -s2 * sol[jj] + c5);
     double h = 2.0 * (A[ri * lda + rj] + dFi * A[r4i * lda + rj] + A[ri * lda + r4j] * dFj + dFi * A[r4i * lda + r4j] * dFj);
-    if (ii == jj && ((bi == 0 && bj == 2) || (bi == 2 && bj == 0))) h += 2.0 * (-s2) * Ab[r4i];
+    if (!gauss_newton && ii == jj && ((bi == 0 && bj == 2) || (bi == 2 && bj == 0))) h += 2.0 * (-s2) * Ab[r4i];
     H[i * ldh + j] = h;
     if (j == 0) grad[i] = 2.0 * (Ab[ri] + dFi * Ab[r4i]);
 }
@@ -285,6 +288,18 @@ __global__ void gp_newton_system_kernel(int d, double s2, const double *A, int64
 __global__ void add_diag_kernel(double *A, int64_t M, double v) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < M) A[i * M + i] += v;
+}
+
+__global__ void set_identity_kernel(double *A, int64_t M) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t r = blockIdx.y;
+    if (c < M) A[r * M + c] = r == c ? 1.0 : 0.0;
+}
+
+__global__ void mirror_lower_kernel(double *A, int64_t M) {   // A[r][c] = A[c][r] for c > r
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t r = blockIdx.y;
+    if (c < M && c > r) A[r * M + c] = A[c * M + r];
 }
 
 __global__ void zero_upper_kernel(double *A, int64_t M) {
@@ -336,14 +351,14 @@ extern "C" int scasml_trsm_lower(const double *L, int64_t M, double *Bmat, int64
     const int64_t nblk = M / NB;
     if (trans == 0) {
         for (int64_t k = 0; k < nblk; ++k) {
-            hipLaunchKernelGGL(trsm_diag_kernel<0>, dim3(cb), dim3(256), 0, s, L, M, Bmat, nrhs, k * NB);
+            hipLaunchKernelGGL(trsm_diag_kernel<0>, dim3(cb), dim3(256), 0, s, L, M, Bmat, nrhs, k * NB, nrhs);
             if (k + 1 < nblk)
-                hipLaunchKernelGGL(trsm_update_kernel<0>, dim3(ct, (unsigned)(((nblk - k - 1) * NB + TB - 1) / TB)), dim3(256), 0, s, L, M, Bmat, nrhs, k * NB);
+                hipLaunchKernelGGL(trsm_update_kernel<0>, dim3(ct, (unsigned)(((nblk - k - 1) * NB + TB - 1) / TB)), dim3(256), 0, s, L, M, Bmat, nrhs, k * NB, 0);
         }
     } else {
         for (int64_t k = nblk - 1; k >= 0; --k) {
-            hipLaunchKernelGGL(trsm_diag_kernel<1>, dim3(cb), dim3(256), 0, s, L, M, Bmat, nrhs, k * NB);
-            if (k > 0) hipLaunchKernelGGL(trsm_update_kernel<1>, dim3(ct, (unsigned)((k * NB + TB - 1) / TB)), dim3(256), 0, s, L, M, Bmat, nrhs, k * NB);
+            hipLaunchKernelGGL(trsm_diag_kernel<1>, dim3(cb), dim3(256), 0, s, L, M, Bmat, nrhs, k * NB, nrhs);
+            if (k > 0) hipLaunchKernelGGL(trsm_update_kernel<1>, dim3(ct, (unsigned)((k * NB + TB - 1) / TB)), dim3(256), 0, s, L, M, Bmat, nrhs, k * NB, 0);
         }
     }
     return check_launch("trsm launch");
@@ -366,13 +381,42 @@ extern "C" int scasml_gemv(const double *A, int64_t M, int64_t lda, const double
 
 extern "C" int scasml_gp_newton_system(int32_t eq_id, int32_t d, double sigma, const double *A, int64_t lda, int32_t n_dom,
                                        int32_t n_bdy, const double *sol, const double *Ab, double *grad, double *H, int64_t ldh,
-                                       void *stream) {
+                                       int gauss_newton, void *stream) {
     if (eq_id != SCASML_EQ_GRAD_DEPENDENT_NONLINEAR) return fail(SCASML_ERR_UNSUPPORTED, "gp_newton_system: unknown equation id %d", eq_id);
     if (!A || !sol || !Ab || !grad || !H || n_dom < 1 || ldh < 3 * (int64_t)n_dom || lda < 4 * (int64_t)n_dom + n_bdy)
         return fail(SCASML_ERR_ARG, "gp_newton_system: bad argument");
     const unsigned gx = (unsigned)((ldh + 15) / 16);
     if (gx > 65535) return fail(SCASML_ERR_UNSUPPORTED, "gp_newton_system: system too large for this build");
     hipLaunchKernelGGL(gp_newton_system_kernel, dim3(gx, gx), dim3(16, 16), 0, (hipStream_t)stream, d, sigma * sigma, A, lda, n_dom,
-                       n_bdy, sol, Ab, grad, H, ldh);
+                       n_bdy, sol, Ab, grad, H, ldh, gauss_newton);
     return check_launch("gp_newton_system launch");
+}
+
+// K_p^-1 = L^-T L^-1 from the Cholesky factor, exploiting structure: X = L^-1 is lower triangular (forward
+// substitution on the identity touches only columns left of the current block) and the result is symmetric
+// (the backward substitution is carried out for the lower triangle only, then mirrored): about a third of
+// the tile updates of two general triangular solves.
+extern "C" int scasml_cholesky_inverse(const double *L, int64_t M, double *A, void *stream) {
+    if (!L || !A || M < 1) return fail(SCASML_ERR_ARG, "cholesky_inverse: bad argument");
+    if (M % NB) return fail(SCASML_ERR_UNSUPPORTED, "cholesky_inverse: M=%lld is not a multiple of %d", (long long)M, NB);
+    if (M > 65535 * (int64_t)NB) return fail(SCASML_ERR_UNSUPPORTED, "cholesky_inverse: M too large for this build");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t nblk = M / NB;
+    hipLaunchKernelGGL(set_identity_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)M), dim3(256), 0, s, A, M);
+    for (int64_t k = 0; k < nblk; ++k) {                    // X = L^-1: block row k is nonzero in columns < (k+1)*NB
+        const int64_t lim = (k + 1) * NB;
+        hipLaunchKernelGGL(trsm_diag_kernel<0>, dim3((unsigned)((lim + 255) / 256)), dim3(256), 0, s, L, M, A, M, k * NB, lim);
+        if (k + 1 < nblk)
+            hipLaunchKernelGGL(trsm_update_kernel<0>, dim3((unsigned)((lim + TB - 1) / TB), (unsigned)(((nblk - k - 1) * NB + TB - 1) / TB)),
+                               dim3(256), 0, s, L, M, A, M, k * NB, 0);
+    }
+    for (int64_t k = nblk - 1; k >= 0; --k) {               // Z = L^-T X, lower triangle only
+        const int64_t lim = (k + 1) * NB;
+        hipLaunchKernelGGL(trsm_diag_kernel<1>, dim3((unsigned)((lim + 255) / 256)), dim3(256), 0, s, L, M, A, M, k * NB, lim);
+        if (k > 0)
+            hipLaunchKernelGGL(trsm_update_kernel<1>, dim3((unsigned)((k * NB + TB - 1) / TB), (unsigned)((k * NB + TB - 1) / TB)),
+                               dim3(256), 0, s, L, M, A, M, k * NB, 1);
+    }
+    hipLaunchKernelGGL(mirror_lower_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)M), dim3(256), 0, s, A, M);
+    return check_launch("cholesky_inverse launch");
 }

@@ -154,9 +154,8 @@ class GP(object):
         Mp = L.shape[0]
         s = _lib.stream_ptr()
         eq_id, d, sig = int(self.equation.eq_id), int(self.d), float(self.equation.sigma())
-        A = torch.eye(Mp, dtype=torch.float64, device="cuda")          # -> K_p^-1 = L^-T L^-1
-        _lib.check(lib.scasml_trsm_lower(_lib.ptr(L), Mp, _lib.ptr(A), Mp, 0, s), "trsm")
-        _lib.check(lib.scasml_trsm_lower(_lib.ptr(L), Mp, _lib.ptr(A), Mp, 1, s), "trsm^T")
+        A = torch.empty((Mp, Mp), dtype=torch.float64, device="cuda")   # -> K_p^-1 = L^-T L^-1
+        _lib.check(lib.scasml_cholesky_inverse(_lib.ptr(L), Mp, _lib.ptr(A), s), "cholesky_inverse")
         bdy_g = torch.as_tensor(np.asarray(self.bdy_g(self.x_t_boundary), dtype=np.float64), device="cuda").contiguous()
         sol = torch.zeros(3 * N, dtype=torch.float64, device="cuda")
         b = torch.empty(M, dtype=torch.float64, device="cuda")
@@ -174,10 +173,17 @@ class GP(object):
         hist = [residual(sol)]
         for _ in range(GN_steps):                                       # :515-588
             _lib.check(lib.scasml_gp_newton_system(eq_id, d, sig, _lib.ptr(A), Mp, N, Nb, _lib.ptr(sol), _lib.ptr(Ab),
-                                                   _lib.ptr(grad), _lib.ptr(H), npad, s), "gp_newton_system")
+                                                   _lib.ptr(grad), _lib.ptr(H), npad, 0, s), "gp_newton_system")
             if float(torch.linalg.vector_norm(grad)) < 1e-5:            # :521
                 break
             step = self._chol_solve_padded(H, -grad, 3 * N, damping)   # :529-533 (H is overwritten by its factor)
+            if step is None:
+                # the full Hessian (:511) is indefinite at this iterate (large collocation sets): the reference's LU
+                # solve would take the step regardless; use the Gauss-Newton part, which is positive semidefinite
+                self.gauss_newton_steps = getattr(self, "gauss_newton_steps", 0) + 1
+                _lib.check(lib.scasml_gp_newton_system(eq_id, d, sig, _lib.ptr(A), Mp, N, Nb, _lib.ptr(sol), _lib.ptr(Ab),
+                                                       _lib.ptr(grad), _lib.ptr(H), npad, 1, s), "gp_newton_system(GN)")
+                step = self._chol_solve_padded(H, -grad, 3 * N, damping)
             if step is None:
                 raise ValueError("Newton system is not positive definite")
             sol = sol + step                                            # alpha = 1, :541,573

@@ -47,6 +47,10 @@ def test_cholesky_and_trsm_against_numpy():
             Bt = torch.from_numpy(Bm.copy()).cuda()
             _lib.check(lib.scasml_trsm_lower(_lib.ptr(At), M, _lib.ptr(Bt), nrhs, trans, _lib.stream_ptr()), "trsm")
             assert np.abs(Bt.cpu().numpy() - ref).max() < 1e-9
+    Ainv = torch.empty((M, M), dtype=torch.float64, device="cuda")
+    _lib.check(lib.scasml_cholesky_inverse(_lib.ptr(At), M, _lib.ptr(Ainv), _lib.stream_ptr()), "cholesky_inverse")
+    want_inv = np.linalg.inv(A + 0.5 * np.eye(M))
+    assert np.abs(Ainv.cpu().numpy() - want_inv).max() < 1e-11 * np.abs(want_inv).max() * M
     # not positive definite -> info reports the pivot, no exception from the C ABI
     Bad = torch.from_numpy(-np.eye(32)).cuda()
     _lib.check(lib.scasml_cholesky(_lib.ptr(Bad), 32, 0.0, _lib.ptr(info), _lib.stream_ptr()), "chol")
