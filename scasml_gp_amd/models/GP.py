@@ -227,6 +227,31 @@ class GP(object):
         self.right_vector = rv[:, None]
         self._pack(torch.from_numpy(rv).cuda())
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def state_dict(self):
+        '''Everything inference needs, as NumPy arrays: collocation points, right_vector, loss history.'''
+        if self.right_vector is None:
+            raise _lib.ScasmlError("GP is not trained: nothing to save")
+        return {"n_input": np.int64(self.n_input), "x_t_domain": np.asarray(self.x_t_domain),
+                "x_t_boundary": np.asarray(self.x_t_boundary), "right_vector": np.asarray(self.right_vector),
+                "loss_history": np.asarray(getattr(self, "loss_history", []), dtype=np.float64),
+                "nugget": np.float64(self.nugget)}
+
+    def load_state_dict(self, state):
+        if int(state["n_input"]) != self.n_input:
+            raise ValueError("state is for n_input=%d, this GP has n_input=%d" % (int(state["n_input"]), self.n_input))
+        self.nugget = float(state["nugget"])
+        self.loss_history = list(np.asarray(state["loss_history"], dtype=np.float64))
+        self.load_right_vector(state["x_t_domain"], state["x_t_boundary"], state["right_vector"])
+        return self
+
+    def save(self, path):
+        np.savez_compressed(path, **self.state_dict())
+
+    def load(self, path):
+        with np.load(path) as f:
+            return self.load_state_dict({k: f[k] for k in f.files})
+
     # ------------------------------------------------------------------ inference
     def predict(self, x_t_infer):
         '''(n, 1) posterior mean (models/GP.py:653-671).'''

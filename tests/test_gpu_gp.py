@@ -127,3 +127,19 @@ def test_evaluation_arithmetic_modes_agree():
     assert err[3] <= 2 * err[0] + 2e-7, err            # fp32-exact products
     assert err[22] <= 4e-6, err                         # 22-bit products
     assert err[2] <= 1e-4, err
+
+
+def test_state_dict_round_trip(tmp_path):
+    gp, _, dom, bdy = _setup(12, 40, 12, seed=9)
+    gp.GPsolver(dom.astype(np.float16), bdy.astype(np.float16), GN_steps=20)
+    X = np.random.default_rng(1).uniform(-0.5, 0.5, (50, 13)).astype(np.float32)
+    X[:, -1] = np.abs(X[:, -1])
+    want = gp.predict(X)
+    path = str(tmp_path / "gp.npz")
+    gp.save(path)
+    from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
+    from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
+    fresh = GP_Grad_Dependent_Nonlinear(Grad_Dependent_Nonlinear(13)).load(path)
+    assert np.array_equal(fresh.predict(X), want) and fresh._colloc_is_f16 and fresh.loss_history == gp.loss_history
+    with pytest.raises(ValueError):
+        GP_Grad_Dependent_Nonlinear(Grad_Dependent_Nonlinear(14)).load(path)
