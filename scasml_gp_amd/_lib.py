@@ -43,7 +43,8 @@ class GpModel(C.Structure):
 
 _STRUCTS = (Problem, Rng, Term, Plan, GpModel)
 _LIB = None
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libscasml_hip.so")
+# SCASML_HIP_LIB: another build of the same library (development: ablation builds of one kernel)
+LIB_PATH = os.environ.get("SCASML_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libscasml_hip.so")
 
 # name -> (restype, argtypes); every symbol include/scasml_hip.h declares
 SIGNATURES = {
@@ -56,6 +57,8 @@ SIGNATURES = {
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "scasml_clip": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
     "scasml_debug_normals": (C.c_int, [Rng, C.c_uint32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
+    "scasml_gp_plane_halfwords": (C.c_int64, [C.c_int32, C.c_int32]),
+    "scasml_gp_coef_floats": (C.c_int64, [C.c_int32]),
     "scasml_gp_pack": (C.c_int, [C.c_int32, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "scasml_gp_eval": (C.c_int, [C.POINTER(GpModel), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),

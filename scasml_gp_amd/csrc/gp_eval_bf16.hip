@@ -138,11 +138,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
 
     // Monte-Carlo sample sharding: a workgroup whose rows all belong to sites this rank does not own has
     // nothing to do (block-uniform, so the barriers below stay consistent)
-    if (g.site_u_only && g.rows_per_site >= 32) {
-        const int64_t b0 = (int64_t)blockIdx.x * WPB * 32;
-        const int64_t b1 = b0 + WPB * 32 - 1 < g.n_inf ? b0 + WPB * 32 - 1 : g.n_inf - 1;
-        if (b0 < g.n_inf && g.site_u_only[b0 / g.rows_per_site] == 2 && g.site_u_only[b1 / g.rows_per_site] == 2) return;
-    }
+    if (g.site_u_only && g.rows_per_site >= 32 && gp_block_unowned(g, (int64_t)blockIdx.x * WPB * 32, WPB * 32)) return;
     // stage one collocation tile: NCHUNK 1-KiB chunks (A fragments (plane, step), then the two coefficient KiB).
     // Every wave issues exactly CPW global_load_lds per tile (surplus slots repeat the last chunk: same bytes
     // to the same place), so a counted s_waitcnt vmcnt(CPW) means "everything but the newest tile has landed".

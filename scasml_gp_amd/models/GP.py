@@ -203,8 +203,8 @@ class GP(object):
         self._n_pad = _round_up(self.N_domain + self.N_boundary, _lib.GP_TILE)
         self._colloc = torch.empty((self._n_pad, kp), dtype=torch.float32, device="cuda")
         self._frag = torch.empty((self._n_pad * kp,), dtype=torch.float32, device="cuda")
-        self._bf16 = torch.empty((5 * self._n_pad * kp,), dtype=torch.int16, device="cuda")
-        self._coef = torch.empty((self._n_pad, 16), dtype=torch.float32, device="cuda")
+        self._bf16 = torch.empty((int(lib.scasml_gp_plane_halfwords(self.d, self._n_pad)),), dtype=torch.int16, device="cuda")
+        self._coef = torch.empty((int(lib.scasml_gp_coef_floats(self._n_pad)),), dtype=torch.float32, device="cuda")
         rv = rv.contiguous()
         # collocation points that are exactly fp16 (the reference's deepxde float16 arrays are) need one plane
         self._colloc_is_f16 = bool((self._xd.half().float() == self._xd).all()) and bool((self._xb.half().float() == self._xb).all())

@@ -125,12 +125,14 @@ def test_large_dimension_scasml(d):
     assert np.all(np.abs(got - want) <= ATOL + RTOL * np.abs(want)), np.abs(got - want).max()
 
 
-def test_sample_sharded_scasml_partials():
+@pytest.mark.parametrize("B", [24, 48, 300])
+def test_sample_sharded_scasml_partials(B):
     """Monte-Carlo sample sharding of the ScaSML root call: the partial sums of world = 2 add up to the
-    unsharded result (un-owned rows of the point buffer are zero and their GP values unused)."""
+    unsharded result (un-owned rows of the point buffer are zero and their GP values unused).  B = 48: a
+    workgroup of the GP evaluation spans several tree sites whose ownership alternates."""
     import torch
     hip, ora, _ = _setup(20, 60, 20, "quad", seed=6)
-    xt = _test_points(20, 24, 37)
+    xt = _test_points(20, B, 37)
     eng = hip._engine
     full, _, _ = eng.solve(3, 3, xt, stream_id=0)
     parts = [eng.solve(3, 3, xt, rank=r, world=2, stream_id=0)[0] for r in range(2)]

@@ -1,0 +1,13 @@
+#!/usr/bin/env python
+"""Development: VGPR count and scratch bytes of every kernel in one csrc/*.hip (device-only compile to ISA text).
+    python tools/kernel_regs.py gp_eval_f16.hip [-DSCASML_GP_ABLATE=1]     (also leaves /tmp/<name>.s for reading)"""
+import os, re, subprocess, sys
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "scasml_gp_amd", "csrc", sys.argv[1])
+out = "/tmp/" + sys.argv[1].replace(".hip", ".s")
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-w", "-S",
+                "--cuda-device-only", "-I" + os.path.join(root, "include"), "-o", out, src] + sys.argv[2:], check=True)
+t = open(out).read()
+for m in re.finditer(r'\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)', t):
+    name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
+    print("%-90s scratch %4s  vgpr %3s" % (name[:90], m.group(2), m.group(3)))

@@ -12,8 +12,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 template <int MODE>
-__global__ __launch_bounds__(768) void k(float *out, int iters, float a, float b) {
+__global__ __launch_bounds__(768) void k(float *out, int iters, float a, float b, unsigned long long *clk = nullptr) {
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
     f32x16 acc0 = {0}, acc1 = {0};
     float v[32];
 #pragma unroll
@@ -68,8 +69,14 @@ __global__ __launch_bounds__(768) void k(float *out, int iters, float a, float b
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += acc0[i] + acc1[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) {   // shader-clock cycles (s_memtime) and 100 MHz wall ticks of this wave
+        clk[0] = __builtin_readcyclecounter() - c0;
+        clk[1] = wall_clock64() - w0;
+    }
 }
 
+static unsigned long long *g_clk;
+static char g_note[96];
 template <int MODE>
 float run(float *out, int threads, int iters) {
     hipEvent_t e0, e1;
@@ -77,11 +84,15 @@ float run(float *out, int threads, int iters) {
     hipEventCreate(&e1);
     hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(threads), 0, 0, out, 100, 1.0001f, 1e-6f);
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(threads), 0, 0, out, iters, 1.0001f, 1e-6f);
+    hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(threads), 0, 0, out, iters, 1.0001f, 1e-6f, g_clk);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long h[2];
+    hipMemcpy(h, g_clk, sizeof h, hipMemcpyDeviceToHost);
+    snprintf(g_note, sizeof g_note, "[%.1f memtime ticks/iter, memtime %.0f MHz]", (double)h[0] / iters, h[0] / (h[1] / 100.0));
+    fprintf(stderr, "      mode %d x %d threads: %s\n", MODE, threads, g_note);
     return ms;
 }
 
@@ -127,6 +138,7 @@ float runv(float *out, int threads, int iters) {
 int main() {
     float *out;
     hipMalloc(&out, 256 * 1024 * 4);
+    hipMalloc(&g_clk, 16);
     const int it = 200000;
     printf("one wave per SIMD (256 threads/block, 1 block/CU)\n");
     printf("  0 mfma_f32 only      : %.3f ms\n", run<0>(out, 256, it));
