@@ -135,12 +135,11 @@ typedef struct {
     float sigma_eq;              /* equation sigma (models/GP.py:748)                        */
     const float *colloc;         /* n_pad x kp   collocation points, domain first, zero pad  */
     const float *colloc_frag;    /* the same, in fp32 MFMA A-fragment order [tile][kp/8][64][4] */
-    const uint16_t *colloc_bf16; /* scasml_gp_plane_halfwords(): 3 truncated-bf16 planes [tile][plane][kp/16][64][8], 2 fp16 planes in
-                                    the same order, then the 2 fp16 planes in 16x16x32 order [tile][plane][2][ceil(kp/32)][64][8] */
+    const uint16_t *colloc_bf16; /* scasml_gp_plane_halfwords(): 3 truncated-bf16 planes [tile][plane][kp/16][64][8], then 2 fp16
+                                    planes in the same order */
     int32_t colloc_is_f16;       /* 1 if every collocation coordinate is exactly representable in fp16 (the reference's
                                     deepxde float16 points are): split = 22 then needs 2 instead of 3 MFMAs per K-step */
-    const float *coef;           /* scasml_gp_coef_floats(): n_pad x 16 per-row constants (a*sum y, a*t_y, c0, cL, ct, cS, a*ct, ...),
-                                    then the first 12 of them column-major per 32-row tile ([tile][3][32][4] + pad to 512) */
+    const float *coef;           /* scasml_gp_coef_floats(): n_pad x 16 per-row constants (a*sum y, a*t_y, c0, cL, ct, cS, a*ct, ...) */
 } scasml_gp_model;
 
 /* Build `coef` and the padded `colloc` from points and right_vector (models/GP.py:599-600):
@@ -151,8 +150,7 @@ int scasml_gp_pack(int32_t d, float a, const float *x_dom, int32_t n_dom, const 
                    uint16_t *colloc_bf16_out /* scasml_gp_plane_halfwords(d, n_pad) */,
                    float *coef_out /* scasml_gp_coef_floats(n_pad) */, void *stream);
 /* Sizes of the two packed buffers above (n_pad = n_dom + n_bdy rounded up to SCASML_GP_TILE): the 16-bit operand planes
- * in MFMA fragment order (3 bf16 + 2 fp16 planes for the 32x32x16 kernels, 2 fp16 planes for the 16x16x32 kernel) and the
- * per-collocation constants (row-major and column-major copies). */
+ * in MFMA fragment order (3 bf16 + 2 fp16 planes) and the per-collocation constants. */
 int64_t scasml_gp_plane_halfwords(int32_t d, int32_t n_pad);
 int64_t scasml_gp_coef_floats(int32_t n_pad);
 

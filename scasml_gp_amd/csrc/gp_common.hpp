@@ -12,9 +12,7 @@ struct GpArgs {
     const float *colloc_frag;  // [n_tiles][NK4][64][4]
     const uint16_t *colloc_bf16;  // [n_tiles][3 planes][kp/16][64][8] truncated-bf16 planes
     const uint16_t *colloc_f16;   // [n_tiles][2 planes][kp/16][64][8] fp16 planes (h, 2^11 * l)
-    const uint16_t *colloc_f16t;  // [n_tiles][2 planes][2 subtiles][ceil(kp/32)][64][8] fp16 planes, 16x16x32 B-fragment order
     const float *coef;         // [n_pad][16]
-    const float *coef_t;       // [n_tiles][512]: [3 groups][32 columns][4] per-collocation constants + pad (gp_eval_f16.hip)
     float4 *out4;              // n_inf x (u, div, eps, dt)
     float *lap;                // n_inf or null
     int64_t n_inf;
@@ -131,7 +129,5 @@ __device__ __forceinline__ bool gp_block_unowned(const GpArgs &g, int64_t b0, in
 }
 
 int launch_gp_eval_bf16(const GpArgs &g, int split, hipStream_t s);   // gp_eval_bf16.hip
-int launch_gp_eval_f16(const GpArgs &g, hipStream_t s);               // gp_eval_f16.hip
-bool gp_eval_f16_supports(const GpArgs &g);
 
 }  // namespace scasml

@@ -289,13 +289,6 @@ __global__ void gp_pack_kernel(int d, float a, const float *x_dom, int n_dom, co
         const _Float16 fl = k <= d ? (_Float16)((vg - (float)fh) * 2048.0f) : (_Float16)0.0f;
         hf[((int64_t)tile * 2 + 0) * ks * 512 + e] = __builtin_bit_cast(unsigned short, fh);
         hf[((int64_t)tile * 2 + 1) * ks * 512 + e] = __builtin_bit_cast(unsigned short, fl);
-        // the same two planes in v_mfma_f32_16x16x32_f16 B-fragment order (gp_eval_f16.hip): [tile][plane][sub = i/16]
-        // [step = k/32][lane = ((k%32)/8)*16 + i%16][k%8]; K is padded with zeros to a multiple of 32 below
-        uint16_t *ht = hf + (int64_t)2 * n_pad * kp;
-        const int ks4 = (kp + 31) / 32;
-        const int64_t et = ((int64_t)(k / 32) * 64 + ((k % 32) / 8) * 16 + (i % 16)) * 8 + (k & 7);
-        ht[(((int64_t)tile * 2 + 0) * 2 + i / 16) * ks4 * 512 + et] = __builtin_bit_cast(unsigned short, fh);
-        ht[(((int64_t)tile * 2 + 1) * 2 + i / 16) * ks4 * 512 + et] = __builtin_bit_cast(unsigned short, fl);
         ny = fmaf(v, v, ny);
         if (k < d) sy += v;
         if (k == d) ty = v;
@@ -325,19 +318,6 @@ __global__ void gp_pack_kernel(int d, float a, const float *x_dom, int n_dom, co
     cf[11] = -2.0f * a * a * fd * cL;
     cf[12] = ny;
     cf[13] = cf[14] = cf[15] = 0.0f;
-    // column-major copy for the collocation-per-lane kernel: [tile][3 groups][32 columns][4], 512 floats per tile
-    float *ct4 = coef + (int64_t)n_pad * kCoefRow + (int64_t)tile * 512 + i * 4;
-    for (int q = 0; q < 4; ++q)
-        for (int e = 0; e < 4; ++e) ct4[q * 128 + e] = q < 3 ? cf[4 * q + e] : 0.0f;
-    {   // zero K padding of the 16x16x32 planes
-        uint16_t *ht = bf + (int64_t)5 * n_pad * kp;
-        const int ks4 = (kp + 31) / 32;
-        for (int k = kp; k < 32 * ks4; ++k) {
-            const int64_t et = ((int64_t)(k / 32) * 64 + ((k % 32) / 8) * 16 + (i % 16)) * 8 + (k & 7);
-            ht[(((int64_t)tile * 2 + 0) * 2 + i / 16) * ks4 * 512 + et] = 0;
-            ht[(((int64_t)tile * 2 + 1) * 2 + i / 16) * ks4 * 512 + et] = 0;
-        }
-    }
 }
 
 template <int NK4>
@@ -372,10 +352,10 @@ using namespace scasml;
 
 extern "C" int64_t scasml_gp_plane_halfwords(int32_t d, int32_t n_pad) {
     const int64_t kp = scasml_point_stride(d);
-    return (int64_t)n_pad * (5 * kp + 2 * ((kp + 31) / 32 * 32));
+    return (int64_t)n_pad * 5 * kp;
 }
 
-extern "C" int64_t scasml_gp_coef_floats(int32_t n_pad) { return (int64_t)n_pad * 2 * kCoefRow; }
+extern "C" int64_t scasml_gp_coef_floats(int32_t n_pad) { return (int64_t)n_pad * kCoefRow; }
 
 extern "C" int scasml_gp_pack(int32_t d, float a, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy,
                               const double *rv, float *colloc_out, float *colloc_frag_out, uint16_t *colloc_bf16_out,
@@ -400,8 +380,6 @@ static int gp_eval_impl(const scasml_gp_model *m, const float *points, int64_t n
     g.colloc_frag = m->colloc_frag;
     g.colloc_bf16 = m->colloc_bf16;
     g.colloc_f16 = m->colloc_bf16 ? m->colloc_bf16 + (int64_t)3 * m->n_pad * m->kp : nullptr;
-    g.colloc_f16t = m->colloc_bf16 ? m->colloc_bf16 + (int64_t)5 * m->n_pad * m->kp : nullptr;
-    g.coef_t = m->coef + (int64_t)m->n_pad * kCoefRow;
     g.colloc_is_f16 = m->colloc_is_f16;
     g.site_u_only = site_u_only;
     g.rows_per_site = rows_per_site;
@@ -419,8 +397,6 @@ static int gp_eval_impl(const scasml_gp_model *m, const float *points, int64_t n
     hipStream_t s = (hipStream_t)stream;
     if (m->split == 2 || m->split == 3 || m->split == 22) {
         if (!m->colloc_bf16) return fail(SCASML_ERR_ARG, "gp_eval: split=%d needs colloc_bf16", m->split);
-        static const bool old32 = getenv("SCASML_GP_OLD32") != nullptr;   // development A/B switch
-        if (m->split == 22 && !old32 && gp_eval_f16_supports(g)) return launch_gp_eval_f16(g, s);
         return launch_gp_eval_bf16(g, m->split, s);
     }
     if (m->split != 0) return fail(SCASML_ERR_ARG, "gp_eval: split must be 0, 2, 3 or 22");
