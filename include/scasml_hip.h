@@ -27,7 +27,7 @@ extern "C" {
 #define SCASML_ABI_VERSION 1
 #define SCASML_MAX_LEVEL 5   /* Picard level n <= 5 (kernels are instantiated per level)      */
 #define SCASML_MAX_Q 6       /* quadrature nodes per rule <= 6 (rho <= 5, solvers/MLP.py:132)  */
-#define SCASML_MAX_DIM 253   /* spatial dimension d <= 253 (one 4-dim quad per lane, +t, +2 spare columns) */
+#define SCASML_MAX_DIM 252   /* spatial dimension d <= 252 (one 4-dim quad per lane, +t, +3 spare columns) */
 #define SCASML_GP_TILE 32     /* collocation points per MFMA tile; n_pad is a multiple of it    */
 
 enum { SCASML_ERR_ARG = -1, SCASML_ERR_UNSUPPORTED = -2, SCASML_ERR_HIP = -3 };
@@ -90,8 +90,8 @@ size_t scasml_sizeof(int which);
 
 /* Rows of the point buffer / GP-value buffer per root: sites[n] + 1 (the root itself last). */
 int64_t scasml_points_per_root(const scasml_plan *plan_h);
-/* Padded row length (floats) of a point row: round_up(d + 3, 16): X, t, two spare columns the GP
- * evaluation uses for folded constants, zero pad to a whole 16-bit MFMA K-step. */
+/* Padded row length (floats) of a point row: round_up(d + 4, 16): X, t, three spare columns the GP
+ * evaluation uses for folded constants (d+1, d+2 and the last one), zero pad to a whole 16-bit MFMA K-step. */
 int32_t scasml_point_stride(int32_t d);
 
 /*
@@ -128,7 +128,7 @@ typedef struct {
     int32_t d;
     int32_t n_dom, n_bdy;        /* N_Omega, N_dOmega                                        */
     int32_t n_pad;               /* (n_dom + n_bdy) rounded up to 32                         */
-    int32_t kp;                  /* point stride = round_up(d+3, 16)                         */
+    int32_t kp;                  /* point stride = round_up(d+4, 16)                         */
     int32_t split;               /* x.y arithmetic: 0 = fp32 MFMA; 3 / 2 = bf16 MFMA on 3 (fp32-exact) / 2 bf16 planes;
                                     22 = fp16 MFMA on two fp16 planes (22-bit products, 3 MFMAs per K-step) */
     float a;                     /* 1/sigma_k^2, sigma_k = 0.25*sqrt(d) (models/GP.py:25)    */
@@ -139,7 +139,8 @@ typedef struct {
                                     planes in the same order */
     int32_t colloc_is_f16;       /* 1 if every collocation coordinate is exactly representable in fp16 (the reference's
                                     deepxde float16 points are): split = 22 then needs 2 instead of 3 MFMAs per K-step */
-    const float *coef;           /* scasml_gp_coef_floats(): n_pad x 16 per-row constants (a*sum y, a*t_y, c0, cL, ct, cS, a*ct, ...) */
+    const float *coef;           /* scasml_gp_coef_floats(): n_pad x 16 per-row constants (a*sum y, a*t_y, c0, cL, ct, cS, ..., |y|^2) for
+                                    the FP32 kernel, then n_pad x 16 in the exponent-scaled form of the 16-bit kernels */
 } scasml_gp_model;
 
 /* Build `coef` and the padded `colloc` from points and right_vector (models/GP.py:599-600):

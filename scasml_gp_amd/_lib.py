@@ -5,7 +5,7 @@ import os
 
 MAX_LEVEL = 5
 MAX_Q = 6
-MAX_DIM = 253
+MAX_DIM = 252
 GP_TILE = 32
 ABI_VERSION = 1
 

@@ -12,7 +12,9 @@ struct GpArgs {
     const float *colloc_frag;  // [n_tiles][NK4][64][4]
     const uint16_t *colloc_bf16;  // [n_tiles][3 planes][kp/16][64][8] truncated-bf16 planes
     const uint16_t *colloc_f16;   // [n_tiles][2 planes][kp/16][64][8] fp16 planes (h, 2^11 * l)
-    const float *coef;         // [n_pad][16]
+    const float *coef;         // [n_pad][16]  FP32-kernel constants
+    const float *coef2;        // [n_pad][16]  exponent-scaled constants of the 16-bit kernels (gp_epilogue_scaled)
+    int32_t first_bdy_tile;    // collocation tiles from here on hold boundary (and padding) rows only: cL = ct = cS = 0
     float4 *out4;              // n_inf x (u, div, eps, dt)
     float *lap;                // n_inf or null
     int64_t n_inf;
@@ -21,7 +23,7 @@ struct GpArgs {
     int32_t colloc_is_f16;
     const uint8_t *site_u_only;   // per tree site: only u_hat needed (null = every row needs everything)
     int64_t rows_per_site;
-    int32_t dbg;   // ablation switches (SCASML_GP_DBG, development only): 1 skip MFMA, 2 skip epilogue, 4 no stagger, 8 stage once
+    int32_t dbg;   // ablation switches (SCASML_GP_DBG, development only): 1 skip MFMA, 2 skip epilogue, 8 stage once
 };
 
 struct GpStageView {
@@ -31,32 +33,75 @@ struct GpStageView {
 
 struct GpConsts {
     float a, a2, ad, kexp, dF;
-    float k1, k2;   // folded form: kappa = exp2(k1 * L0 + k2), L0 = a^2 r2 - a d
 };
 
-// C row = (r&3) + 8*(r>>2) + 4*half, column = lane & 31.  Coefficients of a collocation row are 8
-// consecutive floats (|y|^2, a*sum y, a*t_y, c0, cL, ct, cS, 0): two broadcast ds_read_b128 per row.
-// Per collocation row the coefficient tile holds 16 floats (gp_pack_kernel):
-//   0 a*sum y   1 a*t_y   2 c0   3 cL  |  4 ct   5 cS   6 a*ct   7 2a*cL  |  8 a*d*cS   9 -4a*cL  10 -2a*cS
-//   11 -2a^2*d*cL  |  12 |y|^2   13..15 0
-// so the folded kernel consumes exactly three full ds_read_b128 per row (every component used: the
-// compiler otherwise narrows the reads to ds_read2_b32 whose 8-bit offsets need an address add each).
+// ---------------------------------------------------------------------------------------------------------------
+// FP32 kernel (gp_eval.hip): C row = (r&3) + 8*(r>>2) + 4*half, column = lane & 31.  Per collocation row the
+// coefficient tile holds 16 floats (gp_pack_kernel, `coef`):
+//   0 a*sum y   1 a*t_y   2 c0   3 cL  |  4 ct   5 cS   6..11 unused here  |  12 |y|^2
 constexpr int kCoefRow = 16;
 
-// FOLD: the MFMA already delivered  a^2 (|y|^2 - 2 x.y)  (the collocation planes hold -2 a^2 y and an
-// extra K column a^2 |y|^2 against a constant 1 in the point row), and nx[] holds a^2 |x|^2 - a d, so
-// L0 = acc + nx = a^2 r2 - a d costs one add and kappa one fma + exp2; every row constant that would
-// cost a multiply per element is precomputed.  19 VALU per (collocation, point) pair.
-template <int PT, bool FOLD = false, bool PF = true, bool UONLY = false>
+template <int PT>
 __device__ __forceinline__ void gp_epilogue_tile(const GpStageView &st, const f32x16 (&acc)[PT], const GpConsts &c, int half,
                                                  const float (&nx)[PT], const float (&sx)[PT], const float (&tx)[PT],
                                                  float (&au)[PT], float (&at)[PT], float (&ad)[PT], float (&al)[PT]) {
+    const float4 *cb = reinterpret_cast<const float4 *>(__builtin_assume_aligned(st.coef + 4 * kCoefRow * half, 16));
+    float4 q[2][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[0][i] = cb[i];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int cur = r & 1, nxt = cur ^ 1;
+        if (r + 1 < 16) {
+            const int off = (((r + 1) & 3) + 8 * ((r + 1) >> 2)) * (kCoefRow / 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q[nxt][i] = cb[off + i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float vsy = q[cur][0].x, vty = q[cur][0].y, vc0 = q[cur][0].z, vcL = q[cur][0].w;
+        const float vct = q[cur][1].x, vcS = q[cur][1].y;
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            const float pp = tx[p] - vty;                  // a * r_t
+            const float ss = sx[p] - vsy;                  // a * S
+            const float vny = q[cur][3].x;
+            const float r2 = fmaf(-2.0f, acc[p][r], nx[p] + vny);
+            const float kap = __builtin_amdgcn_exp2f(r2 * c.kexp);
+            const float L = fmaf(-pp, pp, fmaf(c.a2, r2, -c.ad));  // a^2 (r2 - r_t^2) - a d
+            const float E = fmaf(vcS, ss, fmaf(vct, pp, fmaf(vcL, L, vc0)));
+            au[p] = fmaf(kap, E, au[p]);
+            at[p] = fmaf(kap, fmaf(-pp, E, c.a * vct), at[p]);
+            const float dv = fmaf(2.0f * vcL, ss, c.dF * vcS);
+            ad[p] = fmaf(kap, fmaf(-ss, E, c.a * dv), ad[p]);
+            const float lv = fmaf(vcL, fmaf(2.0f, L, c.ad), vcS * ss);
+            al[p] = fmaf(kap, fmaf(L, E, -2.0f * c.a * lv), al[p]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 16-bit kernels (gp_eval_bf16.hip): everything is carried in the units of the exponent, so that the matrix
+// product IS the exponent.  With q = log2(e) / (2a), k1 = -q:
+//   the MFMA delivers  Lam = k1 a^2 |x - y|^2  (space and time; the operand planes hold 2 a^2 q x.y, k1 a^2 |y|^2
+//   against a constant 1, and k1 a^2 |x|^2 in the last K column against a constant 1),  kappa = exp2(Lam);
+//   pp = sqrt(q) a (t_x - t_y),  Lh = Lam + pp^2 = k1 (L + a d)  with L = a^2 |x - y|_space^2 - a d,  ss = a (S_x - S_y);
+//   E = c0 + cL L + ct a r_t + cS ss = e0 + eL Lh + et pp + cS ss.
+// Per collocation row `coef2` holds (gp_pack_kernel):
+//   0 a*sum y   1 sqrt(q) a t_y   2 e0 = c0 - a d cL   3 eL = cL / k1  |  4 et = ct / sqrt(q)   5 cS   6 sqrt(q) a ct
+//   7 2 a cL  |  8 a d cS   9 -4 a cL   10 -2 a k1 cS   11 2 a^2 d k1 cL  |  12..15 0
+// and the sums are  u = sum kappa E,  dt = (1/sqrt(q)) sum kappa (q6 - pp E),  div = sum kappa (-ss E + q7 ss + q8),
+// lap = (1/k1) sum kappa (Lh (E + q9) + q10 ss + q11) - a d u   (the rescalings happen once per point, after the
+// sweep).  17 VALU + 1 exp per (collocation, point) pair.  KIND selects what a wave needs:
+//   0 all four sums;  1 u only (terminal-time points and the root: 7 VALU + exp);
+//   2 / 3 the same on tiles of boundary rows (cL = ct = cS = 0, E = c0): 8 VALU + exp / 1 VALU + exp.
+template <int KIND, bool PF>
+__device__ __forceinline__ void gp_epilogue_scaled(const GpStageView &st, const f32x16 &acc, int half, float sx, float tx,
+                                                   float &au, float &at, float &ad, float &al) {
     // C row = (r&3) + 8*(r>>2) + 4*half: one per-lane base (depends on the half-wave), compile-time row offsets
     const float4 *cb = reinterpret_cast<const float4 *>(__builtin_assume_aligned(st.coef + 4 * kCoefRow * half, 16));
-    constexpr int NQ = UONLY ? 2 : (FOLD ? 3 : 4);       // float4 reads per row (u_hat alone needs sy, ty, c0, cL, ct, cS)
-    // PF: rows ping-pong between two register sets (the reads of row r+1 are issued before row r is
-    // consumed); without PF one set is used and the other resident waves cover the LDS latency.  One
-    // row (PT independent chains) per scheduling region keeps the VGPR budget flat.
+    constexpr int NQ = KIND == 0 ? 3 : (KIND == 1 ? 2 : 1);       // float4 reads per row
+    // PF: rows ping-pong between two register sets (the reads of row r+1 are issued before row r is consumed);
+    // one row per scheduling region keeps the VGPR budget flat
     float4 q[PF ? 2 : 1][NQ];
     if constexpr (PF) {
 #pragma unroll
@@ -77,41 +122,32 @@ __device__ __forceinline__ void gp_epilogue_tile(const GpStageView &st, const f3
             for (int i = 0; i < NQ; ++i) q[0][i] = cb[off + i];
         }
         __builtin_amdgcn_sched_barrier(0);
-        const float vsy = q[cur][0].x, vty = q[cur][0].y, vc0 = q[cur][0].z, vcL = q[cur][0].w;
-        const float vct = q[cur][1].x, vcS = q[cur][1].y;
-#pragma unroll
-        for (int p = 0; p < PT; ++p) {
-            const float pp = tx[p] - vty;                  // a * r_t
-            const float ss = sx[p] - vsy;                  // a * S
-            if constexpr (UONLY) {                           // terminal-time points and the root: u_hat only, 10 VALU
-                static_assert(FOLD, "u-only epilogue is written for the folded form");
-                const float L0 = acc[p][r] + nx[p];
-                const float kap = __builtin_amdgcn_exp2f(fmaf(L0, c.k1, c.k2));
-                const float L = fmaf(-pp, pp, L0);
-                au[p] = fmaf(kap, fmaf(vcS, ss, fmaf(vct, pp, fmaf(vcL, L, vc0))), au[p]);
-            } else if constexpr (FOLD) {
-                const float act = q[cur][1].z, c2 = q[cur][1].w;
-                const float c3 = q[cur][2].x, c4 = q[cur][2].y, c5 = q[cur][2].z, c6 = q[cur][2].w;
-                const float L0 = acc[p][r] + nx[p];        // a^2 r2 - a d
-                const float kap = __builtin_amdgcn_exp2f(fmaf(L0, c.k1, c.k2));
-                const float L = fmaf(-pp, pp, L0);
-                const float E = fmaf(vcS, ss, fmaf(vct, pp, fmaf(vcL, L, vc0)));
-                au[p] = fmaf(kap, E, au[p]);
-                at[p] = fmaf(kap, fmaf(-pp, E, act), at[p]);
-                ad[p] = fmaf(kap, fmaf(-ss, E, fmaf(c2, ss, c3)), ad[p]);
-                al[p] = fmaf(kap, fmaf(L, E, fmaf(c4, L, fmaf(c5, ss, c6))), al[p]);
+        const float lam = acc[r];
+        const float kap = __builtin_amdgcn_exp2f(lam);
+        const float vsy = q[cur][0].x, vty = q[cur][0].y, ve0 = q[cur][0].z, veL = q[cur][0].w;
+        if constexpr (KIND == 3) {
+            au = fmaf(kap, ve0, au);
+        } else {
+            const float pp = tx - vty;
+            const float ss = sx - vsy;
+            const float Lh = fmaf(pp, pp, lam);
+            if constexpr (KIND == 2) {
+                const float w = kap * ve0;
+                au = fmaf(kap, ve0, au);        // the same rounding as KIND 3: u_hat must not depend on which sums a wave needs
+                at = fmaf(-pp, w, at);
+                ad = fmaf(-ss, w, ad);
+                al = fmaf(Lh, w, al);
             } else {
-                const float vny = q[cur][NQ - 1].x;
-                const float r2 = fmaf(-2.0f, acc[p][r], nx[p] + vny);
-                const float kap = __builtin_amdgcn_exp2f(r2 * c.kexp);
-                const float L = fmaf(-pp, pp, fmaf(c.a2, r2, -c.ad));  // a^2 (r2 - r_t^2) - a d
-                const float E = fmaf(vcS, ss, fmaf(vct, pp, fmaf(vcL, L, vc0)));
-                au[p] = fmaf(kap, E, au[p]);
-                at[p] = fmaf(kap, fmaf(-pp, E, c.a * vct), at[p]);
-                const float dv = fmaf(2.0f * vcL, ss, c.dF * vcS);
-                ad[p] = fmaf(kap, fmaf(-ss, E, c.a * dv), ad[p]);
-                const float lv = fmaf(vcL, fmaf(2.0f, L, c.ad), vcS * ss);
-                al[p] = fmaf(kap, fmaf(L, E, -2.0f * c.a * lv), al[p]);
+                const float vet = q[cur][1].x, vcS = q[cur][1].y;
+                const float E = fmaf(vcS, ss, fmaf(vet, pp, fmaf(veL, Lh, ve0)));
+                au = fmaf(kap, E, au);
+                if constexpr (KIND == 0) {
+                    const float act = q[cur][1].z, c2 = q[cur][1].w;
+                    const float c3 = q[cur][2].x, c4 = q[cur][2].y, c5 = q[cur][2].z, c6 = q[cur][2].w;
+                    at = fmaf(kap, fmaf(-pp, E, act), at);
+                    ad = fmaf(kap, fmaf(-ss, E, fmaf(c2, ss, c3)), ad);
+                    al = fmaf(kap, fmaf(Lh, E + c4, fmaf(c5, ss, c6)), al);
+                }
             }
         }
     }

@@ -262,11 +262,15 @@ __global__ void gp_pack_kernel(int d, float a, const float *x_dom, int n_dom, co
         // fragment order [tile][v][lane = half*32 + i][4], half h covers k in [h*kp/2, (h+1)*kp/2)
         const int h = k / (kp / 2), kk = k % (kp / 2);
         frag[(((int64_t)tile * nk4 + kk / 4) * 64 + h * 32 + i) * 4 + (kk & 3)] = v;
-        // bf16 planes (truncation split, v = hi + mid + lo exactly up to 2^-24 |v|), MFMA 32x32x16 A-fragment
-        // order [tile][plane][step][lane = half*32 + i][8]: half h covers k in [h*kp/2, (h+1)*kp/2), step = kk/8
-        // the planes hold the FOLDED operand  -2 a^2 y_k  (k <= d)  and  a^2 |y|^2  in column d+1, which the
-        // evaluation kernel meets with a constant 1: the MFMA then yields a^2 (|y|^2 - 2 x.y) directly
-        const float vf = k <= d ? -2.0f * a * a * v : (k == d + 1 ? a * a * ny_full : 0.0f);
+        // 16-bit operand planes of the exponent-scaled kernels (gp_common.hpp, gp_epilogue_scaled): with
+        // q = log2(e)/(2a), k1 = -q the product of a collocation row and a point row is  Lam = k1 a^2 |x - y|^2.
+        // MFMA 32x32x16 A-fragment order [tile][plane][step][lane = half*32 + i][8]: half h covers k in
+        // [h*kp/2, (h+1)*kp/2), step = kk/8.  Column kp-1 is the constant 1 that meets k1 a^2 |x|^2 of the point row.
+        const float qs = 0.5f * 1.44269504088896341f / a, k1 = -qs;
+        const float ay = k1 * a * a * ny_full;
+        // bf16 planes (truncation split, v = hi + mid + lo exactly up to 2^-24 |v|): the collocation side carries
+        // the factor, 2 a^2 q y_k (k <= d), and k1 a^2 |y|^2 in column d+1 against a constant 1 in the point row
+        const float vf = k <= d ? 2.0f * a * a * qs * v : (k == d + 1 ? ay : (k == kp - 1 ? 1.0f : 0.0f));
         const uint32_t hb = __float_as_uint(vf) & 0xFFFF0000u;
         const float r1 = vf - __uint_as_float(hb);
         const uint32_t mb = __float_as_uint(r1) & 0xFFFF0000u;
@@ -277,14 +281,13 @@ __global__ void gp_pack_kernel(int d, float a, const float *x_dom, int n_dom, co
         bf[((int64_t)tile * 3 + 0) * ks * 512 + e] = (uint16_t)(hb >> 16);
         bf[((int64_t)tile * 3 + 1) * ks * 512 + e] = (uint16_t)(mb >> 16);
         bf[((int64_t)tile * 3 + 2) * ks * 512 + e] = (uint16_t)(lb >> 16);
-        // fp16 planes (h, 2^11 * l), stored behind the bf16 planes.  Here the -2 a^2 fold sits on the POINT side
-        // (gp_eval_bf16.hip): the planes hold y itself, and a^2 |y|^2 as h in column d+1 and 2^11*l in column
+        // fp16 planes (h, 2^11 * l), stored behind the bf16 planes.  Here the factor 2 a^2 q sits on the POINT side
+        // (gp_eval_bf16.hip): the planes hold y itself, and k1 a^2 |y|^2 as h in column d+1 and 2^11*l in column
         // d+2 of plane 0, met by the constants 1 and 2^-11 in the point row.  If y is exactly fp16 (float16
         // collocation points, as in the reference protocol) plane 1 is identically zero and is never read.
         uint16_t *hf = bf + (int64_t)3 * n_pad * kp;
-        const float ay = a * a * ny_full;
         const _Float16 ayh = (_Float16)ay;
-        const float vg = k <= d ? v : (k == d + 1 ? (float)ayh : (k == d + 2 ? (ay - (float)ayh) * 2048.0f : 0.0f));
+        const float vg = k <= d ? v : (k == d + 1 ? (float)ayh : (k == d + 2 ? (ay - (float)ayh) * 2048.0f : (k == kp - 1 ? 1.0f : 0.0f)));
         const _Float16 fh = (_Float16)vg;
         const _Float16 fl = k <= d ? (_Float16)((vg - (float)fh) * 2048.0f) : (_Float16)0.0f;
         hf[((int64_t)tile * 2 + 0) * ks * 512 + e] = __builtin_bit_cast(unsigned short, fh);
@@ -318,6 +321,22 @@ __global__ void gp_pack_kernel(int d, float a, const float *x_dom, int n_dom, co
     cf[11] = -2.0f * a * a * fd * cL;
     cf[12] = ny;
     cf[13] = cf[14] = cf[15] = 0.0f;
+    // exponent-scaled constants of the 16-bit kernels (layout and derivation: gp_common.hpp, gp_epilogue_scaled)
+    const float qs = 0.5f * 1.44269504088896341f / a, k1 = -qs, rq = sqrtf(qs);
+    float *c2 = coef + ((int64_t)n_pad + j) * kCoefRow;
+    c2[0] = a * sy;
+    c2[1] = rq * a * ty;
+    c2[2] = c0 - a * fd * cL;
+    c2[3] = cL / k1;
+    c2[4] = ct / rq;
+    c2[5] = cS;
+    c2[6] = rq * a * ct;
+    c2[7] = 2.0f * a * cL;
+    c2[8] = a * fd * cS;
+    c2[9] = -4.0f * a * cL;
+    c2[10] = -2.0f * a * k1 * cS;
+    c2[11] = 2.0f * a * a * fd * k1 * cL;
+    c2[12] = c2[13] = c2[14] = c2[15] = 0.0f;
 }
 
 template <int NK4>
@@ -355,7 +374,7 @@ extern "C" int64_t scasml_gp_plane_halfwords(int32_t d, int32_t n_pad) {
     return (int64_t)n_pad * 5 * kp;
 }
 
-extern "C" int64_t scasml_gp_coef_floats(int32_t n_pad) { return (int64_t)n_pad * kCoefRow; }
+extern "C" int64_t scasml_gp_coef_floats(int32_t n_pad) { return (int64_t)n_pad * 2 * kCoefRow; }
 
 extern "C" int scasml_gp_pack(int32_t d, float a, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy,
                               const double *rv, float *colloc_out, float *colloc_frag_out, uint16_t *colloc_bf16_out,
@@ -384,6 +403,8 @@ static int gp_eval_impl(const scasml_gp_model *m, const float *points, int64_t n
     g.site_u_only = site_u_only;
     g.rows_per_site = rows_per_site;
     g.coef = m->coef;
+    g.coef2 = m->coef + (int64_t)m->n_pad * kCoefRow;
+    g.first_bdy_tile = (m->n_dom + SCASML_GP_TILE - 1) / SCASML_GP_TILE;
     g.out4 = reinterpret_cast<float4 *>(out4);
     g.lap = lap;
     g.n_inf = n_inf;

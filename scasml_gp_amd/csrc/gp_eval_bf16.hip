@@ -17,10 +17,13 @@
 // exactly fp16 -- the reference's deepxde float16 arrays are -- plane l'_y is zero, so the l'_y * h_x MFMA
 // and the staging of that plane are dropped (YEXACT): 2 MFMAs per K-step.
 //
-// Structure (same as gp_eval.hip): workgroup of 8 waves, 32 points per wave held in VGPRs as bf16 planes
-// for the whole sweep; per collocation tile one LDS slot [SPLIT*KS KiB of A fragments | 1 KiB coefficients]
-// filled one tile ahead by global_load_lds; one barrier per tile; SIMD partner waves (w, w+4) run half a
-// tile apart so one's VALU epilogue overlaps the other's MFMAs.  The epilogue is gp_common.hpp's.
+// Structure: workgroup of 8 waves, 32 points per wave held in VGPRs as 16-bit planes for the whole sweep; per
+// collocation tile one LDS slot [planes*KS KiB of A fragments | 2 KiB constants] filled two tiles ahead by
+// LDS-DMA; one barrier per tile.  The operands are scaled so that the product is the exponent of the kernel
+// (gp_common.hpp, gp_epilogue_scaled); tiles of boundary rows run a shorter epilogue.  Every wave does MFMAs then
+// epilogue of the same tile: on gfx950 matrix and VALU time add up whichever way they are interleaved or spread
+// over the waves of a SIMD (tools/ubench_valu_forms.hip), so there is nothing to gain from
+// staggering partner waves.
 #include <type_traits>
 
 #include "gp_common.hpp"
@@ -132,7 +135,6 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
     extern __shared__ __attribute__((aligned(16))) float lds[];   // NSLOT slots
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int col = lane & 31, half = lane >> 5;
-    const bool late = (__builtin_amdgcn_readfirstlane(wv) >> 2) == 1 && !(g.dbg & 4);    // scalar, wave-uniform role
     const int64_t p0 = ((int64_t)blockIdx.x * WPB + wv) * 32;
     const int n_tiles = g.n_pad / 32;
 
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
     auto stage = [&](int tile, int slot) {
         const uint32_t dst = lds_base + (uint32_t)(slot * STAGE) * 4u;
         const float *srcA = reinterpret_cast<const float *>(F16 ? g.colloc_f16 : g.colloc_bf16) + (int64_t)tile * (F16 ? 2 : 3) * KS * 256;
-        const float *srcC = g.coef + (int64_t)tile * 512 - (int64_t)NPL * KS * 256;   // chunk c >= NPL*KS -> coef + (c - NPL*KS) KiB
+        const float *srcC = g.coef2 + (int64_t)tile * 512 - (int64_t)NPL * KS * 256;   // chunk c >= NPL*KS -> coef + (c - NPL*KS) KiB
 #pragma unroll
         for (int i = 0; i < CPW; ++i) {
             int c = wv + i * WPB;
@@ -176,37 +178,26 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
     stage(0, 0);
     if (NSLOT == 4 && n_tiles > 1) stage(1, 1);
 
-    // ---- this wave's 32 points: fp32 row halves -> |x|^2, a*sum x, a*t, and the bf16 planes ------
+    // ---- this wave's 32 points: fp32 row halves -> a*sum x, sqrt(q) a t, and the 16-bit planes ------
+    // exponent scaling (gp_common.hpp): q = log2(e)/(2a), k1 = -q; the planes hold 2 a^2 q x (fp16 mode) or x (bf16
+    // modes: the factor sits on the collocation side), the constants that meet k1 a^2 |y|^2, and k1 a^2 |x|^2 in
+    // the last column (half 1, step KS-1, element 7) against the collocation side's constant 1
+    const float qs = 0.5f * 1.44269504088896341f / g.a, k1 = -qs;
     s16x8 xb[SPLIT][KS];
-    float nx[1], sx[1], tx[1];
+    float sx, tx;
     {
         int64_t row = p0 + col;
         if (row >= g.n_inf) row = g.n_inf - 1;  // shadow rows, never stored
         const int kbase = half * (8 * KS);
         const float4 *src = reinterpret_cast<const float4 *>(g.points + row * g.kp + kbase);
         float pn = 0.0f, ps = 0.0f, pt = 0.0f;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const float4 q0 = src[2 * s], q1 = src[2 * s + 1];
-            const float e[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-            float t[8];          // the MFMA operand: x itself (bf16 modes) or the folded -2 a^2 x (fp16 mode), plus constants
-            const float fold = F16 ? -2.0f * g.a * g.a : 1.0f;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int k = kbase + 8 * s + c;
-                pn = fmaf(e[c], e[c], pn);
-                ps += k < g.d ? e[c] : 0.0f;
-                pt += k == g.d ? e[c] : 0.0f;
-                // spare columns: d+1 meets a^2|y|^2 (bf16 modes: the whole value; fp16 mode: its h part), d+2 its 2^11*l part
-                const float spare = k == g.d + 1 ? 1.0f : ((F16 && k == g.d + 2) ? 0x1p-11f : 0.0f);
-                t[c] = k <= g.d ? fold * e[c] : spare;
-            }
+        const float fold = F16 ? 2.0f * g.a * g.a * qs : 1.0f;
+        auto make_planes = [&](const float (&t)[8], Frag &fh, Frag &fm, Frag &fl) {
             uint32_t hb[8], mb[8], lb[8];
             if constexpr (!F16) {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) split3(t[c], hb[c], mb[c], lb[c]);
             }
-            Frag fh, fm, fl;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {   // element 2c in the low half-word, 2c+1 in the high one
                 if constexpr (F16) {
@@ -220,26 +211,49 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
                     fl.u[c] = (lb[2 * c] >> 16) | lb[2 * c + 1];
                 }
             }
-            xb[0][s] = fh.v;
-            xb[1][s] = fm.v;
-            if (SPLIT == 3) xb[SPLIT - 1][s] = fl.v;
+        };
+        float tlast[8];   // the operand values of the last step, kept to patch column kp-1 once |x|^2 is known
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const float4 q0 = src[2 * s], q1 = src[2 * s + 1];
+            const float e[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            float t[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int k = kbase + 8 * s + c;
+                pn = fmaf(e[c], e[c], pn);
+                ps += k < g.d ? e[c] : 0.0f;
+                pt += k == g.d ? e[c] : 0.0f;
+                // spare columns: d+1 meets k1 a^2|y|^2 (bf16 modes: the whole value; fp16 mode: its h part), d+2 its 2^11*l part
+                const float spare = k == g.d + 1 ? 1.0f : ((F16 && k == g.d + 2) ? 0x1p-11f : 0.0f);
+                t[c] = k <= g.d ? fold * e[c] : spare;
+            }
+            if (s == KS - 1) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) tlast[c] = t[c];
+            } else {
+                Frag fh, fm, fl;
+                make_planes(t, fh, fm, fl);
+                xb[0][s] = fh.v;
+                xb[1][s] = fm.v;
+                if (SPLIT == 3) xb[SPLIT - 1][s] = fl.v;
+            }
         }
         pn += __shfl_xor(pn, 32);
         ps += __shfl_xor(ps, 32);
         pt += __shfl_xor(pt, 32);
-        nx[0] = g.a * g.a * pn - g.a * (float)g.d;   // folded epilogue: L0 = acc + nx
-        sx[0] = g.a * ps;
-        tx[0] = g.a * pt;
+        tlast[7] = half ? k1 * g.a * g.a * pn : tlast[7];   // column kp-1 (zero in the point buffer): k1 a^2 |x|^2
+        {
+            Frag fh, fm, fl;
+            make_planes(tlast, fh, fm, fl);
+            xb[0][KS - 1] = fh.v;
+            xb[1][KS - 1] = fm.v;
+            if (SPLIT == 3) xb[SPLIT - 1][KS - 1] = fl.v;
+        }
+        sx = g.a * ps;
+        tx = sqrtf(qs) * g.a * pt;
     }
-    float au[1] = {0.0f}, at[1] = {0.0f}, ad[1] = {0.0f}, al[1] = {0.0f};
-    GpConsts c;
-    c.a = g.a;
-    c.a2 = g.a * g.a;
-    c.ad = g.a * (float)g.d;
-    c.kexp = -0.5f * g.a * 1.44269504088896341f;
-    c.dF = (float)g.d;
-    c.k1 = -0.5f * 1.44269504088896341f / g.a;    // exp(-a r2 / 2) = exp2(k1 * (a^2 r2 - a d) + k2)
-    c.k2 = c.k1 * c.ad;
+    float au = 0.0f, at = 0.0f, ad = 0.0f, al = 0.0f;
 
     auto a_of = [&](int slot) { return reinterpret_cast<const float4 *>(lds + slot * STAGE); };
     auto view = [&](int slot) {
@@ -255,38 +269,32 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
         uonly = g.site_u_only[s0] == 1 && g.site_u_only[s1] == 1;
     }
     uonly = __builtin_amdgcn_readfirstlane((int)uonly) != 0;
-    f32x16 acc[1];
+    f32x16 acc;
     // the whole sweep is instantiated twice (full / u-only epilogue) and the wave-uniform choice is made once,
     // outside the tile loops: a branch inside them costs registers (the allocator then spills the point tile)
     auto sweep = [&](auto uo) {
         constexpr bool UO = decltype(uo)::value;
         constexpr int AHEAD = NSLOT == 4 ? 2 : 1;
-        if (!late) {
-            for (int jt = 0; jt < n_tiles; ++jt) {
-                if (jt + AHEAD < n_tiles && !(g.dbg & 8)) stage(jt + AHEAD, (jt + AHEAD) % NSLOT);
-                if (!(g.dbg & 1)) gp_mfma_tile_bf16<KS, SPLIT, PF, F16, YEXACT>(a_of(jt % NSLOT), xb, acc[0], lane);
-                if (!(g.dbg & 2)) gp_epilogue_tile<1, true, PF, UO>(view(jt % NSLOT), acc, c, half, nx, sx, tx, au, at, ad, al);
-                rendezvous(jt + AHEAD < n_tiles);
-            }
-        } else {
-            for (int jt = 0; jt < n_tiles; ++jt) {
-                if (jt + AHEAD < n_tiles && !(g.dbg & 8)) stage(jt + AHEAD, (jt + AHEAD) % NSLOT);
-                if (jt > 0 && !(g.dbg & 2)) gp_epilogue_tile<1, true, PF, UO>(view((jt - 1) % NSLOT), acc, c, half, nx, sx, tx, au, at, ad, al);
-                if (!(g.dbg & 1)) gp_mfma_tile_bf16<KS, SPLIT, PF, F16, YEXACT>(a_of(jt % NSLOT), xb, acc[0], lane);
-                rendezvous(jt + AHEAD < n_tiles);
-            }
-            gp_epilogue_tile<1, true, PF, UO>(view((n_tiles - 1) % NSLOT), acc, c, half, nx, sx, tx, au, at, ad, al);
-        }
+        auto tile = [&](int jt, auto kind) {
+            if (jt + AHEAD < n_tiles && !(g.dbg & 8)) stage(jt + AHEAD, (jt + AHEAD) % NSLOT);
+            if (!(g.dbg & 1)) gp_mfma_tile_bf16<KS, SPLIT, PF, F16, YEXACT>(a_of(jt % NSLOT), xb, acc, lane);
+            if (!(g.dbg & 2)) gp_epilogue_scaled<decltype(kind)::value, PF>(view(jt % NSLOT), acc, half, sx, tx, au, at, ad, al);
+            rendezvous(jt + AHEAD < n_tiles);
+        };
+        const int nb0 = g.first_bdy_tile < n_tiles ? g.first_bdy_tile : n_tiles;
+        for (int jt = 0; jt < nb0; ++jt) tile(jt, std::integral_constant<int, UO ? 1 : 0>{});
+        for (int jt = nb0; jt < n_tiles; ++jt) tile(jt, std::integral_constant<int, UO ? 3 : 2>{});   // boundary rows only
     };
     rendezvous(n_tiles > 1);  // tile 0 has landed (tile 1 may still be in flight)
     if (uonly) sweep(std::true_type{});
     else sweep(std::false_type{});
 
+    // undo the exponent units (gp_common.hpp): dt = sum / sqrt(q), lap = sum / k1 - a d u
     const float s2 = g.sigma * g.sigma;
-    const float u = au[0] + __shfl_xor(au[0], 32);
-    const float dt = at[0] + __shfl_xor(at[0], 32);
-    const float dv = ad[0] + __shfl_xor(ad[0], 32);
-    const float lp = al[0] + __shfl_xor(al[0], 32);
+    const float u = au + __shfl_xor(au, 32);
+    const float dt = (at + __shfl_xor(at, 32)) / sqrtf(qs);
+    const float dv = ad + __shfl_xor(ad, 32);
+    const float lp = (al + __shfl_xor(al, 32)) / k1 - g.a * (float)g.d * u;
     const int64_t row = p0 + col;
     if (half == 0 && row < g.n_inf) {
         const float eps = dt + (s2 * u - 1.0f / (float)g.d - 0.5f * s2) * dv + 0.5f * s2 * lp;   // models/GP.py:767-768

@@ -5,7 +5,7 @@
 // MLP_full_history.uz_solve (solvers/MLP_full_history.py:64-180) and
 // ScaSML_full_history.uz_solve (solvers/ScaSML_full_history.py:75-199).
 //
-// Mapping (DESIGN.md "picard_tree"): a root point owns G = pow2 >= round_up(d+3,16)/4 lanes; lane
+// Mapping (DESIGN.md "picard_tree"): a root point owns G = pow2 >= round_up(d+4,16)/4 lanes; lane
 // `gl` of the group holds spatial dims 4gl..4gl+3 of every d-vector (x, X, W, z) in one float4,
 // so one Philox4x32 block per lane per path-step yields exactly that lane's four normals.
 // 64/G roots share a wavefront and walk the SAME static tree in lock step -- the tree depends
@@ -371,7 +371,7 @@ extern "C" int scasml_plan_site_kinds(const scasml_plan *plan_h, int32_t rank, i
     return 0;
 }
 
-extern "C" int32_t scasml_point_stride(int32_t d) { return (d + 3 + 15) / 16 * 16; }
+extern "C" int32_t scasml_point_stride(int32_t d) { return (d + 4 + 15) / 16 * 16; }
 
 extern "C" int scasml_picard_tree(const scasml_problem *prob, const scasml_plan *plan, int mode, const float *x_t,
                                   int64_t B, scasml_rng rng, float *points, const float *gp_vals, float *out_uz,

@@ -99,15 +99,15 @@ def test_sample_sharding_partials_sum_to_the_unsharded_result():
 
 
 def test_maximum_dimension_and_single_root():
-    hip, ora = _solvers(253, "quad", seed=5)
-    xt = _points(253, 4, 9)[:1]
+    hip, ora = _solvers(252, "quad", seed=5)
+    xt = _points(252, 4, 9)[:1]
     got, want = hip.uz_solve(2, 2, xt), ora.uz_solve(2, 2, xt)
-    assert got.shape == (1, 254) and np.all(np.abs(got - want) <= ATOL + RTOL * np.abs(want))
+    assert got.shape == (1, 253) and np.all(np.abs(got - want) <= ATOL + RTOL * np.abs(want))
     from scasml_gp_amd import _lib
     from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
     from scasml_gp_amd.solvers.MLP import MLP
-    with pytest.raises(_lib.ScasmlError):                      # d = 254 exceeds SCASML_MAX_DIM: error code, not a crash
-        MLP(Grad_Dependent_Nonlinear(255)).uz_solve(1, 1, np.zeros((2, 255), dtype=np.float32))
+    with pytest.raises(_lib.ScasmlError):                      # d = 253 exceeds SCASML_MAX_DIM: error code, not a crash
+        MLP(Grad_Dependent_Nonlinear(254)).uz_solve(1, 1, np.zeros((2, 254), dtype=np.float32))
     with pytest.raises(ValueError):                            # wrong column count is caught on the host
         hip.uz_solve(1, 1, np.zeros((2, 7), dtype=np.float32))
     with pytest.raises(ValueError):                            # level beyond the instantiated kernels

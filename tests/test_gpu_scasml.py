@@ -117,7 +117,7 @@ def test_reference_evaluation_counter_for_scasml():
     assert hip.evaluation_counter == tables.reference_evaluation_count("quad", 2, 2, True)
 
 
-@pytest.mark.parametrize("d", [250, 253])
+@pytest.mark.parametrize("d", [250, 252])
 def test_large_dimension_scasml(d):
     hip, ora, _ = _setup(d, 40, 8, "quad", seed=8)
     xt = _test_points(d, 5, 36)
