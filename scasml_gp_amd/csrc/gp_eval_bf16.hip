@@ -1,19 +1,18 @@
-// Fused GP posterior evaluation with x.y on the bf16 matrix cores (split-bf16 arithmetic).
+// Fused GP posterior evaluation with x.y on the 16-bit matrix cores (split arithmetic).
 //
-// Why: on gfx950 the fp32-input MFMA (v_mfma_f32_32x32x2_f32) runs at the fp32 VALU rate AND does not
-// co-execute with VALU work (tools/ubench_mfma_valu.hip: an MFMA-only and a VALU-only wave on one SIMD
-// take the SUM of their times), so the fp32 kernel's time is matrix time + epilogue time.  bf16 MFMA is
-// 16x faster per flop and does overlap with VALU.  Each fp32 operand is split by truncation into bf16
-// planes  v = hi + mid + lo  (exact to 2^-24 |v|); the products hi*hi, hi*mid, mid*hi, mid*mid, hi*lo,
+// Why: on gfx950 the fp32-input MFMA (v_mfma_f32_32x32x2_f32) runs at the fp32 VALU rate, and with the two or
+// more waves per SIMD the VALU epilogue needs, matrix time and VALU time add (tools/ubench_valu_forms.hip,
+// DESIGN.md 4.2) -- so the matrix part has to be made short: the 16-bit MFMA is 16x faster per flop.
+// Each fp32 operand is split by truncation into bf16 planes  v = hi + mid + lo  (exact to 2^-24 |v|); the products hi*hi, hi*mid, mid*hi, mid*mid, hi*lo,
 // lo*hi carry every term down to 2^-24, i.e. x.y is as exact as the fp32 MFMA (SPLIT = 3, 6 MFMAs per
 // K-step); SPLIT = 2 keeps hi/mid only (3 MFMAs, ~2^-17 per product).  Accumulation is fp32 in the MFMA.
 //
 // MODE 22 ("fp16x2"): two fp16 planes  v = h + 2^-11 * l'  (h = fp16(v), l' = fp16(2^11 (v - h)); 11 + 11
 // mantissa bits, products exact in the fp32 MFMA accumulator).  h*h goes to one accumulator, the cross
 // terms h*l' + l'*h to a second one that enters as 2^-11 * acc2 (l'*l' ~ 2^-22 is dropped): 3 MFMAs per
-// K-step instead of 6, product accuracy ~2^-22 instead of 2^-24.  In this mode the -2 a^2 fold sits on the
-// point side (B = planes of -2 a^2 x, constants 1 and 2^-11 in two spare columns) and the collocation planes
-// hold y itself plus a^2 |y|^2 as (h, l') in those two columns; when every collocation coordinate is
+// K-step instead of 6, product accuracy ~2^-22 instead of 2^-24.  In this mode the scale factor sits on the
+// point side (B = planes of 2 a^2 q x, constants 1 and 2^-11 in two spare columns) and the collocation planes
+// hold y itself plus k1 a^2 |y|^2 as (h, l') in those two columns; when every collocation coordinate is
 // exactly fp16 -- the reference's deepxde float16 arrays are -- plane l'_y is zero, so the l'_y * h_x MFMA
 // and the staging of that plane are dropped (YEXACT): 2 MFMAs per K-step.
 //
