@@ -23,6 +23,7 @@
 // epilogue of the same tile: on gfx950 matrix and VALU time add up whichever way they are interleaved or spread
 // over the waves of a SIMD (tools/ubench_valu_forms.hip), so there is nothing to gain from
 // staggering partner waves.
+#include <stdlib.h>
 #include <type_traits>
 
 #include "gp_common.hpp"
@@ -128,7 +129,7 @@ template <int KS, int SPLIT, int WPB, bool F16, int BPC, bool YEXACT>
 __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(const GpArgs g) {
     constexpr int NPL = YEXACT ? 1 : SPLIT;          // A planes staged per tile
     constexpr bool PF = WPB * BPC <= 8;
-    static_assert(WPB == 8 || WPB == 12 || WPB == 16, "waves per workgroup");
+    static_assert(WPB == 4 || WPB == 8 || WPB == 12 || WPB == 16, "waves per workgroup");
     constexpr int STAGE = NPL * KS * 256 + 512;         // floats per LDS slot (A fragments + 32 rows x 16 coefficients)
     constexpr int NSLOT = (4 * STAGE * 4 * BPC <= 144 * 1024) ? 4 : 3;
     extern __shared__ __attribute__((aligned(16))) float lds[];   // NSLOT slots
@@ -308,13 +309,8 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
     }
 }
 
-template <int KS, int SPLIT, bool F16, bool YEXACT>
-static int launch_one(const GpArgs &g, hipStream_t s) {
-    // three waves per SIMD while the 16-bit planes of the point tile (SPLIT*4*KS VGPRs) leave room under 168
-    constexpr int REGS = SPLIT * 4 * KS + (F16 ? 16 : 0);       // point-tile planes + second accumulator
-    constexpr int WPS = REGS <= 72 ? 4 : (REGS <= 96 ? 3 : 2);  // waves per SIMD the VGPR budget allows
-    constexpr int BPC = WPS == 4 ? 2 : 1;
-    constexpr int WPB = WPS * 4 / BPC;
+template <int KS, int SPLIT, bool F16, bool YEXACT, int WPB, int BPC>
+static int launch_cfg(const GpArgs &g, hipStream_t s) {
     const int64_t waves = (g.n_inf + 31) / 32;
     const int64_t blocks = (waves + WPB - 1) / WPB;
     if (blocks > 0x7FFFFFFF) return fail(SCASML_ERR_UNSUPPORTED, "gp_eval: too many points");
@@ -328,6 +324,20 @@ static int launch_one(const GpArgs &g, hipStream_t s) {
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WPB * 64), lds_bytes, s, g);
     return check_launch("gp_eval(bf16) launch");
+}
+
+template <int KS, int SPLIT, bool F16, bool YEXACT>
+static int launch_one(const GpArgs &g, hipStream_t s) {
+    // three waves per SIMD while the 16-bit planes of the point tile (SPLIT*4*KS VGPRs) leave room under 168
+    constexpr int REGS = SPLIT * 4 * KS + (F16 ? 16 : 0);       // point-tile planes + second accumulator
+    constexpr int WPS = REGS <= 72 ? 4 : (REGS <= 96 ? 3 : 2);  // waves per SIMD the VGPR budget allows
+    constexpr int BPC = WPS == 4 ? 2 : 1;
+    constexpr int WPB = WPS * 4 / BPC;
+    // four waves per SIMD as four 4-wave workgroups per CU when their 4 x 4 LDS slots fit (finer turnover: while one
+    // workgroup reads its point rows the other three sweep; measured 9.19 vs 9.34 ms for 2 x 8 waves, 10.0 for 1 x 16)
+    constexpr size_t stage_bytes = ((YEXACT ? 1 : SPLIT) * KS * 256 + 512) * sizeof(float);
+    if constexpr (WPS == 4 && 16 * stage_bytes <= 144 * 1024) return launch_cfg<KS, SPLIT, F16, YEXACT, 4, 4>(g, s);
+    return launch_cfg<KS, SPLIT, F16, YEXACT, WPB, BPC>(g, s);
 }
 
 template <int SPLIT, bool F16, bool YEXACT>

@@ -152,3 +152,23 @@ def test_site_kinds_partition_the_tree_under_sample_sharding(lib, variant, n, pa
         tab = approx_parameters(par) if variant == "quad" else None
         assert ppr == site_count(variant, n, par, tab) + 1 and base[-1] == 1 and set(base) <= {0, 1}
     assert lib.scasml_plan_site_kinds(C.byref(plan), world, world, np.zeros(ppr, dtype=np.uint8).ctypes.data_as(C.c_void_p)) == -1
+
+
+def test_no_spills_inside_the_gp_tile_loops():
+    """The GP evaluation kernels count LDS-DMA completions with `s_waitcnt vmcnt(N)`; a register spill or reload
+    inside the tile loop would be counted too and silently break the hand-over.  tools/kernel_regs.py compiles the
+    file to ISA text and reports scratch instructions inside loops: only the kernels that drain fully (three LDS
+    slots, `vmcnt(0)`) may have any."""
+    import subprocess, sys, os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_regs.py"), "gp_eval_bf16.hip"],
+                         capture_output=True, text=True, check=True).stdout
+    assert "gp_eval_bf16_kernel<7, 2, 4, true, 4, true>" in out            # the headline instantiation is there
+    for line in out.splitlines():
+        if "!!" not in line:
+            continue
+        ks, split, _, _, _, yexact = re.search(r"<(\d+), (\d+), (\d+), (\w+), (\d+), (\w+)>", line).groups()
+        planes = 1 if yexact == "true" else int(split)
+        stage_bytes = (planes * int(ks) * 256 + 512) * 4
+        bpc = int(re.search(r"<\d+, \d+, \d+, \w+, (\d+),", line).group(1))
+        assert 4 * stage_bytes * bpc > 144 * 1024, "spill inside a counted-vmcnt tile loop: " + line
