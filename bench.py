@@ -234,16 +234,17 @@ def main():
         split = int(gp.eval_split)
         kp = (d + 2 + 15) // 16 * 16
         n_pad = (n_colloc + 31) // 32 * 32
-        products = {0: 1, 2: 3, 3: 6, 22: 3}[split]
+        products = {0: 1, 2: 3, 3: 6, 22: 2 if getattr(gp, "_colloc_is_f16", False) else 3}[split]
         issued = products * 2.0 * n_inf * n_pad * kp / (gp_ms * 1e-3) / 1e12      # MFMA flops actually issued
         peak = MFMA_F32_PEAK_TFLOPS if split == 0 else MFMA_BF16_PEAK_TFLOPS
-        roofline = {"kernel": "gp_eval_kernel (fp32 MFMA)" if split == 0 else ("gp_eval_bf16_kernel (2 fp16 planes)" if split == 22 else "gp_eval_bf16_kernel (%d bf16 planes)" % split),
+        roofline = {"kernel": "gp_eval_kernel (fp32 MFMA)" if split == 0 else ("gp_eval_bf16_kernel (2 fp16 planes, exponent-unit epilogue)" if split == 22 else "gp_eval_bf16_kernel (%d bf16 planes)" % split),
                     "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": traffic, "avg_launch_ms": round(gp_ms, 4),
                     "flops_per_launch": flops, "achieved_vs_fp32_mfma_peak": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
                     "mfma_issued_tflops": round(issued, 1), "mfma_issued_frac": round(issued / peak, 4),
-                    "note": "achieved = algorithmic fp32 flops (SURVEY 8(d)); the split-bf16 kernel issues %dx as many bf16 "
-                            "MFMA flops to keep products exact to fp32; on gfx950 MFMA and VALU time add (DESIGN.md 4.2)" % products}
+                    "note": "achieved = algorithmic fp32 flops (SURVEY 8(d)); the split-precision kernel issues %dx as many "
+                            "16-bit MFMA flops to keep products exact to 2^-22; the kernel is instruction-issue-bound: on gfx950 "
+                            "MFMA and VALU issue time add (DESIGN.md 4.2)" % products}
     # the path kernels, priced with the materialised-state model of SURVEY.md 8(d): 16*d bytes per path-step
     path_ms = (kernel_ms.get("picard_generate") or 0.0) + (kernel_ms.get("picard_accumulate") or 0.0)
     path_roof = None
