@@ -1,0 +1,81 @@
+"""BASELINE.json configs[2] at full size (d = 100, ScaSML n = rho = 3, 16384 roots, GP on 1000 + 200 points) through
+size-independent properties; the oracle is consulted on a 12-root sample only."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+D, N, B = 100, 3, 1 << 14
+
+
+@pytest.fixture(scope="module")
+def headline():
+    import torch
+    from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
+    from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
+    from scasml_gp_amd.solvers.ScaSML import ScaSML
+    eq = Grad_Dependent_Nonlinear(D + 1)
+    eq.geometry()
+    state = np.random.get_state()
+    np.random.seed(1234)
+    x_dom, x_bdy = eq.generate_data(1000, 200)
+    np.random.set_state(state)
+    gp = GP_Grad_Dependent_Nonlinear(eq)
+    gp.GPsolver(x_dom, x_bdy, GN_steps=20)
+    solver = ScaSML(eq, gp, seed=0)
+    g = np.random.default_rng(1234)
+    x_t = np.concatenate([g.uniform(-0.5, 0.5, (B, D)), g.uniform(0.0, 0.5, (B, 1))], axis=1).astype(np.float32)
+    x_dev = torch.from_numpy(x_t).cuda()
+    full, uhat, _ = solver._engine.solve(N, N, x_dev, stream_id=7)
+    return solver, gp, x_dom, x_bdy, x_t, x_dev, full, uhat
+
+
+def test_full_batch_is_finite_clipped_and_deterministic(headline):
+    import torch
+    solver, _, _, _, _, x_dev, full, uhat = headline
+    assert full.shape == (B, D + 1) and bool(torch.isfinite(full).all()) and bool(torch.isfinite(uhat).all())
+    clip = float(solver.equation.norm_estimation)
+    assert float(full.abs().max()) <= clip * (1 + 1e-6)
+    again, uhat2, _ = solver._engine.solve(N, N, x_dev, stream_id=7)
+    assert torch.equal(again, full) and torch.equal(uhat2, uhat)
+    other, _, _ = solver._engine.solve(N, N, x_dev, stream_id=8)          # another call draws other normals
+    assert not torch.equal(other, full)
+
+
+def test_any_slice_of_roots_reproduces_its_rows_bitwise(headline):
+    """Philox is keyed by the global root index and no reduction crosses roots: a slice of the batch solved on
+    its own (root0 = its offset) must give the rows of the full solve bit for bit -- the property roots sharding
+    across GPUs rests on."""
+    import torch
+    solver, _, _, _, _, x_dev, full, uhat = headline
+    for lo, hi in [(0, 64), (5000, 5033), (B - 100, B)]:
+        part, uh, _ = solver._engine.solve(N, N, x_dev[lo:hi], root0=lo, stream_id=7)
+        assert torch.equal(part, full[lo:hi]) and torch.equal(uh, uhat[lo:hi])
+
+
+def test_sample_sharded_partials_add_up_at_full_size(headline):
+    import torch
+    solver, _, _, _, _, x_dev, full, _ = headline
+    eng = solver._engine
+    total = None
+    for r in range(2):
+        part, _, _ = eng.solve(N, N, x_dev, rank=r, world=2, stream_id=7)
+        total = part.clone() if total is None else total + part
+    assert torch.allclose(eng.finalize_partials(total), full, atol=2e-5, rtol=1e-5)
+
+
+def test_sample_of_the_full_batch_matches_the_oracle(headline):
+    from oracle.equation import GradDependentNonlinear
+    from oracle.gp import OracleGP
+    from oracle.mlp import PicardOracle
+    solver, gp, x_dom, x_bdy, x_t, _, full, _ = headline
+    oeq = GradDependentNonlinear(D + 1)
+    ogp = OracleGP(oeq)                                   # the same trained surrogate as the GPU run
+    ogp.x_t_domain, ogp.x_t_boundary = np.asarray(x_dom, dtype=np.float64), np.asarray(x_bdy, dtype=np.float64)
+    ogp.N_domain, ogp.N_boundary = len(x_dom), len(x_bdy)
+    ogp.right_vector = gp.right_vector
+    rows = np.array([0, 1, 2, 3, 4097, 4098, 8191, 8192, 12345, B - 3, B - 2, B - 1])
+    ora = PicardOracle(oeq, "quad", gp=ogp, seed=0, stream=7)
+    want = np.concatenate([ora.uz_solve(N, N, x_t[r:r + 1], root0=int(r)) for r in rows])
+    got = full[rows].cpu().numpy()
+    assert np.max(np.abs(got - want)) < 1e-4              # outputs are clipped to +-0.1: 1e-3 relative to the clip
