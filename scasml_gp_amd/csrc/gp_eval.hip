@@ -287,9 +287,9 @@ __global__ void gp_pack_kernel(int d, float a, const float *x_dom, int n_dom, co
         // collocation points, as in the reference protocol) plane 1 is identically zero and is never read.
         uint16_t *hf = bf + (int64_t)3 * n_pad * kp;
         const _Float16 ayh = (_Float16)ay;
-        const float vg = k <= d ? v : (k == d + 1 ? (float)ayh : (k == d + 2 ? (ay - (float)ayh) * 2048.0f : (k == kp - 1 ? 1.0f : 0.0f)));
+        const float vg = k <= d ? v : (k == d + 1 ? (float)ayh : (k == d + 2 ? ay - (float)ayh : (k == kp - 1 ? 1.0f : 0.0f)));
         const _Float16 fh = (_Float16)vg;
-        const _Float16 fl = k <= d ? (_Float16)((vg - (float)fh) * 2048.0f) : (_Float16)0.0f;
+        const _Float16 fl = k <= d ? (_Float16)(vg - (float)fh) : (_Float16)0.0f;
         hf[((int64_t)tile * 2 + 0) * ks * 512 + e] = __builtin_bit_cast(unsigned short, fh);
         hf[((int64_t)tile * 2 + 1) * ks * 512 + e] = __builtin_bit_cast(unsigned short, fl);
         ny = fmaf(v, v, ny);

@@ -69,9 +69,8 @@ __device__ __forceinline__ void glds16_asm(const float *gsrc_lane, uint32_t lds_
 // KS = kp / 16 K-steps of the 32x32x16 MFMA; half-wave h covers k in [h*8*KS, (h+1)*8*KS)
 template <int KS, int SPLIT, bool PF, bool F16, bool YEXACT>
 __device__ __forceinline__ void gp_mfma_tile_bf16(const float4 *lds_a, const s16x8 (&xb)[SPLIT][KS], f32x16 &acc, int lane) {
-    f32x16 acc2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = acc2[r] = 0.0f;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     // A fragments ping-pong between two register sets selected by the (compile-time) parity of the
     // step: the ds_reads of step s+1 are issued before the MFMAs of step s, with no register copies.
     constexpr int NPL = YEXACT ? 1 : SPLIT;      // A planes actually staged and read
@@ -96,8 +95,8 @@ __device__ __forceinline__ void gp_mfma_tile_bf16(const float4 *lds_a, const s16
             Frag b0, b1;
             b0.v = xb[0][s];
             b1.v = xb[1][s];
-            if constexpr (!YEXACT) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cur][1].h, b0.h, acc2, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cur][0].h, b1.h, acc2, 0, 0, 0);
+            if constexpr (!YEXACT) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cur][1].h, b0.h, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cur][0].h, b1.h, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cur][0].h, b0.h, acc, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             continue;
@@ -112,10 +111,6 @@ __device__ __forceinline__ void gp_mfma_tile_bf16(const float4 *lds_a, const s16
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0].v, xb[1][s], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0].v, xb[0][s], acc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (F16) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = fmaf(acc2[r], 0x1p-11f, acc[r]);
     }
 }
 
@@ -209,7 +204,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
                 if constexpr (F16) {
                     const float h0 = (float)(_Float16)t[2 * c], h1 = (float)(_Float16)t[2 * c + 1];
                     fh.u[c] = pack_h2(t[2 * c], t[2 * c + 1]);
-                    fm.u[c] = pack_h2((t[2 * c] - h0) * 2048.0f, (t[2 * c + 1] - h1) * 2048.0f);
+                    fm.u[c] = pack_h2(t[2 * c] - h0, t[2 * c + 1] - h1);   // unscaled: fp16 subnormals carry it (see header)
                     fl.u[c] = 0;
                 } else {
                     fh.u[c] = (hb[2 * c] >> 16) | hb[2 * c + 1];
@@ -231,7 +226,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
                 ps += k < g.d ? e[c] : 0.0f;
                 pt += k == g.d ? e[c] : 0.0f;
                 // spare columns: d+1 meets k1 a^2|y|^2 (bf16 modes: the whole value; fp16 mode: its h part), d+2 its 2^11*l part
-                const float spare = k == g.d + 1 ? 1.0f : ((F16 && k == g.d + 2) ? 0x1p-11f : 0.0f);
+                const float spare = k == g.d + 1 ? 1.0f : ((F16 && k == g.d + 2) ? 1.0f : 0.0f);
                 t[c] = k <= g.d ? fold * e[c] : spare;
             }
             if (s == KS - 1) {
