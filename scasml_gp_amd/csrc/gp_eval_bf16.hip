@@ -123,7 +123,7 @@ __device__ __forceinline__ void gp_mfma_tile_bf16(const float4 *lds_a, const s16
 template <int KS, int SPLIT, int WPB, bool F16, int BPC, bool YEXACT>
 __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(const GpArgs g) {
     constexpr int NPL = YEXACT ? 1 : SPLIT;          // A planes staged per tile
-    constexpr bool PF = WPB * BPC <= 8;
+    constexpr bool PF = WPB * BPC <= 8 || (F16 && YEXACT && KS <= 7);
     static_assert(WPB == 4 || WPB == 8 || WPB == 12 || WPB == 16, "waves per workgroup");
     constexpr int STAGE = NPL * KS * 256 + 512;         // floats per LDS slot (A fragments + 32 rows x 16 coefficients)
     constexpr int NSLOT = (4 * STAGE * 4 * BPC <= 144 * 1024) ? 4 : 3;
