@@ -281,9 +281,9 @@ __global__ void gp_pack_kernel(int d, float a, const float *x_dom, int n_dom, co
         bf[((int64_t)tile * 3 + 0) * ks * 512 + e] = (uint16_t)(hb >> 16);
         bf[((int64_t)tile * 3 + 1) * ks * 512 + e] = (uint16_t)(mb >> 16);
         bf[((int64_t)tile * 3 + 2) * ks * 512 + e] = (uint16_t)(lb >> 16);
-        // fp16 planes (h, 2^11 * l), stored behind the bf16 planes.  Here the factor 2 a^2 q sits on the POINT side
-        // (gp_eval_bf16.hip): the planes hold y itself, and k1 a^2 |y|^2 as h in column d+1 and 2^11*l in column
-        // d+2 of plane 0, met by the constants 1 and 2^-11 in the point row.  If y is exactly fp16 (float16
+        // fp16 planes (h, l = fp16(v - h), unscaled), stored behind the bf16 planes.  Here the factor 2 a^2 q sits on
+        // the POINT side (gp_eval_bf16.hip): the planes hold y itself, and k1 a^2 |y|^2 as h in column d+1 and l in
+        // column d+2 of plane 0, met by the constants 1 and 1 in the point row.  If y is exactly fp16 (float16
         // collocation points, as in the reference protocol) plane 1 is identically zero and is never read.
         uint16_t *hf = bf + (int64_t)3 * n_pad * kp;
         const _Float16 ayh = (_Float16)ay;

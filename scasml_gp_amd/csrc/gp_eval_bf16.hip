@@ -7,13 +7,14 @@
 // lo*hi carry every term down to 2^-24, i.e. x.y is as exact as the fp32 MFMA (SPLIT = 3, 6 MFMAs per
 // K-step); SPLIT = 2 keeps hi/mid only (3 MFMAs, ~2^-17 per product).  Accumulation is fp32 in the MFMA.
 //
-// MODE 22 ("fp16x2"): two fp16 planes  v = h + 2^-11 * l'  (h = fp16(v), l' = fp16(2^11 (v - h)); 11 + 11
-// mantissa bits, products exact in the fp32 MFMA accumulator).  h*h goes to one accumulator, the cross
-// terms h*l' + l'*h to a second one that enters as 2^-11 * acc2 (l'*l' ~ 2^-22 is dropped): 3 MFMAs per
-// K-step instead of 6, product accuracy ~2^-22 instead of 2^-24.  In this mode the scale factor sits on the
-// point side (B = planes of 2 a^2 q x, constants 1 and 2^-11 in two spare columns) and the collocation planes
-// hold y itself plus k1 a^2 |y|^2 as (h, l') in those two columns; when every collocation coordinate is
-// exactly fp16 -- the reference's deepxde float16 arrays are -- plane l'_y is zero, so the l'_y * h_x MFMA
+// MODE 22 ("fp16x2"): two fp16 planes  v = h + l  (h = fp16(v), l = fp16(v - h): |l| <= 2^-12 |v| lands in the
+// fp16 subnormal range for |v| < 1/4 and is then exact to 2^-25 absolute -- the MFMA honours fp16 subnormals, which
+// tests/test_gpu_gp.py would show at once if it did not).  The products h*h and h*l + l*h are exact in the fp32
+// accumulator and go into ONE accumulator (l*l ~ 2^-24 is dropped): 3 MFMAs per K-step instead of 6, product
+// accuracy ~2^-22 instead of 2^-24, no combining instruction.  In this mode the scale factor sits on the
+// point side (B = planes of 2 a^2 q x, constants 1 and 1 in two spare columns) and the collocation planes
+// hold y itself plus k1 a^2 |y|^2 as (h, l) in those two columns; when every collocation coordinate is
+// exactly fp16 -- the reference's deepxde float16 arrays are -- plane l_y is zero, so the l_y * h_x MFMA
 // and the staging of that plane are dropped (YEXACT): 2 MFMAs per K-step.
 //
 // Structure: workgroup of 8 waves, 32 points per wave held in VGPRs as 16-bit planes for the whole sweep; per
@@ -91,7 +92,7 @@ __device__ __forceinline__ void gp_mfma_tile_bf16(const float4 *lds_a, const s16
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl) a[0][pl].f = lds_a[(pl * KS + s) * 64 + lane];
         }
-        if constexpr (F16) {   // plane 0 = h, plane 1 = 2^11 * l
+        if constexpr (F16) {   // plane 0 = h, plane 1 = l; small terms first
             Frag b0, b1;
             b0.v = xb[0][s];
             b1.v = xb[1][s];

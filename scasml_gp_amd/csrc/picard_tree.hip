@@ -207,8 +207,23 @@ struct Walker {
             for (int m = 0; m < mg; ++m) {                       // MLP.py:175-202
                 if (!owned(TOP)) continue;
                 const uint32_t site = base + (uint32_t)m;
-                const float4 nrm = normals(site);
-                const float4 XT = fma4(vol, nrm, add4(x, drift));
+                float4 nrm, XT;
+                if constexpr (MODE == SCASML_MODE_ACCUMULATE) {
+                    // The emitting pass stored X_T bit for bit: read it back and recover the normals (one rounding
+                    // of a difference of O(1) numbers: ~1e-6 relative) instead of replaying Philox + Box-Muller,
+                    // which is most of this pass's VALU work.  At t = T (vol = 0) they cannot be recovered: replay.
+                    if (__builtin_expect(vol > 0.0f, 1)) {
+                        XT = load_point(site);
+                        const float rv = rcp_fast(vol);
+                        nrm = mul4(fma4(rv, add4(XT, -drift), f4_scale(x, -rv)), mask);
+                    } else {
+                        nrm = normals(site);
+                        XT = fma4(vol, nrm, add4(x, drift));
+                    }
+                } else {
+                    nrm = normals(site);
+                    XT = fma4(vol, nrm, add4(x, drift));
+                }
                 if constexpr (MODE == SCASML_MODE_GENERATE) {
                     emit_point(XT, a.T, site);
                 } else {
