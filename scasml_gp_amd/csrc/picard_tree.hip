@@ -92,10 +92,10 @@ struct Walker {
     }
 
     // equations/equations.py:248-261 at time T; ScaSML.py:61-63 subtracts the surrogate
-    __device__ __forceinline__ float g_terminal(float4 XT, uint32_t site) const {
+    __device__ __forceinline__ float g_terminal(float4 XT, float u_hat) const {
         const float s = a.T + dim_sum(XT);
         float g = 1.0f - rcp_fast(1.0f + exp_fast(s));
-        if constexpr (MODE == SCASML_MODE_ACCUMULATE) g -= gp_at(site).x;
+        if constexpr (MODE == SCASML_MODE_ACCUMULATE) g -= u_hat;
         return g;
     }
     // equations/equations.py:290-304 (MLP.py:27-41) / ScaSML.py:29-47
@@ -204,16 +204,34 @@ struct Walker {
             const float drift = a.mu * tau, vol = a.sigma * sqrt_fast(tau);
             float su = 0.0f;
             float4 sz = f4(0.0f);
+            // ACCUMULATE reads the stored X_T back: the rows of the next sample are requested before this one is
+            // consumed (one dependent HBM round trip per sample otherwise: the pass is latency-bound)
+            const bool readback = MODE == SCASML_MODE_ACCUMULATE && vol > 0.0f;
+            float4 XT_next = f4(0.0f), gp_next = f4(0.0f);
+            if (MODE == SCASML_MODE_ACCUMULATE && !(TOP && a.world > 1)) {
+                if (readback) XT_next = load_point(base);
+                gp_next = gp_at(base);
+            }
             for (int m = 0; m < mg; ++m) {                       // MLP.py:175-202
-                if (!owned(TOP)) continue;
                 const uint32_t site = base + (uint32_t)m;
-                float4 nrm, XT;
+                float4 nrm, XT, gpv = f4(0.0f);
                 if constexpr (MODE == SCASML_MODE_ACCUMULATE) {
-                    // The emitting pass stored X_T bit for bit: read it back and recover the normals (one rounding
-                    // of a difference of O(1) numbers: ~1e-6 relative) instead of replaying Philox + Box-Muller,
-                    // which is most of this pass's VALU work.  At t = T (vol = 0) they cannot be recovered: replay.
-                    if (__builtin_expect(vol > 0.0f, 1)) {
-                        XT = load_point(site);
+                    if (!(TOP && a.world > 1)) {                 // un-sharded: software-pipelined reads
+                        XT = XT_next;
+                        gpv = gp_next;
+                        if (m + 1 < mg) {
+                            if (readback) XT_next = load_point(site + 1);
+                            gp_next = gp_at(site + 1);
+                        }
+                    } else {
+                        if (!owned(TOP)) continue;
+                        if (readback) XT = load_point(site);
+                        gpv = gp_at(site);
+                    }
+                    // The emitting pass stored X_T bit for bit: recover the normals (one rounding of a difference
+                    // of O(1) numbers: ~1e-6 relative) instead of replaying Philox + Box-Muller, which would be most
+                    // of this pass's VALU work.  At t = T (vol = 0) they cannot be recovered: replay.
+                    if (__builtin_expect(readback, 1)) {
                         const float rv = rcp_fast(vol);
                         nrm = mul4(fma4(rv, add4(XT, -drift), f4_scale(x, -rv)), mask);
                     } else {
@@ -221,13 +239,14 @@ struct Walker {
                         XT = fma4(vol, nrm, add4(x, drift));
                     }
                 } else {
+                    if (!owned(TOP)) continue;
                     nrm = normals(site);
                     XT = fma4(vol, nrm, add4(x, drift));
                 }
                 if constexpr (MODE == SCASML_MODE_GENERATE) {
                     emit_point(XT, a.T, site);
                 } else {
-                    const float g = g_terminal(XT, site);
+                    const float g = g_terminal(XT, gpv.x);
                     su += g;
                     sz = fma4(g, nrm, sz);
                 }
