@@ -30,6 +30,13 @@ __global__ __launch_bounds__(1024) void k(float *out, int iters, float a, float 
                 if (MODE == 7) asm volatile("v_mov_b32 %0, %1" : "=v"(v[i]) : "v"(v[(i + 1) & 31]));
                 if (MODE == 8) asm volatile("v_exp_f32 %0, %0" : "+v"(v[i]));
                 if (MODE == 9) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(v[i]) : "v"(v[(i + 3) & 31]));
+                if (MODE == 14) {   // 32 x 32 -> 64 bit multiply-add (Philox rounds)
+                    unsigned long long r;
+                    asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(r) : "v"(v[i]), "v"(av) : "vcc");
+                    asm volatile("v_xor_b32 %0, %1, %2" : "=v"(v[i]) : "v"((unsigned)(r >> 32)), "v"((unsigned)r));
+                }
+                if (MODE == 15) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(v[i]) : "v"(av));
+                if (MODE == 16) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(v[i]) : "v"(av));
                 if (MODE >= 10 && MODE <= 13) {   // v_fma stream with an MFMA every 16 (10, 12) or 8 (11, 13) of them
                     const int every = (MODE & 1) ? 8 : 16;
                     if (i % every == 0) {
@@ -79,6 +86,9 @@ int main() {
     run<7>(out, "v_mov_b32 v,v'");
     run<9>(out, "v_sub_f32 v,v,v'");
     run<8>(out, "v_exp_f32");
+    run<14>(out, "v_mad_u64_u32 + v_xor_b32 (pair)");
+    run<15>(out, "v_mul_hi_u32");
+    run<16>(out, "v_mul_u32_u24");
     printf("64 v_fma_f32 per iteration plus MFMAs (cycles per v_fma, MFMA time included)\n");
     run<10>(out, "+ 4 x mfma 16x16x32 (1 per 16)");
     run<11>(out, "+ 8 x mfma 16x16x32 (1 per 8)");
