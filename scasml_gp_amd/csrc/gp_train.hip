@@ -118,17 +118,25 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int64_t M, i
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int TB = 64;           // output tile edge
 constexpr int LDP = NB + 1;      // LDS leading dimension of a [64][NB] panel (A rows / B^T rows)
+constexpr int64_t kOuterRows = 8 * NB;   // outer block of the two-level factorisation / substitutions
 
-__device__ __forceinline__ void mfma_tile_update(const double (*As)[LDP], const double (*Bt)[LDP], double *C, int64_t ldc,
-                                                 int rows, int cols) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int wr = (wv >> 1) * 32, wc = (wv & 1) * 32;   // quadrant origin
-    const int l15 = lane & 15, l4 = lane >> 4;
-    f64x4 acc[2][2];
+// this wave's 32x32 quadrant of a 64x64 output tile as 2x2 MFMA tiles
+struct TileAcc {
+    f64x4 v[2][2];
+};
+
+__device__ __forceinline__ void mfma_tile_zero(TileAcc &t) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < 2; ++j) t.v[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+}
+
+// t += As (64 x NB) * Bt (64 x NB)^T
+__device__ __forceinline__ void mfma_tile_accumulate(const double (*As)[LDP], const double (*Bt)[LDP], TileAcc &t) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wr = (wv >> 1) * 32, wc = (wv & 1) * 32;   // quadrant origin
+    const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
     for (int k0 = 0; k0 < NB; k0 += 4) {
         double a[2], b[2];
@@ -139,8 +147,15 @@ __device__ __forceinline__ void mfma_tile_update(const double (*As)[LDP], const 
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j) t.v[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], t.v[i][j], 0, 0, 0);
     }
+}
+
+// C -= t (rows x cols valid)
+__device__ __forceinline__ void mfma_tile_subtract(const TileAcc &t, double *C, int64_t ldc, int rows, int cols) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wr = (wv >> 1) * 32, wc = (wv & 1) * 32;
+    const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -148,29 +163,44 @@ __device__ __forceinline__ void mfma_tile_update(const double (*As)[LDP], const 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = wr + 16 * i + l4 + 4 * e, c = wc + 16 * j + l15;
-                if (r < rows && c < cols) C[(int64_t)r * ldc + c] -= acc[i][j][e];
+                if (r < rows && c < cols) C[(int64_t)r * ldc + c] -= t.v[i][j][e];
             }
 }
 
-// (3) trailing update, lower triangle only: C[ti][tj] -= P[ti] * P[tj]^T, 64x64 tile per workgroup
-__global__ __launch_bounds__(256) void chol_update_kernel(double *A, int64_t M, int64_t k0) {
-    const int64_t rest = M - k0 - NB;
-    const int64_t nt = (rest + TB - 1) / TB;
-    const int64_t t = blockIdx.x;   // linear lower-triangular tile index -> (ti, tj), tj <= ti
-    int64_t ti = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    while (ti * (ti + 1) / 2 > t) --ti;
-    const int64_t tj = t - ti * (ti + 1) / 2;
-    if (ti >= nt) return;
+__device__ __forceinline__ void mfma_tile_update(const double (*As)[LDP], const double (*Bt)[LDP], double *C, int64_t ldc,
+                                                 int rows, int cols) {
+    TileAcc t;
+    mfma_tile_zero(t);
+    mfma_tile_accumulate(As, Bt, t);
+    mfma_tile_subtract(t, C, ldc, rows, cols);
+}
+
+// (3) trailing update with a panel of K columns [J, J + K), lower triangle only:
+//   C[r][c] -= sum_k A[r][J + k] * A[c][J + k]   for rows r >= R0, columns R0 <= c < col_end,
+// one 64x64 tile per workgroup, the panel streamed through LDS NB columns at a time while the tile stays in the
+// accumulators: C is read and written ONCE per K columns.  The factorisation below uses it twice: inside an outer
+// panel (K = NB, columns of that panel only) and for the rest of the matrix once per outer panel (K = kOuter) --
+// with K = NB everywhere the factorisation moves M^3 / (3 NB) * 16 bytes through HBM (7 TB at M = 35 000).
+__global__ __launch_bounds__(256) void chol_update_k_kernel(double *A, int64_t M, int64_t J, int64_t K, int64_t R0, int64_t col_end) {
+    const int64_t ti = blockIdx.y, tj = blockIdx.x;
+    if (tj > ti) return;
+    const int64_t r0 = R0 + ti * TB, c0 = R0 + tj * TB;
+    if (r0 >= M || c0 >= col_end) return;
     __shared__ double Pi[TB][LDP], Pj[TB][LDP];
-    const int64_t r0 = k0 + NB + ti * TB, c0 = k0 + NB + tj * TB;
-    for (int idx = threadIdx.x; idx < TB * NB; idx += blockDim.x) {
-        const int rr = idx / NB, cc = idx % NB;
-        Pi[rr][cc] = r0 + rr < M ? A[(r0 + rr) * M + k0 + cc] : 0.0;
-        Pj[rr][cc] = c0 + rr < M ? A[(c0 + rr) * M + k0 + cc] : 0.0;
+    TileAcc t;
+    mfma_tile_zero(t);
+    for (int64_t kk = 0; kk < K; kk += NB) {
+        for (int idx = threadIdx.x; idx < TB * NB; idx += blockDim.x) {
+            const int rr = idx / NB, cc = idx % NB;
+            Pi[rr][cc] = r0 + rr < M ? A[(r0 + rr) * M + J + kk + cc] : 0.0;
+            Pj[rr][cc] = c0 + rr < M ? A[(c0 + rr) * M + J + kk + cc] : 0.0;
+        }
+        __syncthreads();
+        mfma_tile_accumulate(Pi, Pj, t);
+        __syncthreads();
     }
-    __syncthreads();
-    mfma_tile_update(Pi, Pj, A + r0 * M + c0, M, (int)((M - r0) < TB ? (M - r0) : TB), (int)((M - c0) < TB ? (M - c0) : TB));
+    const int64_t rows = M - r0, cols = col_end - c0;
+    mfma_tile_subtract(t, A + r0 * M + c0, M, (int)(rows < TB ? rows : TB), (int)(cols < TB ? cols : TB));
 }
 
 // ---------------------------------------------------------------------------------- TRSM
@@ -207,24 +237,31 @@ __global__ __launch_bounds__(256) void trsm_diag_kernel(const double *L, int64_t
     for (int j = 0; j < NB; ++j) B[(k0 + j) * nrhs + col] = x[j];
 }
 
-// off-diagonal update with the freshly solved block row X_k (NB x nrhs), 64x64 tile per workgroup:
-//   TRANS == 0:  B[r, :] -= L[r, k0:k0+NB] * X_k          for rows r >= k0 + NB
-//   TRANS == 1:  B[r, :] -= L[k0:k0+NB, r]^T * X_k        for rows r < k0
+// off-diagonal update with K freshly solved rows X[J : J + K, :], 64x64 tile per workgroup, the K dimension streamed
+// through LDS NB at a time while the tile stays in the accumulators (B is read and written once per K rows):
+//   TRANS == 0:  B[r, :] -= L[r, J:J+K] * X[J:J+K, :]          for rows rbase <= r < rend  (rows below the solved ones)
+//   TRANS == 1:  B[r, :] -= L[J:J+K, r]^T * X[J:J+K, :]        for rows rbase <= r < rend  (rows above them)
 // tri != 0: only tiles on or below the block diagonal (c0 < r0 + TB) are updated -- the lower triangle of a symmetric result
 template <int TRANS>
-__global__ __launch_bounds__(256) void trsm_update_kernel(const double *L, int64_t M, double *B, int64_t nrhs, int64_t k0, int tri) {
+__global__ __launch_bounds__(256) void trsm_update_kernel(const double *L, int64_t M, double *B, int64_t nrhs, int64_t J, int64_t K,
+                                                          int64_t rbase, int64_t rend, int tri) {
     __shared__ double Ls[TB][LDP], Xt[TB][LDP];
-    const int64_t rbase = TRANS == 0 ? k0 + NB : 0, rend = TRANS == 0 ? M : k0;
     const int64_t r0 = rbase + (int64_t)blockIdx.y * TB, c0 = (int64_t)blockIdx.x * TB;
-    if (tri && c0 >= r0 + TB) return;   // block-uniform
-    for (int idx = threadIdx.x; idx < TB * NB; idx += blockDim.x) {
-        const int rr = idx / NB, cc = idx % NB;
-        Ls[rr][cc] = r0 + rr < rend ? (TRANS == 0 ? L[(r0 + rr) * M + k0 + cc] : L[(k0 + cc) * M + r0 + rr]) : 0.0;
-        Xt[rr][cc] = c0 + rr < nrhs ? B[(k0 + cc) * nrhs + c0 + rr] : 0.0;   // Xt[col][k]
+    if (r0 >= rend || (tri && c0 >= r0 + TB)) return;   // block-uniform
+    TileAcc t;
+    mfma_tile_zero(t);
+    for (int64_t kk = J; kk < J + K; kk += NB) {
+        for (int idx = threadIdx.x; idx < TB * NB; idx += blockDim.x) {
+            const int rr = idx / NB, cc = idx % NB;
+            Ls[rr][cc] = r0 + rr < rend ? (TRANS == 0 ? L[(r0 + rr) * M + kk + cc] : L[(kk + cc) * M + r0 + rr]) : 0.0;
+            Xt[rr][cc] = c0 + rr < nrhs ? B[(kk + cc) * nrhs + c0 + rr] : 0.0;   // Xt[col][k]
+        }
+        __syncthreads();
+        mfma_tile_accumulate(Ls, Xt, t);
+        __syncthreads();
     }
-    __syncthreads();
     const int64_t rows = rend - r0, cols = nrhs - c0;
-    mfma_tile_update(Ls, Xt, B + r0 * nrhs + c0, nrhs, (int)(rows < TB ? rows : TB), (int)(cols < TB ? cols : TB));
+    mfma_tile_subtract(t, B + r0 * nrhs + c0, nrhs, (int)(rows < TB ? rows : TB), (int)(cols < TB ? cols : TB));
 }
 
 // ---------------------------------------------------------------------------------- Newton system
@@ -329,13 +366,24 @@ extern "C" int scasml_cholesky(double *A, int64_t M, double nugget, int32_t *inf
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(info_dev, 0, sizeof(int32_t), s) != hipSuccess) return fail(SCASML_ERR_HIP, "cholesky: memset failed");
     if (nugget != 0.0) hipLaunchKernelGGL(add_diag_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, A, M, nugget);
-    for (int64_t k0 = 0; k0 < M; k0 += NB) {
-        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(NB, NB), 0, s, A, M, k0, info_dev);
-        const int64_t rest = M - k0 - NB;
-        if (rest <= 0) break;
-        hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)((rest + 255) / 256)), dim3(256), 0, s, A, M, k0);
-        const int64_t nt = (rest + TB - 1) / TB;
-        hipLaunchKernelGGL(chol_update_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, s, A, M, k0);
+    // two-level right-looking factorisation: columns are eliminated NB at a time inside an outer panel of kOuter
+    // columns (updates confined to that panel's columns), then the whole trailing matrix is updated once with K = kOuter
+    constexpr int64_t kOuter = kOuterRows;
+    auto update = [&](int64_t J, int64_t K, int64_t R0, int64_t col_end) {
+        const int64_t nti = (M - R0 + TB - 1) / TB, ntj = (col_end - R0 + TB - 1) / TB;
+        if (nti <= 0 || ntj <= 0) return;
+        hipLaunchKernelGGL(chol_update_k_kernel, dim3((unsigned)ntj, (unsigned)nti), dim3(256), 0, s, A, M, J, K, R0, col_end);
+    };
+    for (int64_t J = 0; J < M; J += kOuter) {
+        const int64_t jend = J + kOuter < M ? J + kOuter : M;
+        for (int64_t k0 = J; k0 < jend; k0 += NB) {
+            hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(NB, NB), 0, s, A, M, k0, info_dev);
+            const int64_t rest = M - k0 - NB;
+            if (rest <= 0) break;
+            hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)((rest + 255) / 256)), dim3(256), 0, s, A, M, k0);
+            if (k0 + NB < jend) update(k0, NB, k0 + NB, jend);
+        }
+        if (jend < M) update(J, jend - J, jend, M);
     }
     hipLaunchKernelGGL(zero_upper_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)M), dim3(256), 0, s, A, M);
     return check_launch("cholesky launch");
@@ -348,17 +396,30 @@ extern "C" int scasml_trsm_lower(const double *L, int64_t M, double *Bmat, int64
     if (M > 65535 * (int64_t)NB) return fail(SCASML_ERR_UNSUPPORTED, "trsm: M too large for this build");
     hipStream_t s = (hipStream_t)stream;
     const unsigned cb = (unsigned)((nrhs + 255) / 256), ct = (unsigned)((nrhs + TB - 1) / TB);
-    const int64_t nblk = M / NB;
+    // two-level blocked substitution (see scasml_cholesky): NB rows at a time inside a group of kOuterRows rows, then
+    // one update of all remaining rows per group
+    auto tiles = [](int64_t n) { return (unsigned)((n + TB - 1) / TB); };
     if (trans == 0) {
-        for (int64_t k = 0; k < nblk; ++k) {
-            hipLaunchKernelGGL(trsm_diag_kernel<0>, dim3(cb), dim3(256), 0, s, L, M, Bmat, nrhs, k * NB, nrhs);
-            if (k + 1 < nblk)
-                hipLaunchKernelGGL(trsm_update_kernel<0>, dim3(ct, (unsigned)(((nblk - k - 1) * NB + TB - 1) / TB)), dim3(256), 0, s, L, M, Bmat, nrhs, k * NB, 0);
+        for (int64_t J = 0; J < M; J += kOuterRows) {
+            const int64_t jend = J + kOuterRows < M ? J + kOuterRows : M;
+            for (int64_t k0 = J; k0 < jend; k0 += NB) {
+                hipLaunchKernelGGL(trsm_diag_kernel<0>, dim3(cb), dim3(256), 0, s, L, M, Bmat, nrhs, k0, nrhs);
+                if (k0 + NB < jend)
+                    hipLaunchKernelGGL(trsm_update_kernel<0>, dim3(ct, tiles(jend - k0 - NB)), dim3(256), 0, s, L, M, Bmat, nrhs, k0, (int64_t)NB, k0 + NB, jend, 0);
+            }
+            if (jend < M)
+                hipLaunchKernelGGL(trsm_update_kernel<0>, dim3(ct, tiles(M - jend)), dim3(256), 0, s, L, M, Bmat, nrhs, J, jend - J, jend, M, 0);
         }
     } else {
-        for (int64_t k = nblk - 1; k >= 0; --k) {
-            hipLaunchKernelGGL(trsm_diag_kernel<1>, dim3(cb), dim3(256), 0, s, L, M, Bmat, nrhs, k * NB, nrhs);
-            if (k > 0) hipLaunchKernelGGL(trsm_update_kernel<1>, dim3(ct, (unsigned)((k * NB + TB - 1) / TB)), dim3(256), 0, s, L, M, Bmat, nrhs, k * NB, 0);
+        for (int64_t jend = M; jend > 0; jend -= kOuterRows) {
+            const int64_t J = jend > kOuterRows ? jend - kOuterRows : 0;
+            for (int64_t k0 = jend - NB; k0 >= J; k0 -= NB) {
+                hipLaunchKernelGGL(trsm_diag_kernel<1>, dim3(cb), dim3(256), 0, s, L, M, Bmat, nrhs, k0, nrhs);
+                if (k0 > J)
+                    hipLaunchKernelGGL(trsm_update_kernel<1>, dim3(ct, tiles(k0 - J)), dim3(256), 0, s, L, M, Bmat, nrhs, k0, (int64_t)NB, J, k0, 0);
+            }
+            if (J > 0)
+                hipLaunchKernelGGL(trsm_update_kernel<1>, dim3(ct, tiles(J)), dim3(256), 0, s, L, M, Bmat, nrhs, J, jend - J, (int64_t)0, J, 0);
         }
     }
     return check_launch("trsm launch");
@@ -401,21 +462,29 @@ extern "C" int scasml_cholesky_inverse(const double *L, int64_t M, double *A, vo
     if (M % NB) return fail(SCASML_ERR_UNSUPPORTED, "cholesky_inverse: M=%lld is not a multiple of %d", (long long)M, NB);
     if (M > 65535 * (int64_t)NB) return fail(SCASML_ERR_UNSUPPORTED, "cholesky_inverse: M too large for this build");
     hipStream_t s = (hipStream_t)stream;
-    const int64_t nblk = M / NB;
+    auto tiles = [](int64_t n) { return (unsigned)((n + TB - 1) / TB); };
     hipLaunchKernelGGL(set_identity_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)M), dim3(256), 0, s, A, M);
-    for (int64_t k = 0; k < nblk; ++k) {                    // X = L^-1: block row k is nonzero in columns < (k+1)*NB
-        const int64_t lim = (k + 1) * NB;
-        hipLaunchKernelGGL(trsm_diag_kernel<0>, dim3((unsigned)((lim + 255) / 256)), dim3(256), 0, s, L, M, A, M, k * NB, lim);
-        if (k + 1 < nblk)
-            hipLaunchKernelGGL(trsm_update_kernel<0>, dim3((unsigned)((lim + TB - 1) / TB), (unsigned)(((nblk - k - 1) * NB + TB - 1) / TB)),
-                               dim3(256), 0, s, L, M, A, M, k * NB, 0);
+    for (int64_t J = 0; J < M; J += kOuterRows) {            // X = L^-1: row r is nonzero in columns <= r
+        const int64_t jend = J + kOuterRows < M ? J + kOuterRows : M;
+        for (int64_t k0 = J; k0 < jend; k0 += NB) {
+            const int64_t lim = k0 + NB;
+            hipLaunchKernelGGL(trsm_diag_kernel<0>, dim3((unsigned)((lim + 255) / 256)), dim3(256), 0, s, L, M, A, M, k0, lim);
+            if (k0 + NB < jend)
+                hipLaunchKernelGGL(trsm_update_kernel<0>, dim3(tiles(lim), tiles(jend - k0 - NB)), dim3(256), 0, s, L, M, A, M, k0, (int64_t)NB, k0 + NB, jend, 0);
+        }
+        if (jend < M)
+            hipLaunchKernelGGL(trsm_update_kernel<0>, dim3(tiles(jend), tiles(M - jend)), dim3(256), 0, s, L, M, A, M, J, jend - J, jend, M, 0);
     }
-    for (int64_t k = nblk - 1; k >= 0; --k) {               // Z = L^-T X, lower triangle only
-        const int64_t lim = (k + 1) * NB;
-        hipLaunchKernelGGL(trsm_diag_kernel<1>, dim3((unsigned)((lim + 255) / 256)), dim3(256), 0, s, L, M, A, M, k * NB, lim);
-        if (k > 0)
-            hipLaunchKernelGGL(trsm_update_kernel<1>, dim3((unsigned)((k * NB + TB - 1) / TB), (unsigned)((k * NB + TB - 1) / TB)),
-                               dim3(256), 0, s, L, M, A, M, k * NB, 1);
+    for (int64_t jend = M; jend > 0; jend -= kOuterRows) {   // Z = L^-T X, lower triangle only
+        const int64_t J = jend > kOuterRows ? jend - kOuterRows : 0;
+        for (int64_t k0 = jend - NB; k0 >= J; k0 -= NB) {
+            const int64_t lim = k0 + NB;
+            hipLaunchKernelGGL(trsm_diag_kernel<1>, dim3((unsigned)((lim + 255) / 256)), dim3(256), 0, s, L, M, A, M, k0, lim);
+            if (k0 > J)
+                hipLaunchKernelGGL(trsm_update_kernel<1>, dim3(tiles(k0), tiles(k0 - J)), dim3(256), 0, s, L, M, A, M, k0, (int64_t)NB, J, k0, 1);
+        }
+        if (J > 0)
+            hipLaunchKernelGGL(trsm_update_kernel<1>, dim3(tiles(J), tiles(J)), dim3(256), 0, s, L, M, A, M, J, jend - J, (int64_t)0, J, 1);
     }
     hipLaunchKernelGGL(mirror_lower_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)M), dim3(256), 0, s, A, M);
     return check_launch("cholesky_inverse launch");
