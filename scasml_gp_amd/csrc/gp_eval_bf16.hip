@@ -325,7 +325,7 @@ static int launch_cfg(const GpArgs &g, hipStream_t s) {
 template <int KS, int SPLIT, bool F16, bool YEXACT>
 static int launch_one(const GpArgs &g, hipStream_t s) {
     // three waves per SIMD while the 16-bit planes of the point tile (SPLIT*4*KS VGPRs) leave room under 168
-    constexpr int REGS = SPLIT * 4 * KS + (F16 ? 16 : 0);       // point-tile planes + second accumulator
+    constexpr int REGS = SPLIT * 4 * KS + (F16 ? 16 : 0);       // point-tile planes (+ head-room the fp16 prologue needs)
     constexpr int WPS = REGS <= 72 ? 4 : (REGS <= 96 ? 3 : 2);  // waves per SIMD the VGPR budget allows
     constexpr int BPC = WPS == 4 ? 2 : 1;
     constexpr int WPB = WPS * 4 / BPC;
