@@ -172,3 +172,13 @@ def test_no_spills_inside_the_gp_tile_loops():
         stage_bytes = (planes * int(ks) * 256 + 512) * 4
         bpc = int(re.search(r"<\d+, \d+, \d+, \w+, (\d+),", line).group(1))
         assert 4 * stage_bytes * bpc > 144 * 1024, "spill inside a counted-vmcnt tile loop: " + line
+
+
+def test_header_is_plain_c(tmp_path):
+    """The drop-in boundary is a C ABI: include/scasml_hip.h must compile as C99 with no extensions."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "t.c"
+    src.write_text('#include "scasml_hip.h"\nint main(void) { return (int)sizeof(scasml_plan) > 0 ? 0 : 1; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(root, "include"),
+                    "-c", str(src), "-o", str(tmp_path / "t.o")], check=True)

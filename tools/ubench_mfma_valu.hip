@@ -1,4 +1,6 @@
-// Microbenchmark: do v_mfma_f32_32x32x2_f32 and f32 VALU co-execute on a gfx950 SIMD?
+// Microbenchmark (superseded by ubench_valu_rate.hip / ubench_valu_forms.hip): do v_mfma_f32_32x32x2_f32 and f32 VALU
+// co-execute on a gfx950 SIMD?  NOTE: the "VALU" loops below are plain C++ and hipcc SLP-packs them into v_pk_fma_f32,
+// which never overlaps with MFMA -- the conclusions first drawn from this file held for packed f32 only.
 // Variants (1024-thread grid x 256 CUs, N iterations each):
 //   0: MFMA only            (2 independent accumulators, 8 MFMAs / iter)
 //   1: VALU only            (32 independent v_fma_f32 / iter)
