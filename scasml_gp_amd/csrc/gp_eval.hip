@@ -30,13 +30,10 @@ namespace scasml {
 
 // NK4 = kp / 8 float4 per lane per row; PT = point tiles (of 32) per wave.
 //
-// Workgroup = 8 waves (512 threads); wave w and wave w+4 share a SIMD (MI355X_MICROARCH.md "Two waves
-// per SIMD").  Per collocation tile the workgroup stages [NK4 KiB of A fragments | 1 KiB of
-// coefficients] into one of three LDS slots with global_load_lds (16 B per lane, lane-linear image =
-// the pre-packed fragment order), one tile ahead, and meets at ONE barrier per tile.  The two SIMD
-// partners run half a tile apart: waves 0-3 do MFMA(t) then epilogue(t); waves 4-7 do epilogue(t-1)
-// then MFMA(t), keeping their accumulators across the barrier -- so on every SIMD one wave's VALU
-// epilogue runs under the other's MFMAs and the matrix pipe stays fed.
+// Workgroup = 8 waves (512 threads).  Per collocation tile the workgroup stages [NK4 KiB of A fragments | 2 KiB of
+// constants] into one of three LDS slots with global_load_lds (16 B per lane, lane-linear image = the pre-packed
+// fragment order), one tile ahead, and meets at ONE barrier per tile.  This FP32-input MFMA kernel is the
+// arithmetic reference mode (GP.eval_split = 0); the production kernels are in gp_eval_bf16.hip.
 template <int NK4>
 __device__ __forceinline__ constexpr int gp_stage_floats() { return NK4 * 256 + 512; }
 
@@ -72,9 +69,6 @@ __global__ __launch_bounds__(512, 2) void gp_eval_kernel(const GpArgs g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // 3 slots
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int col = lane & 31, half = lane >> 5;
-    // the half-tile-late SIMD partner; readfirstlane makes the role a scalar (provably wave-uniform)
-    // condition, so the barriers inside the two role loops are never reached under a partial EXEC
-    const bool late = __builtin_amdgcn_readfirstlane(wv) >= 4;
     const int64_t p0 = ((int64_t)blockIdx.x * 8 + wv) * (32 * PT);
     const int n_tiles = g.n_pad / 32;
 
@@ -137,21 +131,11 @@ __global__ __launch_bounds__(512, 2) void gp_eval_kernel(const GpArgs g) {
 
     f32x16 acc[PT];
     __syncthreads();  // tile 0 has landed (the barrier drains the LDS-DMA: vmcnt(0))
-    if (!late) {
-        for (int jt = 0; jt < n_tiles; ++jt) {
-            if (jt + 1 < n_tiles) stage(jt + 1, (jt + 1) % 3);
-            gp_mfma_tile<NK4, PT>(view(jt % 3), xf, acc, lane);
-            gp_epilogue_tile<PT>(view(jt % 3), acc, c, half, nx, sx, tx, au, at, ad, al);
-            __syncthreads();
-        }
-    } else {
-        for (int jt = 0; jt < n_tiles; ++jt) {
-            if (jt + 1 < n_tiles) stage(jt + 1, (jt + 1) % 3);
-            if (jt > 0) gp_epilogue_tile<PT>(view((jt - 1) % 3), acc, c, half, nx, sx, tx, au, at, ad, al);
-            gp_mfma_tile<NK4, PT>(view(jt % 3), xf, acc, lane);
-            __syncthreads();
-        }
-        gp_epilogue_tile<PT>(view((n_tiles - 1) % 3), acc, c, half, nx, sx, tx, au, at, ad, al);
+    for (int jt = 0; jt < n_tiles; ++jt) {
+        if (jt + 1 < n_tiles) stage(jt + 1, (jt + 1) % 3);
+        gp_mfma_tile<NK4, PT>(view(jt % 3), xf, acc, lane);
+        gp_epilogue_tile<PT>(view(jt % 3), acc, c, half, nx, sx, tx, au, at, ad, al);
+        __syncthreads();
     }
 
     // ---- combine the two half-waves (rows 4h..4h+3 of each group) and store -------------------
