@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int64_t M, i
 // MFMA tiles; operands come from LDS panels with a padded leading dimension.
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int TB = 64;           // output tile edge
-constexpr int LDP = NB + 1;      // LDS leading dimension of a [64][NB] panel (A rows / B^T rows)
+constexpr int LDP = NB + 2;      // LDS leading dimension of a [64][NB] panel (A rows / B^T rows): 2 (row LDP + k) mod 64 is distinct over a ds_read_b64 group (16 rows x 2 k)
 constexpr int64_t kOuterRows = 8 * NB;   // outer block of the two-level factorisation / substitutions
 
 // this wave's 32x32 quadrant of a 64x64 output tile as 2x2 MFMA tiles
@@ -186,18 +186,39 @@ __global__ __launch_bounds__(256) void chol_update_k_kernel(double *A, int64_t M
     if (tj > ti) return;
     const int64_t r0 = R0 + ti * TB, c0 = R0 + tj * TB;
     if (r0 >= M || c0 >= col_end) return;
-    __shared__ double Pi[TB][LDP], Pj[TB][LDP];
+    // two LDS panels per operand: the global loads of chunk k+1 are in flight while chunk k feeds the matrix cores
+    __shared__ double Pi[2][TB][LDP], Pj[2][TB][LDP];
+    constexpr int PER = TB * NB / 256;            // elements of each panel chunk per thread
+    double ri[PER], rj[PER];
+    auto fetch = [&](int64_t kk) {
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int idx = threadIdx.x + e * 256, rr = idx / NB, cc = idx % NB;
+            ri[e] = r0 + rr < M ? A[(r0 + rr) * M + J + kk + cc] : 0.0;
+            rj[e] = c0 + rr < M ? A[(c0 + rr) * M + J + kk + cc] : 0.0;
+        }
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int idx = threadIdx.x + e * 256, rr = idx / NB, cc = idx % NB;
+            Pi[buf][rr][cc] = ri[e];
+            Pj[buf][rr][cc] = rj[e];
+        }
+    };
     TileAcc t;
     mfma_tile_zero(t);
+    fetch(0);
+    park(0);
+    __syncthreads();
+    int cur = 0;
     for (int64_t kk = 0; kk < K; kk += NB) {
-        for (int idx = threadIdx.x; idx < TB * NB; idx += blockDim.x) {
-            const int rr = idx / NB, cc = idx % NB;
-            Pi[rr][cc] = r0 + rr < M ? A[(r0 + rr) * M + J + kk + cc] : 0.0;
-            Pj[rr][cc] = c0 + rr < M ? A[(c0 + rr) * M + J + kk + cc] : 0.0;
-        }
+        const bool more = kk + NB < K;
+        if (more) fetch(kk + NB);
+        mfma_tile_accumulate(Pi[cur], Pj[cur], t);
+        if (more) park(cur ^ 1);
         __syncthreads();
-        mfma_tile_accumulate(Pi, Pj, t);
-        __syncthreads();
+        cur ^= 1;
     }
     const int64_t rows = M - r0, cols = col_end - c0;
     mfma_tile_subtract(t, A + r0 * M + c0, M, (int)(rows < TB ? rows : TB), (int)(cols < TB ? cols : TB));
@@ -245,20 +266,40 @@ __global__ __launch_bounds__(256) void trsm_diag_kernel(const double *L, int64_t
 template <int TRANS>
 __global__ __launch_bounds__(256) void trsm_update_kernel(const double *L, int64_t M, double *B, int64_t nrhs, int64_t J, int64_t K,
                                                           int64_t rbase, int64_t rend, int tri) {
-    __shared__ double Ls[TB][LDP], Xt[TB][LDP];
+    __shared__ double Ls[2][TB][LDP], Xt[2][TB][LDP];   // double-buffered like chol_update_k_kernel
     const int64_t r0 = rbase + (int64_t)blockIdx.y * TB, c0 = (int64_t)blockIdx.x * TB;
     if (r0 >= rend || (tri && c0 >= r0 + TB)) return;   // block-uniform
+    constexpr int PER = TB * NB / 256;
+    double rl[PER], rx[PER];
+    auto fetch = [&](int64_t kk) {
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int idx = threadIdx.x + e * 256, rr = idx / NB, cc = idx % NB;
+            rl[e] = r0 + rr < rend ? (TRANS == 0 ? L[(r0 + rr) * M + kk + cc] : L[(kk + cc) * M + r0 + rr]) : 0.0;
+            rx[e] = c0 + rr < nrhs ? B[(kk + cc) * nrhs + c0 + rr] : 0.0;   // Xt[col][k]
+        }
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int idx = threadIdx.x + e * 256, rr = idx / NB, cc = idx % NB;
+            Ls[buf][rr][cc] = rl[e];
+            Xt[buf][rr][cc] = rx[e];
+        }
+    };
     TileAcc t;
     mfma_tile_zero(t);
+    fetch(J);
+    park(0);
+    __syncthreads();
+    int cur = 0;
     for (int64_t kk = J; kk < J + K; kk += NB) {
-        for (int idx = threadIdx.x; idx < TB * NB; idx += blockDim.x) {
-            const int rr = idx / NB, cc = idx % NB;
-            Ls[rr][cc] = r0 + rr < rend ? (TRANS == 0 ? L[(r0 + rr) * M + kk + cc] : L[(kk + cc) * M + r0 + rr]) : 0.0;
-            Xt[rr][cc] = c0 + rr < nrhs ? B[(kk + cc) * nrhs + c0 + rr] : 0.0;   // Xt[col][k]
-        }
+        const bool more = kk + NB < J + K;
+        if (more) fetch(kk + NB);
+        mfma_tile_accumulate(Ls[cur], Xt[cur], t);
+        if (more) park(cur ^ 1);
         __syncthreads();
-        mfma_tile_accumulate(Ls, Xt, t);
-        __syncthreads();
+        cur ^= 1;
     }
     const int64_t rows = rend - r0, cols = nrhs - c0;
     mfma_tile_subtract(t, B + r0 * nrhs + c0, nrhs, (int)(rows < TB ? rows : TB), (int)(cols < TB ? cols : TB));
