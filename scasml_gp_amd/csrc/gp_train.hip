@@ -110,56 +110,65 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int64_t M, i
     for (int j = 0; j < NB; ++j) A[r * M + k0 + j] = x[j];
 }
 
-// ---- C(64x64) -= A(64x32) * B(32x64) on the FP64 matrix cores -------------------------------------
+// ---- C(TB x TB) -= A(TB x K) * B(K x TB) on the FP64 matrix cores ------------------------------------
 // v_mfma_f64_16x16x4_f64: lane l supplies A[row = l&15][k = l>>4] and B[k = l>>4][col = l&15]; the four
 // results of a lane are C[row = (l>>4) + 4*i][col = l&15], i = 0..3 (cdna_hip_programming.md section 3: the
-// f64 C/D map differs from the f32 one).  Four waves per workgroup, each owning a 32x32 quadrant = 2x2
-// MFMA tiles; operands come from LDS panels with a padded leading dimension.
+// f64 C/D map differs from the f32 one).  Four waves per workgroup, each owning a quadrant of NT x NT MFMA tiles:
+// NT = 2 -> 64 x 64 output tile (the one in use: the K = 256 updates of large matrices are L2-bandwidth-bound at
+// 6.4 flop/B with it, 32 TFLOP/s; NT = 4 -> 128 x 128 doubles the flops per operand byte but needs 438 VGPRs, one wave
+// per SIMD, and measured 23 TFLOP/s).  Operands come from LDS panels
+// [TB][LDP] (A rows / B^T rows), double-buffered: the global loads of chunk k+1 are in flight while chunk k feeds
+// the matrix cores.
 typedef double f64x4 __attribute__((ext_vector_type(4)));
-constexpr int TB = 64;           // output tile edge
-constexpr int LDP = NB + 2;      // LDS leading dimension of a [64][NB] panel (A rows / B^T rows): 2 (row LDP + k) mod 64 is distinct over a ds_read_b64 group (16 rows x 2 k)
+constexpr int TB = 64;           // output tile edge of the NT = 2 kernels (grid geometry of the callers)
+constexpr int LDP = NB + 2;      // padded leading dimension: 2 (row LDP + k) mod 64 is distinct over a ds_read_b64 group (16 rows x 2 k)
 constexpr int64_t kOuterRows = 8 * NB;   // outer block of the two-level factorisation / substitutions
 
-// this wave's 32x32 quadrant of a 64x64 output tile as 2x2 MFMA tiles
+template <int NT>
 struct TileAcc {
-    f64x4 v[2][2];
+    f64x4 v[NT][NT];
 };
+template <int NT>
+constexpr size_t tile_lds_bytes() { return (size_t)2 * 2 * (32 * NT) * LDP * sizeof(double); }   // 2 operands x 2 buffers
 
-__device__ __forceinline__ void mfma_tile_zero(TileAcc &t) {
+template <int NT>
+__device__ __forceinline__ void mfma_tile_zero(TileAcc<NT> &t) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) t.v[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < NT; ++j) t.v[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
 }
 
-// t += As (64 x NB) * Bt (64 x NB)^T
-__device__ __forceinline__ void mfma_tile_accumulate(const double (*As)[LDP], const double (*Bt)[LDP], TileAcc &t) {
+// t += As (TB x NB) * Bt (TB x NB)^T
+template <int NT>
+__device__ __forceinline__ void mfma_tile_accumulate(const double (*As)[LDP], const double (*Bt)[LDP], TileAcc<NT> &t) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int wr = (wv >> 1) * 32, wc = (wv & 1) * 32;   // quadrant origin
+    const int wr = (wv >> 1) * (16 * NT), wc = (wv & 1) * (16 * NT);   // quadrant origin
     const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
     for (int k0 = 0; k0 < NB; k0 += 4) {
-        double a[2], b[2];
+        double a[NT], b[NT];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = As[wr + 16 * i + l15][k0 + l4];
+        for (int i = 0; i < NT; ++i) a[i] = As[wr + 16 * i + l15][k0 + l4];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) b[j] = Bt[wc + 16 * j + l15][k0 + l4];
+        for (int j = 0; j < NT; ++j) b[j] = Bt[wc + 16 * j + l15][k0 + l4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NT; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) t.v[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], t.v[i][j], 0, 0, 0);
+            for (int j = 0; j < NT; ++j) t.v[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], t.v[i][j], 0, 0, 0);
     }
 }
 
 // C -= t (rows x cols valid)
-__device__ __forceinline__ void mfma_tile_subtract(const TileAcc &t, double *C, int64_t ldc, int rows, int cols) {
+template <int NT>
+__device__ __forceinline__ void mfma_tile_subtract(const TileAcc<NT> &t, double *C, int64_t ldc, int64_t rows, int64_t cols) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int wr = (wv >> 1) * 32, wc = (wv & 1) * 32;
+    const int wr = (wv >> 1) * (16 * NT), wc = (wv & 1) * (16 * NT);
     const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = wr + 16 * i + l4 + 4 * e, c = wc + 16 * j + l15;
@@ -167,61 +176,62 @@ __device__ __forceinline__ void mfma_tile_subtract(const TileAcc &t, double *C, 
             }
 }
 
-__device__ __forceinline__ void mfma_tile_update(const double (*As)[LDP], const double (*Bt)[LDP], double *C, int64_t ldc,
-                                                 int rows, int cols) {
-    TileAcc t;
-    mfma_tile_zero(t);
-    mfma_tile_accumulate(As, Bt, t);
-    mfma_tile_subtract(t, C, ldc, rows, cols);
-}
-
-// (3) trailing update with a panel of K columns [J, J + K), lower triangle only:
-//   C[r][c] -= sum_k A[r][J + k] * A[c][J + k]   for rows r >= R0, columns R0 <= c < col_end,
-// one 64x64 tile per workgroup, the panel streamed through LDS NB columns at a time while the tile stays in the
-// accumulators: C is read and written ONCE per K columns.  The factorisation below uses it twice: inside an outer
-// panel (K = NB, columns of that panel only) and for the rest of the matrix once per outer panel (K = kOuter) --
-// with K = NB everywhere the factorisation moves M^3 / (3 NB) * 16 bytes through HBM (7 TB at M = 35 000).
-__global__ __launch_bounds__(256) void chol_update_k_kernel(double *A, int64_t M, int64_t J, int64_t K, int64_t R0, int64_t col_end) {
-    const int64_t ti = blockIdx.y, tj = blockIdx.x;
-    if (tj > ti) return;
-    const int64_t r0 = R0 + ti * TB, c0 = R0 + tj * TB;
-    if (r0 >= M || c0 >= col_end) return;
-    // two LDS panels per operand: the global loads of chunk k+1 are in flight while chunk k feeds the matrix cores
-    __shared__ double Pi[2][TB][LDP], Pj[2][TB][LDP];
-    constexpr int PER = TB * NB / 256;            // elements of each panel chunk per thread
-    double ri[PER], rj[PER];
-    auto fetch = [&](int64_t kk) {
-#pragma unroll
-        for (int e = 0; e < PER; ++e) {
-            const int idx = threadIdx.x + e * 256, rr = idx / NB, cc = idx % NB;
-            ri[e] = r0 + rr < M ? A[(r0 + rr) * M + J + kk + cc] : 0.0;
-            rj[e] = c0 + rr < M ? A[(c0 + rr) * M + J + kk + cc] : 0.0;
-        }
-    };
+// The K loop shared by the Cholesky and triangular-solve updates: `fetch(kk, ra, rb)` loads this thread's elements
+// of the two operand chunks of columns [kk, kk + NB) into registers (element e of a thread is panel entry
+// idx = tid + 256 e, row idx / NB, column idx % NB).
+template <int NT, class Fetch>
+__device__ __forceinline__ void mfma_tile_k_loop(double *smem, int64_t k_begin, int64_t k_end, Fetch fetch, TileAcc<NT> &t) {
+    constexpr int TBX = 32 * NT, PER = TBX * NB / 256;
+    double (*Pa)[TBX][LDP] = reinterpret_cast<double (*)[TBX][LDP]>(smem);
+    double (*Pb)[TBX][LDP] = reinterpret_cast<double (*)[TBX][LDP]>(smem + 2 * TBX * LDP);
+    double ra[PER], rb[PER];
     auto park = [&](int buf) {
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
             const int idx = threadIdx.x + e * 256, rr = idx / NB, cc = idx % NB;
-            Pi[buf][rr][cc] = ri[e];
-            Pj[buf][rr][cc] = rj[e];
+            Pa[buf][rr][cc] = ra[e];
+            Pb[buf][rr][cc] = rb[e];
         }
     };
-    TileAcc t;
-    mfma_tile_zero(t);
-    fetch(0);
+    fetch(k_begin, ra, rb);
     park(0);
     __syncthreads();
     int cur = 0;
-    for (int64_t kk = 0; kk < K; kk += NB) {
-        const bool more = kk + NB < K;
-        if (more) fetch(kk + NB);
-        mfma_tile_accumulate(Pi[cur], Pj[cur], t);
+    for (int64_t kk = k_begin; kk < k_end; kk += NB) {
+        const bool more = kk + NB < k_end;
+        if (more) fetch(kk + NB, ra, rb);
+        mfma_tile_accumulate<NT>(Pa[cur], Pb[cur], t);
         if (more) park(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
-    const int64_t rows = M - r0, cols = col_end - c0;
-    mfma_tile_subtract(t, A + r0 * M + c0, M, (int)(rows < TB ? rows : TB), (int)(cols < TB ? cols : TB));
+}
+
+// (3) trailing update with a panel of K columns [J, J + K), lower triangle only:
+//   C[r][c] -= sum_k A[r][J + k] * A[c][J + k]   for rows r >= R0, columns R0 <= c < col_end,
+// one tile per workgroup, the panel streamed through LDS NB columns at a time while the tile stays in the
+// accumulators: C is read and written ONCE per K columns.  The factorisation below uses it twice: inside an outer
+// panel (K = NB, columns of that panel only) and for the rest of the matrix once per outer panel (K = kOuter) --
+// with K = NB everywhere the factorisation moves M^3 / (3 NB) * 16 bytes through HBM (7 TB at M = 35 000).
+template <int NT>
+__global__ __launch_bounds__(256) void chol_update_k_kernel(double *A, int64_t M, int64_t J, int64_t K, int64_t R0, int64_t col_end) {
+    constexpr int TBX = 32 * NT, PER = TBX * NB / 256;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int64_t ti = blockIdx.y, tj = blockIdx.x;
+    if (tj > ti) return;
+    const int64_t r0 = R0 + ti * TBX, c0 = R0 + tj * TBX;
+    if (r0 >= M || c0 >= col_end) return;
+    TileAcc<NT> t;
+    mfma_tile_zero(t);
+    mfma_tile_k_loop<NT>(smem, J, J + K, [&](int64_t kk, double (&ra)[PER], double (&rb)[PER]) {
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int idx = threadIdx.x + e * 256, rr = idx / NB, cc = idx % NB;
+            ra[e] = r0 + rr < M ? A[(r0 + rr) * M + kk + cc] : 0.0;
+            rb[e] = c0 + rr < M ? A[(c0 + rr) * M + kk + cc] : 0.0;
+        }
+    }, t);
+    mfma_tile_subtract<NT>(t, A + r0 * M + c0, M, M - r0, col_end - c0);
 }
 
 // ---------------------------------------------------------------------------------- TRSM
@@ -263,46 +273,24 @@ __global__ __launch_bounds__(256) void trsm_diag_kernel(const double *L, int64_t
 //   TRANS == 0:  B[r, :] -= L[r, J:J+K] * X[J:J+K, :]          for rows rbase <= r < rend  (rows below the solved ones)
 //   TRANS == 1:  B[r, :] -= L[J:J+K, r]^T * X[J:J+K, :]        for rows rbase <= r < rend  (rows above them)
 // tri != 0: only tiles on or below the block diagonal (c0 < r0 + TB) are updated -- the lower triangle of a symmetric result
-template <int TRANS>
+template <int TRANS, int NT>
 __global__ __launch_bounds__(256) void trsm_update_kernel(const double *L, int64_t M, double *B, int64_t nrhs, int64_t J, int64_t K,
                                                           int64_t rbase, int64_t rend, int tri) {
-    __shared__ double Ls[2][TB][LDP], Xt[2][TB][LDP];   // double-buffered like chol_update_k_kernel
-    const int64_t r0 = rbase + (int64_t)blockIdx.y * TB, c0 = (int64_t)blockIdx.x * TB;
-    if (r0 >= rend || (tri && c0 >= r0 + TB)) return;   // block-uniform
-    constexpr int PER = TB * NB / 256;
-    double rl[PER], rx[PER];
-    auto fetch = [&](int64_t kk) {
+    constexpr int TBX = 32 * NT, PER = TBX * NB / 256;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int64_t r0 = rbase + (int64_t)blockIdx.y * TBX, c0 = (int64_t)blockIdx.x * TBX;
+    if (r0 >= rend || (tri && c0 >= r0 + TBX)) return;   // block-uniform
+    TileAcc<NT> t;
+    mfma_tile_zero(t);
+    mfma_tile_k_loop<NT>(smem, J, J + K, [&](int64_t kk, double (&rl)[PER], double (&rx)[PER]) {
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
             const int idx = threadIdx.x + e * 256, rr = idx / NB, cc = idx % NB;
             rl[e] = r0 + rr < rend ? (TRANS == 0 ? L[(r0 + rr) * M + kk + cc] : L[(kk + cc) * M + r0 + rr]) : 0.0;
             rx[e] = c0 + rr < nrhs ? B[(kk + cc) * nrhs + c0 + rr] : 0.0;   // Xt[col][k]
         }
-    };
-    auto park = [&](int buf) {
-#pragma unroll
-        for (int e = 0; e < PER; ++e) {
-            const int idx = threadIdx.x + e * 256, rr = idx / NB, cc = idx % NB;
-            Ls[buf][rr][cc] = rl[e];
-            Xt[buf][rr][cc] = rx[e];
-        }
-    };
-    TileAcc t;
-    mfma_tile_zero(t);
-    fetch(J);
-    park(0);
-    __syncthreads();
-    int cur = 0;
-    for (int64_t kk = J; kk < J + K; kk += NB) {
-        const bool more = kk + NB < J + K;
-        if (more) fetch(kk + NB);
-        mfma_tile_accumulate(Ls[cur], Xt[cur], t);
-        if (more) park(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
-    }
-    const int64_t rows = rend - r0, cols = nrhs - c0;
-    mfma_tile_subtract(t, B + r0 * nrhs + c0, nrhs, (int)(rows < TB ? rows : TB), (int)(cols < TB ? cols : TB));
+    }, t);
+    mfma_tile_subtract<NT>(t, B + r0 * nrhs + c0, nrhs, rend - r0, nrhs - c0);
 }
 
 // ---------------------------------------------------------------------------------- Newton system
@@ -400,6 +388,41 @@ extern "C" int scasml_gp_gram(int32_t d, double a, const float *x_dom, int32_t n
     return check_launch("gp_gram launch");
 }
 
+// ---- launch helpers ------------------------------------------------------------------------------------------
+template <class Kern>
+static bool reserve_lds(Kern kern, size_t bytes) {
+    return bytes <= 64 * 1024 ||
+           hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+}
+
+template <int NT>
+static void launch_chol_update(double *A, int64_t M, int64_t J, int64_t K, int64_t R0, int64_t col_end, hipStream_t s) {
+    constexpr int TBX = 32 * NT;
+    const int64_t nti = (M - R0 + TBX - 1) / TBX, ntj = (col_end - R0 + TBX - 1) / TBX;
+    if (nti <= 0 || ntj <= 0) return;
+    auto kern = chol_update_k_kernel<NT>;
+    if (!reserve_lds(kern, tile_lds_bytes<NT>())) return;   // reported by check_launch through hipGetLastError
+    hipLaunchKernelGGL(kern, dim3((unsigned)ntj, (unsigned)nti), dim3(256), tile_lds_bytes<NT>(), s, A, M, J, K, R0, col_end);
+}
+
+// rows [rbase, rend) x columns [0, ncols) of B
+template <int TRANS, int NT>
+static void launch_trsm_update(const double *L, int64_t M, double *B, int64_t nrhs, int64_t J, int64_t K, int64_t rbase, int64_t rend,
+                               int64_t ncols, int tri, hipStream_t s) {
+    constexpr int TBX = 32 * NT;
+    const int64_t ntr = (rend - rbase + TBX - 1) / TBX, ntc = (ncols + TBX - 1) / TBX;
+    if (ntr <= 0 || ntc <= 0) return;
+    auto kern = trsm_update_kernel<TRANS, NT>;
+    if (!reserve_lds(kern, tile_lds_bytes<NT>())) return;
+    hipLaunchKernelGGL(kern, dim3((unsigned)ntc, (unsigned)ntr), dim3(256), tile_lds_bytes<NT>(), s, L, M, B, nrhs, J, K, rbase, rend, tri);
+}
+
+template <int TRANS>
+static void trsm_update(const double *L, int64_t M, double *B, int64_t nrhs, int64_t J, int64_t K, int64_t rbase, int64_t rend,
+                        int64_t ncols, int tri, hipStream_t s) {
+    launch_trsm_update<TRANS, 2>(L, M, B, nrhs, J, K, rbase, rend, ncols, tri, s);
+}
+
 extern "C" int scasml_cholesky(double *A, int64_t M, double nugget, int32_t *info_dev, void *stream) {
     if (!A || !info_dev || M < 1) return fail(SCASML_ERR_ARG, "cholesky: bad argument");
     if (M % NB) return fail(SCASML_ERR_UNSUPPORTED, "cholesky: M=%lld is not a multiple of %d (pad with an identity block)", (long long)M, NB);
@@ -411,9 +434,7 @@ extern "C" int scasml_cholesky(double *A, int64_t M, double nugget, int32_t *inf
     // columns (updates confined to that panel's columns), then the whole trailing matrix is updated once with K = kOuter
     constexpr int64_t kOuter = kOuterRows;
     auto update = [&](int64_t J, int64_t K, int64_t R0, int64_t col_end) {
-        const int64_t nti = (M - R0 + TB - 1) / TB, ntj = (col_end - R0 + TB - 1) / TB;
-        if (nti <= 0 || ntj <= 0) return;
-        hipLaunchKernelGGL(chol_update_k_kernel, dim3((unsigned)ntj, (unsigned)nti), dim3(256), 0, s, A, M, J, K, R0, col_end);
+        launch_chol_update<2>(A, M, J, K, R0, col_end, s);
     };
     for (int64_t J = 0; J < M; J += kOuter) {
         const int64_t jend = J + kOuter < M ? J + kOuter : M;
@@ -446,10 +467,10 @@ extern "C" int scasml_trsm_lower(const double *L, int64_t M, double *Bmat, int64
             for (int64_t k0 = J; k0 < jend; k0 += NB) {
                 hipLaunchKernelGGL(trsm_diag_kernel<0>, dim3(cb), dim3(256), 0, s, L, M, Bmat, nrhs, k0, nrhs);
                 if (k0 + NB < jend)
-                    hipLaunchKernelGGL(trsm_update_kernel<0>, dim3(ct, tiles(jend - k0 - NB)), dim3(256), 0, s, L, M, Bmat, nrhs, k0, (int64_t)NB, k0 + NB, jend, 0);
+                    trsm_update<0>(L, M, Bmat, nrhs, k0, NB, k0 + NB, jend, nrhs, 0, s);
             }
             if (jend < M)
-                hipLaunchKernelGGL(trsm_update_kernel<0>, dim3(ct, tiles(M - jend)), dim3(256), 0, s, L, M, Bmat, nrhs, J, jend - J, jend, M, 0);
+                trsm_update<0>(L, M, Bmat, nrhs, J, jend - J, jend, M, nrhs, 0, s);
         }
     } else {
         for (int64_t jend = M; jend > 0; jend -= kOuterRows) {
@@ -457,10 +478,10 @@ extern "C" int scasml_trsm_lower(const double *L, int64_t M, double *Bmat, int64
             for (int64_t k0 = jend - NB; k0 >= J; k0 -= NB) {
                 hipLaunchKernelGGL(trsm_diag_kernel<1>, dim3(cb), dim3(256), 0, s, L, M, Bmat, nrhs, k0, nrhs);
                 if (k0 > J)
-                    hipLaunchKernelGGL(trsm_update_kernel<1>, dim3(ct, tiles(k0 - J)), dim3(256), 0, s, L, M, Bmat, nrhs, k0, (int64_t)NB, J, k0, 0);
+                    trsm_update<1>(L, M, Bmat, nrhs, k0, NB, J, k0, nrhs, 0, s);
             }
             if (J > 0)
-                hipLaunchKernelGGL(trsm_update_kernel<1>, dim3(ct, tiles(J)), dim3(256), 0, s, L, M, Bmat, nrhs, J, jend - J, (int64_t)0, J, 0);
+                trsm_update<1>(L, M, Bmat, nrhs, J, jend - J, 0, J, nrhs, 0, s);
         }
     }
     return check_launch("trsm launch");
@@ -511,10 +532,10 @@ extern "C" int scasml_cholesky_inverse(const double *L, int64_t M, double *A, vo
             const int64_t lim = k0 + NB;
             hipLaunchKernelGGL(trsm_diag_kernel<0>, dim3((unsigned)((lim + 255) / 256)), dim3(256), 0, s, L, M, A, M, k0, lim);
             if (k0 + NB < jend)
-                hipLaunchKernelGGL(trsm_update_kernel<0>, dim3(tiles(lim), tiles(jend - k0 - NB)), dim3(256), 0, s, L, M, A, M, k0, (int64_t)NB, k0 + NB, jend, 0);
+                trsm_update<0>(L, M, A, M, k0, NB, k0 + NB, jend, lim, 0, s);
         }
         if (jend < M)
-            hipLaunchKernelGGL(trsm_update_kernel<0>, dim3(tiles(jend), tiles(M - jend)), dim3(256), 0, s, L, M, A, M, J, jend - J, jend, M, 0);
+            trsm_update<0>(L, M, A, M, J, jend - J, jend, M, jend, 0, s);
     }
     for (int64_t jend = M; jend > 0; jend -= kOuterRows) {   // Z = L^-T X, lower triangle only
         const int64_t J = jend > kOuterRows ? jend - kOuterRows : 0;
@@ -522,10 +543,10 @@ extern "C" int scasml_cholesky_inverse(const double *L, int64_t M, double *A, vo
             const int64_t lim = k0 + NB;
             hipLaunchKernelGGL(trsm_diag_kernel<1>, dim3((unsigned)((lim + 255) / 256)), dim3(256), 0, s, L, M, A, M, k0, lim);
             if (k0 > J)
-                hipLaunchKernelGGL(trsm_update_kernel<1>, dim3(tiles(k0), tiles(k0 - J)), dim3(256), 0, s, L, M, A, M, k0, (int64_t)NB, J, k0, 1);
+                trsm_update<1>(L, M, A, M, k0, NB, J, k0, k0, 1, s);
         }
         if (J > 0)
-            hipLaunchKernelGGL(trsm_update_kernel<1>, dim3(tiles(J), tiles(J)), dim3(256), 0, s, L, M, A, M, J, jend - J, (int64_t)0, J, 1);
+            trsm_update<1>(L, M, A, M, J, jend - J, 0, J, J, 1, s);
     }
     hipLaunchKernelGGL(mirror_lower_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)M), dim3(256), 0, s, A, M);
     return check_launch("cholesky_inverse launch");
