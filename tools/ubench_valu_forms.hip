@@ -36,6 +36,10 @@ __global__ __launch_bounds__(1024) void k(float *out, int iters, float a, float 
                     asm volatile("v_xor_b32 %0, %1, %2" : "=v"(v[i]) : "v"((unsigned)(r >> 32)), "v"((unsigned)r));
                 }
                 if (MODE == 15) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(v[i]) : "v"(av));
+                if (MODE == 17) asm volatile("v_add_f32 %0, 0x3e0eaaaa, %0" : "+v"(v[i]));                    // 32-bit literal
+                if (MODE == 19) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(v[i]));                           // inline constant
+                if (MODE == 20) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(v[i]) : "v"(av));
+                if (MODE == 21) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(v[i]) : "v"(av));
                 if (MODE == 16) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(v[i]) : "v"(av));
                 if (MODE >= 10 && MODE <= 13) {   // v_fma stream with an MFMA every 16 (10, 12) or 8 (11, 13) of them
                     const int every = (MODE & 1) ? 8 : 16;
@@ -86,6 +90,10 @@ int main() {
     run<7>(out, "v_mov_b32 v,v'");
     run<9>(out, "v_sub_f32 v,v,v'");
     run<8>(out, "v_exp_f32");
+    run<17>(out, "v_add_f32 v, literal, v");
+    run<19>(out, "v_add_f32 v, 1.0, v");
+    run<20>(out, "v_cndmask_b32 v, v, v, vcc");
+    run<21>(out, "v_xor_b32 v, v, v");
     run<14>(out, "v_mad_u64_u32 + v_xor_b32 (pair)");
     run<15>(out, "v_mul_hi_u32");
     run<16>(out, "v_mul_u32_u24");
