@@ -40,10 +40,13 @@ def main():
         groups[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
         meta[key] = (r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"], r["Scratch_Size"], r["LDS_Block_Size"])
     with open(os.path.join(HERE, tag + "_kernel_by_grid.txt"), "w") as f:
-        f.write("# kernel | grid threads | calls | avg ms | min ms | max ms | vgpr accum_vgpr sgpr scratch lds\n")
+        f.write("# kernel | grid threads | calls | avg ms | min ms | max ms | median ms | vgpr accum_vgpr sgpr scratch lds\n"
+                "# (the first launch of a kernel in a process is cold -- code load, clock ramp -- and is the max; bench.py's\n"
+                "#  avg_launch_ms covers the timed steps only and should be compared with the median)\n")
         for key in sorted(groups, key=lambda k: -sum(groups[k])):
             v = groups[key]
-            f.write("%s | %d | %d | %.4f | %.4f | %.4f | %s\n" % (key[0], key[1], len(v), sum(v) / len(v), min(v), max(v), " ".join(meta[key])))
+            f.write("%s | %d | %d | %.4f | %.4f | %.4f | %.4f | %s\n" % (key[0], key[1], len(v), sum(v) / len(v), min(v), max(v),
+                                                                     sorted(v)[len(v) // 2], " ".join(meta[key])))
     if pmc_dirs:
         big = max((k for k in groups if "gp_eval" in k[0]), key=lambda k: k[1])
         out = {"kernel": big[0], "grid_threads": big[1], "avg_ms_kernel_trace": sum(groups[big]) / len(groups[big])}
