@@ -253,8 +253,8 @@ __global__ void gp_pack_kernel(int d, float a, const float *x_dom, int n_dom, co
         const float qs = 0.5f * 1.44269504088896341f / a, k1 = -qs;
         const float ay = k1 * a * a * ny_full;
         // bf16 planes (truncation split, v = hi + mid + lo exactly up to 2^-24 |v|): the collocation side carries
-        // the factor, 2 a^2 q y_k (k <= d), and k1 a^2 |y|^2 in column d+1 against a constant 1 in the point row
-        const float vf = k <= d ? 2.0f * a * a * qs * v : (k == d + 1 ? ay : (k == kp - 1 ? 1.0f : 0.0f));
+        // the factor, 2 a^2 q y_k (k <= d), and k1 a^2 |y|^2 in column kp-2 against a constant 1 in the point row
+        const float vf = k <= d ? 2.0f * a * a * qs * v : (k == kp - 2 ? ay : (k == kp - 1 ? 1.0f : 0.0f));
         const uint32_t hb = __float_as_uint(vf) & 0xFFFF0000u;
         const float r1 = vf - __uint_as_float(hb);
         const uint32_t mb = __float_as_uint(r1) & 0xFFFF0000u;
@@ -266,12 +266,13 @@ __global__ void gp_pack_kernel(int d, float a, const float *x_dom, int n_dom, co
         bf[((int64_t)tile * 3 + 1) * ks * 512 + e] = (uint16_t)(mb >> 16);
         bf[((int64_t)tile * 3 + 2) * ks * 512 + e] = (uint16_t)(lb >> 16);
         // fp16 planes (h, l = fp16(v - h), unscaled), stored behind the bf16 planes.  Here the factor 2 a^2 q sits on
-        // the POINT side (gp_eval_bf16.hip): the planes hold y itself, and k1 a^2 |y|^2 as h in column d+1 and l in
-        // column d+2 of plane 0, met by the constants 1 and 1 in the point row.  If y is exactly fp16 (float16
+        // the POINT side (gp_eval_bf16.hip): the planes hold y itself, and k1 a^2 |y|^2 as h in column kp-3 and l in
+        // column kp-2 of plane 0, met by the constants 1 and 1 in the point row (the kernel patches them in: the last
+        // three columns are compile-time fragment positions; kp >= d + 4 keeps them clear of the data).  If y is exactly fp16 (float16
         // collocation points, as in the reference protocol) plane 1 is identically zero and is never read.
         uint16_t *hf = bf + (int64_t)3 * n_pad * kp;
         const _Float16 ayh = (_Float16)ay;
-        const float vg = k <= d ? v : (k == d + 1 ? (float)ayh : (k == d + 2 ? ay - (float)ayh : (k == kp - 1 ? 1.0f : 0.0f)));
+        const float vg = k <= d ? v : (k == kp - 3 ? (float)ayh : (k == kp - 2 ? ay - (float)ayh : (k == kp - 1 ? 1.0f : 0.0f)));
         const _Float16 fh = (_Float16)vg;
         const _Float16 fl = k <= d ? (_Float16)(vg - (float)fh) : (_Float16)0.0f;
         hf[((int64_t)tile * 2 + 0) * ks * 512 + e] = __builtin_bit_cast(unsigned short, fh);

@@ -12,7 +12,7 @@
 // tests/test_gpu_gp.py would show at once if it did not).  The products h*h and h*l + l*h are exact in the fp32
 // accumulator and go into ONE accumulator (l*l ~ 2^-24 is dropped): 3 MFMAs per K-step instead of 6, product
 // accuracy ~2^-22 instead of 2^-24, no combining instruction.  In this mode the scale factor sits on the
-// point side (B = planes of 2 a^2 q x, constants 1 and 1 in two spare columns) and the collocation planes
+// point side (B = planes of 2 a^2 q x, constants 1 and 1 in columns kp-3 and kp-2) and the collocation planes
 // hold y itself plus k1 a^2 |y|^2 as (h, l) in those two columns; when every collocation coordinate is
 // exactly fp16 -- the reference's deepxde float16 arrays are -- plane l_y is zero, so the l_y * h_x MFMA
 // and the staging of that plane are dropped (YEXACT): 2 MFMAs per K-step.
@@ -192,7 +192,11 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
         if (row >= g.n_inf) row = g.n_inf - 1;  // shadow rows, never stored
         const int kbase = half * (8 * KS);
         const float4 *src = reinterpret_cast<const float4 *>(g.points + row * g.kp + kbase);
-        float pn = 0.0f, ps = 0.0f, pt = 0.0f;
+        // No per-element selects: the point rows hold zeros beyond column d (scasml_hip.h), so |x|^2 (with t) and the
+        // row sum need no masks, t is fetched on its own, and the three constants live in the LAST three columns
+        // (half 1, step KS-1, elements 5..7: compile-time fragment positions), patched once after the loop.
+        float pn = 0.0f, ps = 0.0f;
+        const float pt = g.points[row * g.kp + g.d];
         const float fold = F16 ? 2.0f * g.a * g.a * qs : 1.0f;
         auto make_planes = [&](const float (&t)[8], Frag &fh, Frag &fm, Frag &fl) {
             uint32_t hb[8], mb[8], lb[8];
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
                 }
             }
         };
-        float tlast[8];   // the operand values of the last step, kept to patch column kp-1 once |x|^2 is known
+        float tlast[8];   // the operand values of the last step, kept to patch its last three columns once |x|^2 is known
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const float4 q0 = src[2 * s], q1 = src[2 * s + 1];
@@ -222,13 +226,9 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
             float t[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const int k = kbase + 8 * s + c;
                 pn = fmaf(e[c], e[c], pn);
-                ps += k < g.d ? e[c] : 0.0f;
-                pt += k == g.d ? e[c] : 0.0f;
-                // spare columns: d+1 meets k1 a^2|y|^2 (bf16 modes: the whole value; fp16 mode: its h part), d+2 its 2^11*l part
-                const float spare = k == g.d + 1 ? 1.0f : ((F16 && k == g.d + 2) ? 1.0f : 0.0f);
-                t[c] = k <= g.d ? fold * e[c] : spare;
+                ps += e[c];
+                t[c] = fold * e[c];
             }
             if (s == KS - 1) {
 #pragma unroll
@@ -243,8 +243,11 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
         }
         pn += __shfl_xor(pn, 32);
         ps += __shfl_xor(ps, 32);
-        pt += __shfl_xor(pt, 32);
-        tlast[7] = half ? k1 * g.a * g.a * pn : tlast[7];   // column kp-1 (zero in the point buffer): k1 a^2 |x|^2
+        // columns kp-3, kp-2 (fp16 mode: against the (h, l) parts of k1 a^2 |y|^2; bf16 modes: kp-2 against the whole
+        // value) hold the constant 1, column kp-1 holds k1 a^2 |x|^2 against the collocation side's constant 1
+        if (F16) tlast[5] = half ? 1.0f : tlast[5];
+        tlast[6] = half ? 1.0f : tlast[6];
+        tlast[7] = half ? k1 * g.a * g.a * pn : tlast[7];
         {
             Frag fh, fm, fl;
             make_planes(tlast, fh, fm, fl);
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
             xb[1][KS - 1] = fm.v;
             if (SPLIT == 3) xb[SPLIT - 1][KS - 1] = fl.v;
         }
-        sx = g.a * ps;
+        sx = g.a * (ps - pt);                 // the row sum includes t
         tx = sqrtf(qs) * g.a * pt;
     }
     float au = 0.0f, at = 0.0f, ad = 0.0f, al = 0.0f;
