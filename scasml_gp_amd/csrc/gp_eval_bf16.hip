@@ -59,11 +59,13 @@ __device__ __forceinline__ uint32_t pack_h2(float a, float b) {   // two fp16 (R
 // moment it was issued; an asm statement is opaque to that pass, so completion is counted by hand (counted
 // vmcnt + raw s_barrier in `rendezvous`).  M0 carries the wave-uniform LDS byte address and is saved/restored
 // inside the same statement (cdna_hip_programming.md section 5.7).
-__device__ __forceinline__ void glds16_asm(const float *gsrc_lane, uint32_t lds_byte_addr_uniform) {
+__device__ __forceinline__ void glds16_asm(const float *gsrc_uniform, uint32_t lane_byte_offset, uint32_t lds_byte_addr_uniform) {
+    // SADDR form: wave-uniform 64-bit base in an SGPR pair + a 32-bit per-lane byte offset, so the per-tile address
+    // arithmetic is scalar (a 64-bit VGPR pointer per chunk costs ~7 VALU instructions in an issue-bound kernel)
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
-                 : "v"(gsrc_lane), "s"(lds_byte_addr_uniform)
+                 : "v"(lane_byte_offset), "s"(gsrc_uniform), "s"(lds_byte_addr_uniform)
                  : "memory");
 }
 
@@ -143,7 +145,8 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
     // constant, so a counted s_waitcnt vmcnt(own count) means "everything but the newest tile has landed".
     constexpr int NCHUNK = NPL * KS + 2;
     constexpr int CLO = NCHUNK / WPB, CREM = NCHUNK % WPB;
-    const bool extra = __builtin_amdgcn_readfirstlane(wv) < CREM;   // scalar: this wave issues CLO + 1
+    const int wvs = __builtin_amdgcn_readfirstlane(wv);              // the wave index as a scalar: staging addresses stay on the SALU
+    const bool extra = wvs < CREM;                                   // this wave issues CLO + 1
     // low 32 bits of a flat pointer into the LDS aperture = the LDS byte address
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
     auto stage = [&](int tile, int slot) {
@@ -152,11 +155,11 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
         const float *srcC = g.coef2 + (int64_t)tile * 512 - (int64_t)NPL * KS * 256;   // chunk c >= NPL*KS -> coef + (c - NPL*KS) KiB
         auto chunk = [&](int c) {
             const float *src = c < NPL * KS ? srcA : srcC;
-            glds16_asm(src + c * 256 + lane * 4, (uint32_t)__builtin_amdgcn_readfirstlane((int)(dst + (uint32_t)c * 1024u)));
+            glds16_asm(src + c * 256, (uint32_t)lane * 16u, dst + (uint32_t)c * 1024u);
         };
 #pragma unroll
-        for (int i = 0; i < CLO; ++i) chunk(wv + i * WPB);
-        if (CREM && extra) chunk(wv + CLO * WPB);
+        for (int i = 0; i < CLO; ++i) chunk(wvs + i * WPB);
+        if (CREM && extra) chunk(wvs + CLO * WPB);
     };
     // NSLOT = 4: tiles are fetched TWO ahead and the per-tile rendezvous is a raw s_barrier behind a counted
     // vmcnt, so the newest tile's DMA stays in flight across the barrier (__syncthreads() would drain it:
