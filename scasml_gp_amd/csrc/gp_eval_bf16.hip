@@ -284,6 +284,10 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
         constexpr bool UO = decltype(uo)::value;
         constexpr int AHEAD = NSLOT == 4 ? 2 : 1;
         auto tile = [&](int jt, auto kind) {
+            // The three tests of the (runtime) ablation switches below are load-bearing: they end a basic block after the
+            // staging and after the MFMAs.  Made compile-time constants, the tile body becomes one scheduling region,
+            // the register allocator interleaves the point planes with the epilogue's temporaries and spills 624 B per
+            // lane inside the loop (measured: 72 ms instead of 8; tests/test_abi_and_host.py fails on the spills).
             if (jt + AHEAD < n_tiles && !(g.dbg & 8)) stage(jt + AHEAD, (jt + AHEAD) % NSLOT);
             if (!(g.dbg & 1)) gp_mfma_tile_bf16<KS, SPLIT, PF, F16, YEXACT>(a_of(jt % NSLOT), xb, acc, lane);
             if (!(g.dbg & 2)) gp_epilogue_scaled<decltype(kind)::value, PF>(view(jt % NSLOT), acc, half, sx, tx, au, at, ad, al);
