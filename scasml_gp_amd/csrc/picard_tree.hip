@@ -55,6 +55,10 @@ template <int VAR, int MODE>
 struct Walker {
     const TreeArgs &a;
     float4 mask;       // 1 on this lane's live spatial dims, 0 on padding
+    float4 tmask;      // 1 on the component that holds t in a stored row (column d)
+    uint32_t row_off4; // (local * kp + 4 * gl) / 4: this lane's float4 inside a site's block of B rows
+    uint32_t gp_off;   // local
+    bool row_lane;     // 4 * gl < kp
     uint32_t gl;       // lane index inside the root's group = Philox quad index
     uint32_t root;     // global root index (Philox counter word 2)
     int64_t local;     // this root's index inside the call's batch: row of site s = s * B + local
@@ -70,19 +74,17 @@ struct Walker {
     __device__ __forceinline__ float4 normals(uint32_t site) const {
         return mul4(normal4(gl, site, root, a.stream, a.k0, a.k1), mask);
     }
+    // Row addressing: row = site * B + local, so a site's rows start at a wave-uniform base (scalar 64-bit arithmetic) and
+    // the lane contributes a fixed 32-bit element offset -- a 64-bit VGPR product per access costs three v_mad_u64_u32.
     __device__ __forceinline__ void emit_point(float4 X, float t, uint32_t site) const {
-        const int dim0 = 4 * (int)gl;
-        if (dim0 >= a.kp) return;
-        float4 v;
-        v.x = dim0 + 0 < a.d ? X.x : (dim0 + 0 == a.d ? t : 0.0f);
-        v.y = dim0 + 1 < a.d ? X.y : (dim0 + 1 == a.d ? t : 0.0f);
-        v.z = dim0 + 2 < a.d ? X.z : (dim0 + 2 == a.d ? t : 0.0f);
-        v.w = dim0 + 3 < a.d ? X.w : (dim0 + 3 == a.d ? t : 0.0f);
-        *reinterpret_cast<float4 *>(a.points + ((int64_t)site * a.B + local) * a.kp + dim0) = v;
+        if (!row_lane) return;                                    // lanes past the padded row
+        float4 *base = reinterpret_cast<float4 *>(a.points + (int64_t)site * a.B * a.kp);
+        base[row_off4] = fma4(t, tmask, mul4(X, mask));           // (X, t, zero pad)
     }
-    __device__ __forceinline__ float4 gp_at(uint32_t site) const { return a.gpv[(int64_t)site * a.B + local]; }
+    __device__ __forceinline__ float4 gp_at(uint32_t site) const { return (a.gpv + (int64_t)site * a.B)[gp_off]; }
     __device__ __forceinline__ float4 load_point(uint32_t site) const {   // this lane's four dims of a stored tree point
-        return *reinterpret_cast<const float4 *>(a.points + ((int64_t)site * a.B + local) * a.kp + 4 * (int)gl);
+        const float4 *base = reinterpret_cast<const float4 *>(a.points + (int64_t)site * a.B * a.kp);
+        return base[row_off4];
     }
     __device__ __forceinline__ bool owned(bool top) {
         if (!top || a.world == 1) return true;
@@ -284,6 +286,11 @@ __global__ __launch_bounds__(256) void picard_tree_kernel(const TreeArgs a) {
     const int dim0 = 4 * (int)w.gl;
     w.mask = make_float4(dim0 + 0 < a.d ? 1.0f : 0.0f, dim0 + 1 < a.d ? 1.0f : 0.0f,
                          dim0 + 2 < a.d ? 1.0f : 0.0f, dim0 + 3 < a.d ? 1.0f : 0.0f);
+    w.tmask = make_float4(dim0 + 0 == a.d ? 1.0f : 0.0f, dim0 + 1 == a.d ? 1.0f : 0.0f,
+                          dim0 + 2 == a.d ? 1.0f : 0.0f, dim0 + 3 == a.d ? 1.0f : 0.0f);
+    w.row_lane = dim0 < a.kp;
+    w.row_off4 = (uint32_t)((local * a.kp + (dim0 < a.kp ? dim0 : 0)) >> 2);   // a chunk's point buffer is < 2^32 floats per site block
+    w.gp_off = (uint32_t)local;
     const float *row = a.x_t + local * (a.d + 1);
     float4 x;
     x.x = dim0 + 0 < a.d ? row[dim0 + 0] : 0.0f;
