@@ -161,7 +161,8 @@ int64_t scasml_gp_coef_floats(int32_t n_pad);
  * without materialising any (n_inf x M) feature matrix.  x.y on the matrix cores -- bf16 MFMA over
  * 3 (fp32-exact) or 2 bf16 planes of each operand, or FP32 MFMA (gp_h->split) -- and the closed-form
  * derivative features in the epilogue.
- *   points : n_inf x kp rows (X, t, zero pad)
+ *   points : n_inf x kp rows (X, t, zero pad); columns d+1 .. kp-1 MUST be zero (row sums are taken unmasked and the
+ *            last three columns carry folded constants inside the kernel)
  *   out4   : n_inf x 4 = (u_hat, div_x u_hat, eps_PDE, dt u_hat)
  *   lap    : n_inf Laplacian of u_hat, may be NULL
  */
