@@ -84,8 +84,15 @@ __device__ __forceinline__ void sincos_u24(uint32_t k, float &cc, float &ss) {
     c = c * z;
     c = c - 0.5f * z;
     c = c + 1.0f;
-    cc = quad == 0 ? c : quad == 1 ? -s : quad == 2 ? -c : s;
-    ss = quad == 0 ? s : quad == 1 ? c : quad == 2 ? -s : -c;
+    // quadrant: (cos, sin) = (c, s), (-s, c), (-c, -s), (s, -c) for quad = 0..3.  Bit-select and sign-bit XOR instead of six
+    // compare-selects (a v_cndmask reads its mask from SGPRs and issues at half rate): odd quadrants swap the two,
+    // cos is negated in quadrants 1 and 2 (bit 1 of quad + 1), sin in quadrants 2 and 3 (bit 1 of quad).
+    const uint32_t swap = (uint32_t)__builtin_amdgcn_sbfe((int)k, 22, 1);                  // bit 22 of k -> 0 or 0xFFFFFFFF
+    const uint32_t cb = __float_as_uint(c), sb = __float_as_uint(s);
+    const uint32_t cm = (sb & swap) | (cb & ~swap), sm = (cb & swap) | (sb & ~swap);
+    cc = __uint_as_float(cm ^ (((k + 0x400000u) << 8) & 0x80000000u));
+    ss = __uint_as_float(sm ^ ((k << 8) & 0x80000000u));
+    (void)quad;
 }
 
 // Correctly rounded binary32 square root, spelled out so that it does not depend on compiler flags or
