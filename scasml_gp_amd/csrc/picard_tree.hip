@@ -485,6 +485,28 @@ extern "C" int scasml_clip(float *uz, int64_t count, float clip, void *stream) {
     return check_launch("clip launch");
 }
 
+// radius sqrt(-2 ln((k+1) 2^-24)) and (cos, sin) of the angle word k, for k = k0 .. k0 + n - 1: the two halves of the normal
+// transform on their whole 24-bit domains (tests/test_gpu_rng.py checks all 2^24 inputs of each against NumPy)
+__global__ void debug_transform_kernel(uint32_t k0, int64_t n, float *rad, float *cs) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k = k0 + (uint32_t)i;
+    float t = -2.0f * ln_u24(k + 1u);
+    t = t < 0.0f ? 0.0f : t;
+    rad[i] = sqrt_rn(t);
+    float c, s;
+    sincos_u24(k, c, s);
+    cs[2 * i] = c;
+    cs[2 * i + 1] = s;
+}
+
+extern "C" int scasml_debug_transform(uint32_t k0, int64_t n, float *rad, float *cos_sin, void *stream) {
+    if (!rad || !cos_sin || n < 0 || (uint64_t)k0 + (uint64_t)n > (1ull << 24)) return fail(SCASML_ERR_ARG, "debug_transform: bad argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(debug_transform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, k0, n, rad, cos_sin);
+    return check_launch("debug_transform launch");
+}
+
 extern "C" int scasml_debug_normals(scasml_rng rng, uint32_t site, int32_t d, int64_t B, float *out, void *stream) {
     if (!out || d < 1 || B < 0) return fail(SCASML_ERR_ARG, "debug_normals: bad argument");
     if (B == 0) return 0;
