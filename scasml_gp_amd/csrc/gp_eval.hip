@@ -403,6 +403,10 @@ static int gp_eval_impl(const scasml_gp_model *m, const float *points, int64_t n
     hipStream_t s = (hipStream_t)stream;
     if (m->split == 2 || m->split == 3 || m->split == 22) {
         if (!m->colloc_bf16) return fail(SCASML_ERR_ARG, "gp_eval: split=%d needs colloc_bf16", m->split);
+        // fp16 planes carry k1 a^2 |x|^2 = -0.72 a |x|^2 itself: with |x_k| <= 2 that stays far inside the fp16 range for
+        // the reference's length scale (a = 16 / d: 46) but not for an arbitrarily small GP.sigma
+        if (m->split == 22 && 0.7213f * m->a * 4.0f * (float)(m->d + 1) > 3.0e4f)
+            return fail(SCASML_ERR_UNSUPPORTED, "gp_eval: a = 1/sigma^2 = %g is outside the range of the fp16x2 mode at d = %d; use split = 3", (double)m->a, m->d);
         return launch_gp_eval_bf16(g, m->split, s);
     }
     if (m->split != 0) return fail(SCASML_ERR_ARG, "gp_eval: split must be 0, 2, 3 or 22");
