@@ -143,3 +143,16 @@ def test_state_dict_round_trip(tmp_path):
     assert np.array_equal(fresh.predict(X), want) and fresh._colloc_is_f16 and fresh.loss_history == gp.loss_history
     with pytest.raises(ValueError):
         GP_Grad_Dependent_Nonlinear(Grad_Dependent_Nonlinear(14)).load(path)
+
+
+def test_fp16_mode_refuses_out_of_range_length_scale():
+    from scasml_gp_amd import _lib
+    gp, _, dom, bdy = _setup(12, 40, 12, seed=4)
+    gp.GPsolver(dom.astype(np.float16), bdy.astype(np.float16), GN_steps=20)
+    X = np.zeros((4, 13), dtype=np.float32)
+    gp.predict(X)
+    gp.sigma = 1e-3                                        # a = 1e6: k1 a^2 |x|^2 would overflow fp16
+    with pytest.raises(_lib.ScasmlError):
+        gp.predict(X)
+    gp.eval_split = 3                                      # the bf16 x 3 mode has the fp32 exponent range (stale planes: no numbers checked)
+    gp.predict(X)
