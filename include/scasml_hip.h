@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SCASML_ABI_VERSION 1
+#define SCASML_ABI_VERSION 2
 #define SCASML_MAX_LEVEL 5   /* Picard level n <= 5 (kernels are instantiated per level)      */
 #define SCASML_MAX_Q 6       /* quadrature nodes per rule <= 6 (rho <= 5, solvers/MLP.py:132)  */
 #define SCASML_MAX_DIM 252   /* spatial dimension d <= 252 (one 4-dim quad per lane, +t, +3 spare columns) */
@@ -52,7 +52,17 @@ typedef struct {
     uint32_t root0;   /* global index of the first root in this call (root sharding)       */
     int32_t rank;     /* Monte-Carlo sample sharding of the ROOT call: unit % world == rank */
     int32_t world;    /* 1 = no sample sharding; >1 => outputs are un-clipped partial sums  */
+    uint32_t flags;   /* SCASML_RNG_*                                                       */
+    uint32_t reserved;
 } scasml_rng;
+
+/* scasml_rng.flags.  COMPAT_CRN reproduces the reference's key reuse as pure counter
+ * keying: every uz_solve call draws its terminal normals from the same fixed key (solvers/MLP.py:167-168,178), so
+ * the child calls of the q quadrature nodes of one sample path -- calls of equal shape -- share their terminal
+ * draws: a call's terminal sample m is keyed by the site it would have at node k = 0 of every ancestor path.  In
+ * the full-history solvers the level-0 normals equal the terminal ones (solvers/MLP_full_history.py:92-93,99,138).
+ * Default (0): independent draws everywhere. */
+enum { SCASML_RNG_COMPAT_CRN = 1 };
 
 /* One (level n', sub-level l) term of the Picard sum: MLP.py:210-271 / MLP_full_history.py:131-177. */
 typedef struct {
@@ -222,6 +232,32 @@ int scasml_gemv(const double *A, int64_t M, int64_t lda, const double *x, double
 int scasml_gp_newton_system(int32_t eq_id, int32_t d, double sigma, const double *A, int64_t lda, int32_t n_dom,
                             int32_t n_bdy, const double *sol, const double *Ab, double *grad, double *H, int64_t ldh,
                             int gauss_newton, void *stream);
+
+/* ------------------------------------------------------------------ reference-compat surrogate
+ * The reference's surrogate AS CODED differs from the operators it documents:
+ * laplacian_op (models/GP.py:28-39) is a 5-index Hutchinson subsample applied to a cyclically shifted argument
+ * (:87-105, 119-127, 141-179: t_x = x_t[0] although time is the last column), and every kernel entry is rounded to
+ * float16 (:43, 55-179).  These entry points compute exactly that, in float64, for GP(compat="reference"):
+ *   idx_h   : the five Hutchinson indices, HOST int32[5], distinct, 0 <= i < d.  The reference draws them with
+ *             random.choice(PRNGKey(0), d, (5,), replace=False) -- JAX threefry, not reproducible without JAX -- so they are
+ *             an argument.  Index i differentiates along component i of the SHIFTED vector (original coordinate i+1).
+ *   round16 : != 0 rounds every kernel entry to float16 (RNE) before it is stored / used.
+ * scasml_gp_gram_compat   K(phi, phi), same block order as scasml_gp_gram              (models/GP.py:182-258)
+ * scasml_round16_diag     A[i][i] = float16(A[i][i] + nugget): K_p as right_vector sees it   (:267-268, 599)
+ * scasml_round16          v = float16(v) elementwise (time_der_rep(...).astype(float16), :719)
+ * scasml_gp_compat_pack   colloc_t[k][j] (float64, leading dimension ldc >= n_dom + n_bdy) = coordinate k of collocation point j
+ * scasml_gp_eval_compat   out4 = (u_hat, div_x u_hat, eps_PDE, dt u_hat) and optionally the "Laplacian" of u_hat, as
+ *                         scasml_gp_eval, from kernel_x_t_phi_single and the {dt, div, laplacian}_x_t_kernel_x_t_phi rows
+ *                         (:326-411, 630-651, 746-769); points: n_inf rows of stride kp floats (X, t, ...). */
+int scasml_gp_gram_compat(int32_t d, double a, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy,
+                          const int32_t *idx_h, int32_t round16, double *K, void *stream);
+int scasml_round16_diag(double *A, int64_t M, int64_t lda, double nugget, void *stream);
+int scasml_round16(double *v, int64_t n, void *stream);
+int scasml_gp_compat_pack(int32_t d, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy,
+                          double *colloc_t, int64_t ldc, void *stream);
+int scasml_gp_eval_compat(int32_t d, double a, double sigma_eq, const double *colloc_t, int32_t n_dom, int32_t n_bdy,
+                          int64_t ldc, const double *rv, const int32_t *idx_h, int32_t round16, const float *points,
+                          int64_t n_inf, int32_t kp, float *out4, float *lap, void *stream);
 
 #ifdef __cplusplus
 }

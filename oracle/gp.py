@@ -100,12 +100,20 @@ class OracleGP:
     # ---------------------------------------------------------------- training (models/GP.py:487-604)
     def GPsolver(self, x_dom, x_bdy, GN_steps=20):
         K = self.kernel_phi_phi(x_dom, x_bdy)
-        M, N, Nb = self.phi_dim, self.N_domain, self.N_boundary
+        M = self.phi_dim
         Kp = K + self.nugget * np.eye(M)                    # :260-267 (== L L^T of the SVD factor)
         self.cholesky_phi_phi_perturb = np.linalg.cholesky(Kp)
         A = np.linalg.inv(Kp)
         A = 0.5 * (A + A.T)
-        bdy_g = self.eq.g(self.x_t_boundary)[:, 0]          # :417-419
+        self._newton(A, GN_steps)
+        z = self._b(self.sol, self._bdy_g)                  # :593-598
+        self.right_vector = np.linalg.solve(Kp, z)[:, None]  # :599-600
+        return self.predict(self.x_t_domain)                # :602
+
+    def _newton(self, A, GN_steps):
+        """Newton iteration of models/GP.py:501-588 on J(sol) = b(sol)^T A b(sol); A = (L L^T)^-1."""
+        M, N, Nb = self.phi_dim, self.N_domain, self.N_boundary
+        bdy_g = self._bdy_g = self.eq.g(self.x_t_boundary)[:, 0]          # :417-419
         d, s = self.d, self.sigma_eq
         r1, r3, r4, r5 = slice(0, N), slice(N + Nb, 2 * N + Nb), slice(2 * N + Nb, 3 * N + Nb), slice(3 * N + Nb, M)
         sol = np.zeros(3 * N)
@@ -145,9 +153,6 @@ class OracleGP:
             hist.append(loss(sol))
         self.loss_history = hist
         self.sol = sol
-        z = self._b(sol, bdy_g)                             # :593-598
-        self.right_vector = np.linalg.solve(Kp, z)[:, None]  # :599-600
-        return self.predict(self.x_t_domain)                # :602
 
     # ---------------------------------------------------------------- inference (models/GP.py:630-687, 746-769)
     def _features(self, opx, X):

@@ -1,0 +1,168 @@
+"""Oracle of the reference's surrogate AS CODED (quirks included).  TEST INFRASTRUCTURE (oracle/__init__.py).
+
+oracle/gp.py restates models/GP.py with the mathematically exact operators.  The reference's code
+computes something else in three deterministic ways, and this
+module restates exactly those, in float64 NumPy with explicit float16 rounding points:
+
+* ``laplacian_op`` (models/GP.py:28-39) is a 5-index Hutchinson subsample ``d/5 * sum_{i in idx}``
+  and is applied to a CYCLICALLY SHIFTED argument: ``laplacian_x_t_kappa`` (:87-95) takes
+  ``t_x = x_t[0]`` (the first SPATIAL coordinate -- time is the last column) and differentiates
+  ``kappa(concat(x_t[1:], x_t[0]), y_t)``, i.e. the kernel of ``x' = (x_2..x_d, t, x_1)`` against the
+  un-shifted ``y``; ``laplacian_y_t_kappa`` (:97-105) shifts y instead.  Only the x-y double Laplacian
+  (:171-179) shifts both and is aligned again.  With ``v'[k] = v[(k+1) mod (d+1)]``:
+      geometry "xs": r = x' - y      (lap_x of anything that is not already a lap_y)
+      geometry "ys": r = x  - y'     (lap_y of anything)
+      geometry "al": r = x  - y      (everything without a Laplacian; lap_x lap_y up to a shift)
+  The index set comes from ``random.choice(PRNGKey(0), d, (5,), replace=False)`` -- JAX threefry,
+  not reproducible here -- so it is a PARAMETER (``idx``); it indexes the shifted vector, i.e.
+  index i differentiates along original coordinate i+1 (i = d-1: the time column).
+* every kernel entry is rounded to float16 (:43 and the ``.astype(jnp.float16)`` closing every
+  derivative kernel, :55-179); the stacked matrix is cast back to float64 for the SVD (:258).
+* the "Cholesky" is ``U sqrt(S + nugget)`` from an SVD (:260-263): for a symmetric but indefinite
+  K -- which the shifted Laplacian blocks make it -- ``L L^T = |K| + nugget I`` (matrix absolute
+  value).  The loss uses ``L`` rounded to float16 (:266, 439) and ``right_vector`` is solved against
+  ``L L^T`` rounded to float16 (:267-268, 599).
+
+Closed forms (a = 1/sigma_k^2, g_i = a^2 r_i^2 - a, S = sum_{k<d} r_k, r_D = last component, all in
+the geometry named; derived from the definitions above and checked against finite differences of
+the shifted kernels in tests/test_oracle_gp_compat.py):
+    lap_y kappa            = d/5 sum_i g_i kappa                              [ys]
+    lap_x kappa            = d/5 sum_i g_i kappa                              [xs]
+    dt_x lap_y kappa       = -a r_D d/5 sum_i g_i kappa                       [ys]   r_D = t_x - y_1
+    lap_x dt_y kappa       = +a r_D d/5 sum_i g_i kappa                       [xs]   r_D = x_1 - t_y
+    div_x lap_y kappa      = d/5 sum_i (2 a^2 r_i + a^2 S - a^3 S r_i^2) kappa    [ys]
+    lap_x div_y kappa      = -d/5 sum_i (2 a^2 r_i + a^2 S - a^3 S r_i^2) kappa   [xs]
+    lap_x lap_y kappa      = (d/5)^2 ((sum_i g_i)^2 + sum_i (2 a^2 - 4 a^3 r_i^2)) kappa   [al, r_i = r_{i+1}]
+and the Laplacian-free blocks are those of oracle/gp.py.  Arithmetic inside an entry is float64
+with ONE rounding to float16 at the end (the reference evaluates the whole expression in float16;
+XLA's float16 evaluation order is not pinned, so intermediate roundings are not modelled).
+"""
+import numpy as np
+
+from .gp import OracleGP
+
+
+def f16(v):
+    """Round to float16 and return float64 (the reference stores float16 and promotes on use)."""
+    with np.errstate(over="ignore"):
+        return np.asarray(v, dtype=np.float64).astype(np.float16).astype(np.float64)
+
+
+def shift(P):
+    """v' = (v_2, ..., v_d, t, v_1): models/GP.py:91-93 (concatenate((x_t[1:], x_t[0:1])))."""
+    return np.roll(np.asarray(P, dtype=np.float64), -1, axis=1)
+
+
+class OracleGPCompat(OracleGP):
+    """``compat="reference"`` surrogate.  ``idx``: the five Hutchinson indices (0 <= i < d).
+    ``round16``: round kernel entries / K_p / z4 to float16 as the reference does.  ``round_factor``: also round the
+    SVD factor L the loss is evaluated with (models/GP.py:266, 439).  The product factors by Cholesky, where that
+    rounding has no counterpart, and is checked against ``round_factor=False``; the effect of the factor rounding
+    on the predictions is bounded in tests/test_oracle_gp_compat.py."""
+
+    MC = 5                                            # models/GP.py:30
+
+    def __init__(self, eq, idx, round16=True, round_factor=True):
+        super().__init__(eq)
+        self.round_factor = bool(round_factor) and bool(round16)
+        idx = np.asarray(idx, dtype=np.int64)
+        if idx.shape != (self.MC,) or len(set(idx.tolist())) != self.MC or idx.min() < 0 or idx.max() >= self.d:
+            raise ValueError("idx must be %d distinct indices in [0, d)" % self.MC)
+        self.idx = idx
+        self.round16 = bool(round16)
+
+    def _r(self, v):
+        return f16(v) if self.round16 else np.asarray(v, dtype=np.float64)
+
+    # ---------------------------------------------------------------- geometries
+    def _geom(self, X, Y, which):
+        """kappa, S, r_D and the (n, m, 5) Hutchinson components of r in geometry ``which``."""
+        X = np.asarray(X, dtype=np.float64)
+        Y = np.asarray(Y, dtype=np.float64)
+        d = self.d
+        if which == "xs":
+            X = shift(X)
+        elif which == "ys":
+            Y = shift(Y)
+        diff2 = (X * X).sum(1)[:, None] + (Y * Y).sum(1)[None, :] - 2.0 * X @ Y.T
+        diff2 = np.maximum(diff2, 0.0)
+        kap = np.exp(-self.a * diff2 / 2.0)
+        S = X[:, :d].sum(1)[:, None] - Y[:, :d].sum(1)[None, :]
+        rD = X[:, d][:, None] - Y[:, d][None, :]
+        cols = self.idx if which != "al" else self.idx + 1          # aligned: shifted index i = coordinate i+1
+        ri = X[:, cols][:, None, :] - Y[:, cols][None, :, :]
+        return kap, S, rD, ri
+
+    def block(self, opx, opy, X, Y):
+        a, d = self.a, self.d
+        key = (opx, opy)
+        if "lap" not in key:
+            return self._r(super().block(opx, opy, X, Y))
+        h = d / float(self.MC)
+        if key == ("lap", "lap"):
+            kap, _, _, ri = self._geom(X, Y, "al")
+            g = a * a * ri * ri - a
+            return self._r(h * h * (g.sum(2) ** 2 + (2 * a * a - 4 * a ** 3 * ri * ri).sum(2)) * kap)
+        if opy == "lap":                                   # I / dt / div in x, Laplacian in y: geometry ys
+            kap, S, rD, ri = self._geom(X, Y, "ys")
+            sg = (a * a * ri * ri - a).sum(2)
+            if opx == "I":
+                P = h * sg
+            elif opx == "dt":
+                P = -a * rD * h * sg
+            else:
+                P = h * (2 * a * a * ri + (a * a * S)[:, :, None] - a ** 3 * S[:, :, None] * ri * ri).sum(2)
+            return self._r(P * kap)
+        kap, S, rD, ri = self._geom(X, Y, "xs")            # Laplacian in x of I / dt / div in y: geometry xs
+        sg = (a * a * ri * ri - a).sum(2)
+        if opy == "I":
+            P = h * sg
+        elif opy == "dt":
+            P = a * rD * h * sg
+        else:
+            P = -h * (2 * a * a * ri + (a * a * S)[:, :, None] - a ** 3 * S[:, :, None] * ri * ri).sum(2)
+        return self._r(P * kap)
+
+    # ---------------------------------------------------------------- factor (models/GP.py:258-268)
+    def factor(self, K):
+        """-> (A_loss, Kp_solve): the inverse the loss sees, (L16 L16^T)^-1, and the matrix
+        ``right_vector`` is solved against, float16(L L^T) with L = U sqrt(S + nugget)."""
+        K = 0.5 * (K + K.T)
+        lam, U = np.linalg.eigh(K)                          # symmetric K: SVD = (U sign(lam), |lam|, U)
+        self.K_eig_min = float(lam.min())
+        s = np.abs(lam) + self.nugget
+        L = U * np.sqrt(s)[None, :]                         # :263
+        Kp = (L @ L.T)                                      # :267
+        L16 = self._r(L) if self.round_factor else L        # :266
+        Kp16 = self._r(Kp)                                  # :268
+        self.cholesky_phi_phi_perturb = L16
+        G = L16 @ L16.T
+        A = np.linalg.inv(G)
+        return 0.5 * (A + A.T), Kp16
+
+    def GPsolver(self, x_dom, x_bdy, GN_steps=20):
+        K = self.kernel_phi_phi(x_dom, x_bdy)
+        A, Kp16 = self.factor(K)
+        self._newton(A, GN_steps)
+        z = self._b(self.sol, self._bdy_g)
+        N, Nb = self.N_domain, self.N_boundary
+        if self.round16:
+            z[2 * N + Nb:3 * N + Nb] = f16(z[2 * N + Nb:3 * N + Nb])   # time_der_rep(...).astype(float16), :719
+        self.right_vector = np.linalg.solve(Kp16, z)[:, None]          # :599
+        return self.predict(self.x_t_domain)
+
+    # ---------------------------------------------------------------- inference
+    def compute_gradient(self, X, sol=None):
+        """(n, d+1) array whose spatial columns SUM to div_x of the posterior mean (each holds div/d) and whose last
+        column is dt: all the solvers consume is sum_i z_i (f = sigma u sum z, equations.py:290-304), and the
+        per-coordinate gradient of the shifted Hutchinson features is not needed anywhere on the path."""
+        X = np.asarray(X, dtype=np.float64)
+        rv = self.right_vector
+        out = np.empty((X.shape[0], self.d + 1))
+        out[:, :self.d] = (self._features("div", X) @ rv) / self.d
+        out[:, self.d] = (self._features("dt", X) @ rv)[:, 0]
+        return out
+
+    def div_x(self, X):
+        """sum_{k<d} d/dx_k of the posterior mean = div_x_t_kernel_x_t_phi @ right_vector (:397-411)."""
+        return self._features("div", X) @ self.right_vector

@@ -7,9 +7,10 @@ MAX_LEVEL = 5
 MAX_Q = 6
 MAX_DIM = 252
 GP_TILE = 32
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 MODE_MLP, MODE_GENERATE, MODE_ACCUMULATE = 0, 1, 2
+RNG_COMPAT_CRN = 1
 EQ_GRAD_DEPENDENT_NONLINEAR = 0
 
 
@@ -20,7 +21,7 @@ class Problem(C.Structure):
 
 class Rng(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("stream", C.c_uint32), ("root0", C.c_uint32),
-                ("rank", C.c_int32), ("world", C.c_int32)]
+                ("rank", C.c_int32), ("world", C.c_int32), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class Term(C.Structure):
@@ -71,6 +72,13 @@ SIGNATURES = {
     "scasml_gemv": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "scasml_gp_newton_system": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "scasml_gp_gram_compat": (C.c_int, [C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                        C.c_void_p, C.c_void_p]),
+    "scasml_round16_diag": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_double, C.c_void_p]),
+    "scasml_round16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    "scasml_gp_compat_pack": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "scasml_gp_eval_compat": (C.c_int, [C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p,
+                                        C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "scasml_cholesky": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_void_p]),
     "scasml_cholesky_inverse": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "scasml_trsm_lower": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),

@@ -11,7 +11,7 @@ struct GpArgs {
     const float *points;       // n_inf x kp
     const float *colloc_frag;  // [n_tiles][NK4][64][4]
     const uint16_t *colloc_bf16;  // [n_tiles][3 planes][kp/16][64][8] truncated-bf16 planes
-    const uint16_t *colloc_f16;   // [n_tiles][2 planes][kp/16][64][8] fp16 planes (h, 2^11 * l)
+    const uint16_t *colloc_f16;   // [n_tiles][2 planes][kp/16][64][8] fp16 planes (h, l = fp16(v - h), unscaled)
     const float *coef;         // [n_pad][16]  FP32-kernel constants
     const float *coef2;        // [n_pad][16]  exponent-scaled constants of the 16-bit kernels (gp_epilogue_scaled)
     int32_t first_bdy_tile;    // collocation tiles from here on hold boundary (and padding) rows only: cL = ct = cS = 0

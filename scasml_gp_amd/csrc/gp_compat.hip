@@ -1,0 +1,287 @@
+// The reference's surrogate AS CODED (GP.compat = "reference"): the 5-index Hutchinson "Laplacian" on a cyclically
+// shifted argument (models/GP.py:28-39, 87-105, 119-127, 141-179) and the float16 rounding of every kernel entry
+// (:43 and the .astype(jnp.float16) that closes every derivative kernel).  SURVEY.md Appendix E-5/E-6; derivation and
+// the CPU statement: oracle/gp_compat.py.  This is the parity mode for the reference's own experiment protocol
+// (1000 + 200 collocation points, 1200 evaluation points, n = rho = 2: 6.8e7 kernel pairs per solve) -- the default
+// surrogate with the exact operators runs on the MFMA kernels of gp_eval_bf16.hip.  Arithmetic is float64 throughout so
+// that the float16 rounding of an entry is decided exactly as the float64 NumPy statement decides it.
+//
+// Geometries (v' = (v_2, ..., v_d, t, v_1), the shift of models/GP.py:91-93; time is the last column):
+//   al: r = x - y      everything without a Laplacian, and lap_x lap_y (components i+1)
+//   ys: r = x - y'     lap_y of kappa, dt_x kappa, div_x kappa
+//   xs: r = x' - y     lap_x of kappa, dt_y kappa, div_y kappa
+// idx[5] indexes the SHIFTED vector (0 <= i < d): component i of x', i.e. original coordinate i+1.
+#include "common.hpp"
+
+namespace scasml {
+
+constexpr int kMC = 5;   // models/GP.py:30
+
+struct CompatIdx {
+    int32_t i[kMC];
+};
+
+__device__ __forceinline__ double round16(double v, int on) {
+    // float64 -> float16 (RNE, one rounding: v_cvt_f16_f32 of a float64 would round twice) -> float64
+    if (!on) return v;
+    const double av = fabs(v);
+    if (!(av == av)) return v;
+    if (av >= 65520.0) return v < 0 ? -INFINITY : INFINITY;
+    if (av < 5.9604644775390625e-8 * 0.5) return v < 0 ? -0.0 : 0.0;     // below half the smallest subnormal
+    int e;
+    frexp(av, &e);                                     // av = m 2^e, m in [0.5, 1)
+    int ulp_exp = e - 11;                              // 11 significant bits
+    if (ulp_exp < -24) ulp_exp = -24;                  // subnormal spacing 2^-24
+    const double q = ldexp(av, -ulp_exp);              // integer part carries the kept bits
+    const double r = rint(q);                          // RNE (default rounding mode)
+    const double o = ldexp(r, ulp_exp);
+    return v < 0 ? -o : o;
+}
+
+// The three geometries of one (x, y) pair.  x, y: pointers to d+1 coordinates with strides sx, sy (elements).
+struct PairGeom {
+    double kap[3];   // al, ys, xs
+    double S[3];
+    double rD[3];
+    double ri[3][kMC];
+};
+
+template <class FX, class FY>
+__device__ __forceinline__ void pair_geometry(int d, double a, const CompatIdx &ix, FX x, FY y, PairGeom &g) {
+    const int D = d + 1;
+    double r2[3] = {0.0, 0.0, 0.0}, S[3] = {0.0, 0.0, 0.0};
+    // one pass over k: x_k, x'_k = x_{k+1 mod D}, y_k, y'_k
+    double xk = x(0), yk = y(0);
+    const double x0 = xk, y0 = yk;
+    for (int k = 0; k < D; ++k) {
+        const double xn = k + 1 < D ? x(k + 1) : x0, yn = k + 1 < D ? y(k + 1) : y0;
+        const double ral = xk - yk, rys = xk - yn, rxs = xn - yk;
+        r2[0] = fma(ral, ral, r2[0]);
+        r2[1] = fma(rys, rys, r2[1]);
+        r2[2] = fma(rxs, rxs, r2[2]);
+        if (k < d) {
+            S[0] += ral;
+            S[1] += rys;
+            S[2] += rxs;
+        } else {
+            g.rD[0] = ral;
+            g.rD[1] = rys;
+            g.rD[2] = rxs;
+        }
+        xk = xn;
+        yk = yn;
+    }
+#pragma unroll
+    for (int j = 0; j < kMC; ++j) {
+        const int i = ix.i[j];                                  // 0 <= i < d, so i + 1 <= d
+        g.ri[0][j] = x(i + 1) - y(i + 1);                       // al: shifted component i of (x - y)'
+        g.ri[1][j] = x(i) - y(i + 1);                           // ys: x_i - y'_i
+        g.ri[2][j] = x(i + 1) - y(i);                           // xs: x'_i - y_i
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        g.kap[q] = exp(-0.5 * a * r2[q]);
+        g.S[q] = S[q];
+    }
+}
+
+// The 16 operator pairs (opx, opy), ops: 0 = I, 1 = Lap, 2 = dt, 3 = div, each rounded to float16 if asked.
+__device__ __forceinline__ void compat_blocks(int d, double a, const PairGeom &g, int r16, double (&P)[4][4]) {
+    const double h = (double)d / kMC, a2 = a * a, a3 = a2 * a;
+    const double kal = g.kap[0], S = g.S[0], rt = g.rD[0];
+    double sg[3], mix[3], dbl = 0.0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        double s = 0.0, m = 0.0;
+#pragma unroll
+        for (int j = 0; j < kMC; ++j) {
+            const double r = g.ri[q][j];
+            s += a2 * r * r - a;
+            m += 2.0 * a2 * r + a2 * g.S[q] - a3 * g.S[q] * r * r;
+            if (q == 0) dbl += 2.0 * a2 - 4.0 * a3 * r * r;
+        }
+        sg[q] = s;
+        mix[q] = m;
+    }
+    P[0][0] = kal;
+    P[0][2] = a * rt * kal;
+    P[0][3] = a * S * kal;
+    P[2][0] = -a * rt * kal;
+    P[2][2] = (a - a2 * rt * rt) * kal;
+    P[2][3] = -a2 * rt * S * kal;
+    P[3][0] = -a * S * kal;
+    P[3][2] = -a2 * rt * S * kal;
+    P[3][3] = (a * d - a2 * S * S) * kal;
+    P[0][1] = h * sg[1] * g.kap[1];                                  // lap_y kappa            [ys]
+    P[2][1] = -a * g.rD[1] * h * sg[1] * g.kap[1];                   // dt_x lap_y             [ys]
+    P[3][1] = h * mix[1] * g.kap[1];                                 // div_x lap_y            [ys]
+    P[1][0] = h * sg[2] * g.kap[2];                                  // lap_x kappa            [xs]
+    P[1][2] = a * g.rD[2] * h * sg[2] * g.kap[2];                    // lap_x dt_y             [xs]
+    P[1][3] = -h * mix[2] * g.kap[2];                                // lap_x div_y            [xs]
+    P[1][1] = h * h * (sg[0] * sg[0] + dbl) * kal;                   // lap_x lap_y            [al]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) P[i][j] = round16(P[i][j], r16);
+}
+
+// ---------------------------------------------------------------------------------- Gram (models/GP.py:182-258)
+__global__ void gp_gram_compat_kernel(int d, double a, const float *x_dom, int n_dom, const float *x_bdy, int n_bdy,
+                                      CompatIdx ix, int r16, double *K) {
+    const int N = n_dom + n_bdy;
+    const int i = blockIdx.y * blockDim.y + threadIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N || j >= N) return;
+    const int64_t M = 4 * (int64_t)n_dom + n_bdy;
+    const float *xi = i < n_dom ? x_dom + (int64_t)i * (d + 1) : x_bdy + (int64_t)(i - n_dom) * (d + 1);
+    const float *yj = j < n_dom ? x_dom + (int64_t)j * (d + 1) : x_bdy + (int64_t)(j - n_dom) * (d + 1);
+    PairGeom g;
+    pair_geometry(d, a, ix, [&](int k) { return (double)xi[k]; }, [&](int k) { return (double)yj[k]; }, g);
+    double P[4][4];
+    compat_blocks(d, a, g, r16, P);
+    const int nops_i = i < n_dom ? 4 : 1, nops_j = j < n_dom ? 4 : 1;
+    for (int ox = 0; ox < nops_i; ++ox) {
+        const int64_t row = ox == 0 ? i : (int64_t)n_dom + n_bdy + (int64_t)(ox - 1) * n_dom + i;
+        for (int oy = 0; oy < nops_j; ++oy) {
+            const int64_t col = oy == 0 ? j : (int64_t)n_dom + n_bdy + (int64_t)(oy - 1) * n_dom + j;
+            K[row * M + col] = P[ox][oy];
+        }
+    }
+}
+
+// diagonal of K + nugget I rounded to float16 (kernel_phi_phi_perturb.astype(float16), models/GP.py:268): the entries of K are
+// float16 values already, so only the diagonal moves
+__global__ void round16_diag_kernel(double *A, int64_t M, int64_t lda, double nugget) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) A[i * lda + i] = round16(A[i * lda + i] + nugget, 1);
+}
+
+__global__ void round16_vec_kernel(double *v, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = round16(v[i], 1);
+}
+
+// ---------------------------------------------------------------------------------- evaluation
+// One wavefront per evaluation point; lanes stride the collocation points (transposed float64 copy, so a lane's reads
+// of coordinate k are contiguous across lanes); the point's coordinates sit in LDS.  Outputs as scasml_gp_eval:
+// (u_hat, div_x u_hat, eps_PDE, dt u_hat) and optionally the "Laplacian".
+// Feature rows (models/GP.py:326-411, 630-651): with (c0, cL, ct, cS) the right_vector entries of the u / Lap / dt / div
+// features of a domain point and c0 that of a boundary point,
+//   L^x u_hat = sum_j c0 P[x][0] + cL P[x][1] + ct P[x][2] + cS P[x][3],   x in {I, dt, div, lap}.
+__global__ __launch_bounds__(256) void gp_eval_compat_kernel(int d, double a, double sigma, const double *colloc_t, int n_dom,
+                                                             int n_bdy, int64_t ldc, const double *rv, CompatIdx ix, int r16,
+                                                             const float *points, int64_t n_inf, int kp, float4 *out4,
+                                                             float *lap_out) {
+    extern __shared__ double xs_all[];   // 4 waves x (d + 1)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int D = d + 1;
+    int64_t row = (int64_t)blockIdx.x * 4 + wv;
+    const bool valid = row < n_inf;
+    if (!valid) row = n_inf - 1;
+    double *xs = xs_all + wv * D;
+    for (int k = lane; k < D; k += 64) xs[k] = (double)points[row * kp + k];
+    __syncthreads();
+    const int N = n_dom + n_bdy;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};   // I, lap, dt, div applied in x
+    for (int j = lane; j < N; j += 64) {
+        PairGeom g;
+        pair_geometry(d, a, ix, [&](int k) { return xs[k]; }, [&](int k) { return colloc_t[(int64_t)k * ldc + j]; }, g);
+        double P[4][4];
+        compat_blocks(d, a, g, r16, P);
+        const double c0 = rv[j];
+        double cL = 0.0, ct = 0.0, cS = 0.0;
+        if (j < n_dom) {
+            cL = rv[(int64_t)N + j];
+            ct = rv[(int64_t)N + n_dom + j];
+            cS = rv[(int64_t)N + 2 * n_dom + j];
+        }
+#pragma unroll
+        for (int ox = 0; ox < 4; ++ox) acc[ox] += c0 * P[ox][0] + cL * P[ox][1] + ct * P[ox][2] + cS * P[ox][3];
+    }
+#pragma unroll
+    for (int ox = 0; ox < 4; ++ox)
+        for (int o = 32; o > 0; o >>= 1) acc[ox] += __shfl_xor(acc[ox], o);
+    if (valid && lane == 0) {
+        const double s2 = sigma * sigma;
+        const double u = acc[0], lp = acc[1], dt = acc[2], dv = acc[3];
+        const double eps = dt + (s2 * u - 1.0 / d - 0.5 * s2) * dv + 0.5 * s2 * lp;      // models/GP.py:767-768
+        out4[row] = make_float4((float)u, (float)dv, (float)eps, (float)dt);
+        if (lap_out) lap_out[row] = (float)lp;
+    }
+}
+
+__global__ void transpose_colloc_kernel(const float *x_dom, int n_dom, const float *x_bdy, int n_bdy, int d, int64_t ldc, double *out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = blockIdx.y;
+    const int N = n_dom + n_bdy;
+    if (j >= N) return;
+    const float *src = j < n_dom ? x_dom + (int64_t)j * (d + 1) : x_bdy + (int64_t)(j - n_dom) * (d + 1);
+    out[(int64_t)k * ldc + j] = (double)src[k];
+}
+
+static int check_idx(const int32_t *idx_h, int d, CompatIdx &ix, const char *who) {
+    if (!idx_h) return fail(SCASML_ERR_ARG, "%s: idx is null", who);
+    for (int j = 0; j < kMC; ++j) {
+        if (idx_h[j] < 0 || idx_h[j] >= d) return fail(SCASML_ERR_ARG, "%s: idx[%d] = %d outside [0, d)", who, j, idx_h[j]);
+        for (int q = 0; q < j; ++q)
+            if (idx_h[q] == idx_h[j]) return fail(SCASML_ERR_ARG, "%s: idx has a repeated entry %d", who, idx_h[j]);
+        ix.i[j] = idx_h[j];
+    }
+    return 0;
+}
+
+}  // namespace scasml
+
+using namespace scasml;
+
+extern "C" int scasml_gp_gram_compat(int32_t d, double a, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy,
+                                     const int32_t *idx_h, int32_t round16, double *K, void *stream) {
+    if (!x_dom || !K || (n_bdy > 0 && !x_bdy)) return fail(SCASML_ERR_ARG, "gp_gram_compat: null argument");
+    if (d < kMC || n_dom < 1 || n_bdy < 0) return fail(SCASML_ERR_ARG, "gp_gram_compat: bad sizes (d >= %d needed)", kMC);
+    CompatIdx ix;
+    if (int rc = check_idx(idx_h, d, ix, "gp_gram_compat")) return rc;
+    const int N = n_dom + n_bdy;
+    hipLaunchKernelGGL(gp_gram_compat_kernel, dim3((N + 15) / 16, (N + 15) / 16), dim3(16, 16), 0, (hipStream_t)stream, d, a,
+                       x_dom, n_dom, x_bdy, n_bdy, ix, round16, K);
+    return check_launch("gp_gram_compat launch");
+}
+
+extern "C" int scasml_round16_diag(double *A, int64_t M, int64_t lda, double nugget, void *stream) {
+    if (!A || M < 1 || lda < M) return fail(SCASML_ERR_ARG, "round16_diag: bad argument");
+    hipLaunchKernelGGL(round16_diag_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A, M, lda, nugget);
+    return check_launch("round16_diag launch");
+}
+
+extern "C" int scasml_round16(double *v, int64_t n, void *stream) {
+    if (!v || n < 0) return fail(SCASML_ERR_ARG, "round16: bad argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(round16_vec_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, v, n);
+    return check_launch("round16 launch");
+}
+
+extern "C" int scasml_gp_compat_pack(int32_t d, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy,
+                                     double *colloc_t, int64_t ldc, void *stream) {
+    if (!x_dom || !colloc_t || (n_bdy > 0 && !x_bdy) || d < 1 || n_dom < 1 || n_bdy < 0 || ldc < n_dom + n_bdy)
+        return fail(SCASML_ERR_ARG, "gp_compat_pack: bad argument");
+    const int N = n_dom + n_bdy;
+    hipLaunchKernelGGL(transpose_colloc_kernel, dim3((N + 255) / 256, d + 1), dim3(256), 0, (hipStream_t)stream, x_dom, n_dom,
+                       x_bdy, n_bdy, d, ldc, colloc_t);
+    return check_launch("gp_compat_pack launch");
+}
+
+extern "C" int scasml_gp_eval_compat(int32_t d, double a, double sigma_eq, const double *colloc_t, int32_t n_dom, int32_t n_bdy,
+                                     int64_t ldc, const double *rv, const int32_t *idx_h, int32_t round16, const float *points,
+                                     int64_t n_inf, int32_t kp, float *out4, float *lap, void *stream) {
+    if (n_inf == 0) return 0;
+    if (!colloc_t || !rv || !points || !out4 || n_inf < 0) return fail(SCASML_ERR_ARG, "gp_eval_compat: bad argument");
+    if (d < kMC || d > SCASML_MAX_DIM || n_dom < 1 || n_bdy < 0 || ldc < n_dom + n_bdy || kp < d + 1)
+        return fail(SCASML_ERR_ARG, "gp_eval_compat: bad sizes");
+    CompatIdx ix;
+    if (int rc = check_idx(idx_h, d, ix, "gp_eval_compat")) return rc;
+    const int64_t blocks = (n_inf + 3) / 4;
+    if (blocks > 0x7FFFFFFF) return fail(SCASML_ERR_UNSUPPORTED, "gp_eval_compat: too many points");
+    const size_t lds = 4 * (size_t)(d + 1) * sizeof(double);
+    hipLaunchKernelGGL(gp_eval_compat_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, d, a, sigma_eq, colloc_t,
+                       n_dom, n_bdy, ldc, rv, ix, round16, points, n_inf, kp, reinterpret_cast<float4 *>(out4), lap);
+    return check_launch("gp_eval_compat launch");
+}

@@ -14,8 +14,9 @@
 // VGPRs, sum_i over the dims is a log2(G)-step xor-shuffle, sum over Monte-Carlo samples is a
 // register accumulation, and nothing but the root row is read from or written to HBM in
 // MODE_MLP.  For ScaSML the same walk runs twice around the batched GP evaluation:
-// MODE_GENERATE emits every tree point (coalesced float4 rows), MODE_ACCUMULATE replays the
-// identical Philox stream and consumes (u_hat, div u_hat, eps_PDE) per point.
+// MODE_GENERATE emits every tree point (coalesced float4 rows), MODE_ACCUMULATE reads those states
+// back (recovering the normals from them; it replays Philox only where that would be inaccurate, see
+// kReadbackMinVol, and for the full-history draws) and consumes (u_hat, div u_hat, eps_PDE) per point.
 #include "common.hpp"
 #include "philox_normal.hpp"
 
@@ -32,6 +33,7 @@ struct TreeArgs {
     int64_t ppr;  // points per root = plan.sites[n] + 1
     uint32_t k0, k1, stream, root0;
     int32_t rank, world;
+    int32_t crn;  // SCASML_RNG_COMPAT_CRN: terminal draws keyed by the call's k = 0 position (reference key reuse, E-2/E-3)
     int32_t d, G, logG, kp;
     float T, mu, sigma, clip;
 };
@@ -50,6 +52,12 @@ __device__ __forceinline__ float clip1(float v, float c) { return v < -c ? -c : 
 __device__ __forceinline__ float rcp_fast(float v) { return __builtin_amdgcn_rcpf(v); }
 __device__ __forceinline__ float sqrt_fast(float v) { return __builtin_amdgcn_sqrtf(v); }
 __device__ __forceinline__ float exp_fast(float v) { return __builtin_amdgcn_exp2f(v * 1.44269504088896341f); }
+
+// ACCUMULATE recovers the terminal normals as (X_T - x - drift) / vol.  X_T was rounded to binary32 when it was stored
+// (|X_T| 2^-24 ~ 3e-8), so the recovered normal is off by ~3e-8 / vol and the z estimator, which divides by T - t, by
+// ~g 1.2e-7 / (sqrt(T-t) (T-t) sqrt(mg)): 1e-4 g at T - t = 1.6e-3 but 0.03 g one fp16 ulp below T.  Below this
+// volatility (sigma sqrt(T-t) < 1e-2, i.e. T - t < 1.6e-3 at sigma = 0.25) the normals are replayed instead.
+constexpr float kReadbackMinVol = 1e-2f;
 
 template <int VAR, int MODE>
 struct Walker {
@@ -113,7 +121,7 @@ struct Walker {
 
     // ---- one (n', l) term of the Picard sum ------------------------------------------------
     template <int N, int L, bool TOP>
-    __device__ __forceinline__ void level(float4 x, float t, float tau, uint32_t base, uint32_t &o, float &u, float4 &z) {
+    __device__ __forceinline__ void level(float4 x, float t, float tau, uint32_t base, uint32_t cbase, uint32_t &o, float &u, float4 &z) {
         const scasml_term &tm = a.plan.term[N][L];
         const int q = tm.q, mc = tm.mc;
         const uint32_t s_l = (uint32_t)tm.sites_l, s_lm = (uint32_t)tm.sites_lm1;
@@ -124,6 +132,9 @@ struct Walker {
                 continue;
             }
             float4 X = x, W = f4(0.0f);
+            // compat_crn: the children of every node k draw their terminal normals where the k = 0 children do
+            // (MLP.py:167-168,178: one fixed key per uz_solve call, so calls of equal shape share their draws)
+            const uint32_t c_plus = cbase + o + 1u, c_minus = c_plus + s_l;
             for (int k = 0; k < q; ++k) {
                 const uint32_t site = base + o;
                 o += 1;
@@ -154,7 +165,8 @@ struct Walker {
                     dplus = rcp_fast(fmaf(tau, tm.dplus[k], 1e-6f));   // MLP.py:249 (stale) / ScaSML.py:253
                     dminus = rcp_fast(fmaf(tau, tm.cfrac[k], 1e-6f));  // MLP.py:270
                 } else {                                         // MLP_full_history.py:133-145
-                    const float4 xi = normals(site);
+                    // compat_crn: the level-0 draws ARE the terminal draws (MLP_full_history.py:92-93,99,138: one subkey)
+                    const float4 xi = normals(a.crn && L == 0 ? base + (uint32_t)m : site);
                     const float D = uniform_tau(site, root, a.stream, a.k0, a.k1) * tau;
                     const float sD = sqrt_fast(D);
                     X = fma4(a.sigma * sD, xi, add4(x, a.mu * D));
@@ -169,7 +181,7 @@ struct Walker {
 
                 float uc;
                 float4 zc;
-                uz<L, false>(X, tk, base + o, uc, zc);
+                uz<L, false>(X, tk, base + o, (a.crn && VAR == 0) ? c_plus : base + o, uc, zc);
                 o += s_l;
                 if constexpr (MODE != SCASML_MODE_GENERATE) {
                     const float y = f_eval(uc, zc, gp) * (wk * inv_mc);
@@ -177,7 +189,7 @@ struct Walker {
                     z = fma4(y * dplus, wvec, z);                // MLP.py:249
                 }
                 if constexpr (L > 0) {
-                    uz<L - 1, false>(X, tk, base + o, uc, zc);
+                    uz<L - 1, false>(X, tk, base + o, (a.crn && VAR == 0) ? c_minus : base + o, uc, zc);
                     o += s_lm;
                     if constexpr (MODE != SCASML_MODE_GENERATE) {
                         const float y = f_eval(uc, zc, gp) * (wk * inv_mc);
@@ -191,12 +203,12 @@ struct Walker {
                 }
             }
         }
-        if constexpr (L + 1 < N) level<N, L + 1, TOP>(x, t, tau, base, o, u, z);
+        if constexpr (L + 1 < N) level<N, L + 1, TOP>(x, t, tau, base, cbase, o, u, z);
     }
 
     // ---- uz_solve at compile-time level N -----------------------------------------------------
     template <int N, bool TOP>
-    __device__ __forceinline__ void uz(float4 x, float t, uint32_t base, float &u_out, float4 &z_out) {
+    __device__ __forceinline__ void uz(float4 x, float t, uint32_t base, uint32_t cbase, float &u_out, float4 &z_out) {
         if constexpr (N == 0) {                                  // MLP.py:205-207
             u_out = 0.0f;
             z_out = f4(0.0f);
@@ -208,7 +220,7 @@ struct Walker {
             float4 sz = f4(0.0f);
             // ACCUMULATE reads the stored X_T back: the rows of the next sample are requested before this one is
             // consumed (one dependent HBM round trip per sample otherwise: the pass is latency-bound)
-            const bool readback = MODE == SCASML_MODE_ACCUMULATE && vol > 0.0f;
+            const bool readback = MODE == SCASML_MODE_ACCUMULATE && vol >= kReadbackMinVol;
             float4 XT_next = f4(0.0f), gp_next = f4(0.0f);
             if (MODE == SCASML_MODE_ACCUMULATE && !(TOP && a.world > 1)) {
                 if (readback) XT_next = load_point(base);
@@ -232,17 +244,17 @@ struct Walker {
                     }
                     // The emitting pass stored X_T bit for bit: recover the normals (one rounding of a difference
                     // of O(1) numbers: ~1e-6 relative) instead of replaying Philox + Box-Muller, which would be most
-                    // of this pass's VALU work.  At t = T (vol = 0) they cannot be recovered: replay.
+                    // of this pass's VALU work.  Close to T they cannot be recovered accurately (kReadbackMinVol): replay.
                     if (__builtin_expect(readback, 1)) {
                         const float rv = rcp_fast(vol);
                         nrm = mul4(fma4(rv, add4(XT, -drift), f4_scale(x, -rv)), mask);
                     } else {
-                        nrm = normals(site);
+                        nrm = normals(cbase + (uint32_t)m);
                         XT = fma4(vol, nrm, add4(x, drift));
                     }
                 } else {
                     if (!owned(TOP)) continue;
-                    nrm = normals(site);
+                    nrm = normals(cbase + (uint32_t)m);
                     XT = fma4(vol, nrm, add4(x, drift));
                 }
                 if constexpr (MODE == SCASML_MODE_GENERATE) {
@@ -258,7 +270,7 @@ struct Walker {
             const float zs = inv_mg * rcp_fast(VAR == 0 ? tau + 1e-6f : tau);   // MLP.py:201 / MLP_full_history.py:122
             float4 z = make_float4(sz.x * zs, sz.y * zs, sz.z * zs, sz.w * zs);
             uint32_t o = (uint32_t)mg;
-            level<N, 0, TOP>(x, t, tau, base, o, u, z);
+            level<N, 0, TOP>(x, t, tau, base, cbase, o, u, z);
             if (!(TOP && a.world > 1)) {                         // MLP.py:272-274
                 u = clip1(u, a.clip);
                 z = make_float4(clip1(z.x, a.clip), clip1(z.y, a.clip), clip1(z.z, a.clip), clip1(z.w, a.clip));
@@ -304,7 +316,7 @@ __global__ __launch_bounds__(256) void picard_tree_kernel(const TreeArgs a) {
     }
     float u;
     float4 z;
-    w.template uz<N, true>(x, t, 0u, u, z);
+    w.template uz<N, true>(x, t, 0u, 0u, u, z);
     if constexpr (MODE != SCASML_MODE_GENERATE) {
         if (valid) {
             float *out = a.out_uz + local * (a.d + 1);
@@ -461,6 +473,7 @@ extern "C" int scasml_picard_tree(const scasml_problem *prob, const scasml_plan 
     a.root0 = rng.root0;
     a.rank = rng.rank;
     a.world = rng.world;
+    a.crn = (rng.flags & SCASML_RNG_COMPAT_CRN) ? 1 : 0;
     a.d = prob->d;
     a.kp = scasml_point_stride(prob->d);
     a.G = ceil_pow2(a.kp / 4);

@@ -10,9 +10,15 @@ What runs where:
   no autodiff and no per-iteration GEMM is needed ........... scasml_gp_newton_b / _gemv / _gp_newton_system
 * predict / compute_gradient / compute_PDE_loss (:653-687, 746-769) .. scasml_gp_eval, scasml_gp_gradient
 
-Deviations from the reference, all documented in DESIGN.md: exact Laplacian features instead of
-the 5-index subsample (:28-39; the index set is threefry-dependent), no float16 rounding of
-L / K_p / outputs, Newton start at 0 instead of 1e-3*N(0,1) from PRNGKey(0) (:501).
+Two surrogates (``compat``):
+* ``None`` (default): the operators the reference documents -- exact Laplacian features, no float16 rounding.
+* ``"reference"``: the surrogate the reference's code actually builds: the 5-index
+  Hutchinson "Laplacian" on a cyclically shifted argument (:28-39, 87-105, 119-179) with a caller-supplied index set
+  (``laplacian_idx``; the reference's comes from JAX threefry), every kernel entry rounded to float16 (:43), K_p rounded
+  to float16 for the right_vector solve (:267-268, 599), z4 rounded to float16 (:719).  float64 kernels in
+  csrc/gp_compat.hip; CPU statement in oracle/gp_compat.py.
+Remaining deviations in both: Newton start at 0 instead of 1e-3*N(0,1) from PRNGKey(0) (:501); Cholesky instead of
+the SVD factor, so the float16 rounding of L itself (:266) has no counterpart (no measurable effect).
 """
 import ctypes as C
 import os
@@ -29,7 +35,17 @@ def _round_up(v, m):
 class GP(object):
     '''Gaussian Kernel Solver for high dimensional PDE'''
 
-    def __init__(self, equation):
+    def __init__(self, equation, compat=None, laplacian_idx=None):
+        if compat not in (None, "reference"):
+            raise ValueError("compat must be None or 'reference'")
+        self.compat = compat
+        self.laplacian_idx = None
+        if compat == "reference":
+            idx = np.asarray(laplacian_idx if laplacian_idx is not None else [], dtype=np.int32).reshape(-1)
+            if idx.size != 5 or len(set(idx.tolist())) != 5 or idx.min() < 0 or idx.max() >= equation.n_input - 1:
+                raise ValueError("compat='reference' needs laplacian_idx: five distinct indices in [0, d) "
+                                 "(models/GP.py:35 draws them from PRNGKey(0))")
+            self.laplacian_idx = np.ascontiguousarray(idx)
         self.equation = equation
         equation.geometry()
         self.T = equation.T
@@ -75,11 +91,29 @@ class GP(object):
 
     def _eval_device(self, pts):
         torch = _lib.require_gpu()
-        lib = _lib.load()
         out = torch.empty((pts.shape[0], 4), dtype=torch.float32, device="cuda")
-        model = self._device_model()
-        _lib.check(lib.scasml_gp_eval(C.byref(model), _lib.ptr(pts), pts.shape[0], _lib.ptr(out), None, _lib.stream_ptr()), "gp_eval")
+        self._eval_rows(pts, pts.shape[0], 0, None, out)
         return out
+
+    def _eval_rows(self, pts, n_rows, rows_per_site, kinds, out4):
+        """(u_hat, div u_hat, eps_PDE, dt u_hat) of the first n_rows point rows into out4: the one place the solvers and
+        predict / compute_PDE_loss reach the evaluation kernels (kinds: per-site byte of scasml_plan_site_kinds or None)."""
+        lib = _lib.load()
+        if self.right_vector is None:
+            raise _lib.ScasmlError("GP is not trained: call GPsolver(x_domain, x_boundary) first")
+        if self.compat == "reference":
+            N = self.N_domain + self.N_boundary
+            _lib.check(lib.scasml_gp_eval_compat(self.d, 1.0 / float(self.sigma) ** 2, float(self.equation.sigma()),
+                                                 _lib.ptr(self._colloc_t), self.N_domain, self.N_boundary, N, _lib.ptr(self._rv_dev),
+                                                 self.laplacian_idx.ctypes.data_as(C.c_void_p), 1, _lib.ptr(pts), n_rows,
+                                                 pts.shape[1], _lib.ptr(out4), None, _lib.stream_ptr()), "gp_eval_compat")
+            return
+        model = self._device_model()
+        if kinds is None:
+            _lib.check(lib.scasml_gp_eval(C.byref(model), _lib.ptr(pts), n_rows, _lib.ptr(out4), None, _lib.stream_ptr()), "gp_eval")
+        else:
+            _lib.check(lib.scasml_gp_eval_sites(C.byref(model), _lib.ptr(pts), n_rows, rows_per_site, _lib.ptr(kinds),
+                                                _lib.ptr(out4), _lib.stream_ptr()), "gp_eval")
 
     def _predict_device(self, x_dev):
         pts, _ = self._points_device(x_dev)
@@ -98,8 +132,13 @@ class GP(object):
         self._xd, self._xb = xd, xb
         s = _lib.stream_ptr()
         K = torch.empty((M, M), dtype=torch.float64, device="cuda")
-        _lib.check(lib.scasml_gp_gram(self.d, 1.0 / float(self.sigma) ** 2, _lib.ptr(xd), self.N_domain,
-                                      _lib.ptr(xb), self.N_boundary, _lib.ptr(K), s), "gp_gram")
+        if self.compat == "reference":
+            _lib.check(lib.scasml_gp_gram_compat(self.d, 1.0 / float(self.sigma) ** 2, _lib.ptr(xd), self.N_domain, _lib.ptr(xb),
+                                                 self.N_boundary, self.laplacian_idx.ctypes.data_as(C.c_void_p), 1, _lib.ptr(K), s),
+                       "gp_gram_compat")
+        else:
+            _lib.check(lib.scasml_gp_gram(self.d, 1.0 / float(self.sigma) ** 2, _lib.ptr(xd), self.N_domain,
+                                          _lib.ptr(xb), self.N_boundary, _lib.ptr(K), s), "gp_gram")
         Mp = _round_up(M, 32)
         L = torch.eye(Mp, dtype=torch.float64, device="cuda")
         L[:M, :M] = K
@@ -109,7 +148,10 @@ class GP(object):
             raise ValueError("Cholesky decomposition resulted in NaN values.")        # models/GP.py:264-265
         self._L_pad = L
         self.cholesky_phi_phi_perturb = L[:M, :M]
-        K.diagonal().add_(self.nugget)
+        if self.compat == "reference":     # kernel_phi_phi_perturb.astype(float16) (:268): the entries are float16 already, the diagonal moves
+            _lib.check(lib.scasml_round16_diag(_lib.ptr(K), M, M, float(self.nugget), s), "round16_diag")
+        else:
+            K.diagonal().add_(self.nugget)
         return K
 
     def rhs_f(self, x_t_domain):
@@ -148,7 +190,9 @@ class GP(object):
         lib = _lib.load()
         if getattr(self.equation, "eq_id", None) is None:
             raise NotImplementedError("no HIP Newton kernels for equation %s" % type(self.equation).__name__)
-        self.kernel_phi_phi(x_t_domain, x_t_boundary)
+        Kp = self.kernel_phi_phi(x_t_domain, x_t_boundary)
+        if self.compat != "reference":
+            del Kp
         N, Nb, M = self.N_domain, self.N_boundary, self.phi_dim
         L = self._L_pad
         Mp = L.shape[0]
@@ -189,8 +233,21 @@ class GP(object):
             sol = sol + step                                            # alpha = 1, :541,573
             hist.append(residual(sol))
         self.loss_history = hist
-        rv = torch.empty(M, dtype=torch.float64, device="cuda")
-        _lib.check(lib.scasml_gemv(_lib.ptr(A), M, Mp, _lib.ptr(b), _lib.ptr(rv), s), "gemv")   # right_vector = K_p^-1 z, :593-600
+        if self.compat == "reference":
+            # z4 = time_der_rep(sol).astype(float16) (:719), right_vector = solve(float16(K_p), z) (:268, 599): a second
+            # factorisation, of the rounded matrix (still positive definite: rounding moves only the diagonal, by < nugget)
+            _lib.check(lib.scasml_round16(C.c_void_p(b.data_ptr() + 8 * (2 * N + Nb)), N, s), "round16")
+            Lp = torch.eye(Mp, dtype=torch.float64, device="cuda")
+            Lp[:M, :M] = Kp
+            del Kp
+            rv = self._chol_solve_padded(Lp, b, M, 0.0)
+            del Lp
+            if rv is None:
+                raise ValueError("float16-rounded K_p is not positive definite")
+            rv = rv.contiguous()
+        else:
+            rv = torch.empty(M, dtype=torch.float64, device="cuda")
+            _lib.check(lib.scasml_gemv(_lib.ptr(A), M, Mp, _lib.ptr(b), _lib.ptr(rv), s), "gemv")   # right_vector = K_p^-1 z, :593-600
         self.right_vector = rv.cpu().numpy()[:, None]
         self._sol = sol
         self._pack(rv)
@@ -199,6 +256,13 @@ class GP(object):
     def _pack(self, rv):
         torch = _lib.require_gpu()
         lib = _lib.load()
+        if self.compat == "reference":
+            N = self.N_domain + self.N_boundary
+            self._colloc_t = torch.empty((self.d + 1, N), dtype=torch.float64, device="cuda")
+            _lib.check(lib.scasml_gp_compat_pack(self.d, _lib.ptr(self._xd), self.N_domain, _lib.ptr(self._xb), self.N_boundary,
+                                                 _lib.ptr(self._colloc_t), N, _lib.stream_ptr()), "gp_compat_pack")
+            self._rv_dev = rv.to(dtype=torch.float64).contiguous().clone()
+            return
         kp = int(lib.scasml_point_stride(self.d))
         self._n_pad = _round_up(self.N_domain + self.N_boundary, _lib.GP_TILE)
         self._colloc = torch.empty((self._n_pad, kp), dtype=torch.float32, device="cuda")
@@ -235,11 +299,15 @@ class GP(object):
         return {"n_input": np.int64(self.n_input), "x_t_domain": np.asarray(self.x_t_domain),
                 "x_t_boundary": np.asarray(self.x_t_boundary), "right_vector": np.asarray(self.right_vector),
                 "loss_history": np.asarray(getattr(self, "loss_history", []), dtype=np.float64),
-                "nugget": np.float64(self.nugget)}
+                "nugget": np.float64(self.nugget), "compat": np.str_(self.compat or ""),
+                "laplacian_idx": np.asarray(self.laplacian_idx if self.laplacian_idx is not None else [], dtype=np.int32)}
 
     def load_state_dict(self, state):
         if int(state["n_input"]) != self.n_input:
             raise ValueError("state is for n_input=%d, this GP has n_input=%d" % (int(state["n_input"]), self.n_input))
+        if str(state.get("compat", "")) != (self.compat or "") or (
+                self.compat and not np.array_equal(np.asarray(state["laplacian_idx"]), self.laplacian_idx)):
+            raise ValueError("state was trained with compat=%r, laplacian_idx=%s" % (str(state.get("compat", "")), state.get("laplacian_idx")))
         self.nugget = float(state["nugget"])
         self.loss_history = list(np.asarray(state["loss_history"], dtype=np.float64))
         self.load_right_vector(state["x_t_domain"], state["x_t_boundary"], state["right_vector"])
@@ -263,6 +331,9 @@ class GP(object):
         '''(n, d+1) gradient of the posterior mean, time derivative last (models/GP.py:673-687).'''
         torch = _lib.require_gpu()
         lib = _lib.load()
+        if self.compat == "reference":
+            raise NotImplementedError("compat='reference': the per-coordinate gradient of the shifted Hutchinson features is not "
+                                      "built; the solvers use the spatial sum (column 1 of the fused evaluation)")
         pts, was_numpy = self._points_device(x_t_infer)
         grad = torch.empty((pts.shape[0], self.d + 1), dtype=torch.float32, device="cuda")
         model = self._device_model()

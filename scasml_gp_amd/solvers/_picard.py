@@ -19,13 +19,15 @@ def _as_device(x_t, torch):
 
 
 class PicardEngine:
-    def __init__(self, equation, variant, gp=None, seed=0):
+    def __init__(self, equation, variant, gp=None, seed=0, compat_crn=False):
         if getattr(equation, "eq_id", None) is None:
             raise NotImplementedError("no HIP kernels for equation %s (eq_id unset)" % type(equation).__name__)
         self.equation = equation
         self.variant = variant
         self.gp = gp
         self.seed = int(seed)
+        # reference key reuse (Appendix E-2/E-3) as counter keying: SCASML_RNG_COMPAT_CRN in include/scasml_hip.h
+        self.compat_crn = bool(compat_crn)
         self.calls = 0                 # Philox stream id: advances once per uz_solve (E-9)
         self.profile = False           # bench.py: bracket every launch with HIP events on the launch stream
         self._events = []
@@ -96,7 +98,8 @@ class PicardEngine:
             raise ValueError("x_t must have shape (batch, %d), got %s" % (d + 1, tuple(x.shape)))
         B = x.shape[0]
         plan, prob = self.plan(n, par), self.problem()
-        rng = _lib.Rng(self.seed, self.calls if stream_id is None else stream_id, root0, rank, world)
+        flags = _lib.RNG_COMPAT_CRN if self.compat_crn else 0
+        rng = _lib.Rng(self.seed, self.calls if stream_id is None else stream_id, root0, rank, world, flags, 0)
         if stream_id is None:
             self.calls += 1
         out = torch.empty((B, d + 1), dtype=torch.float32, device="cuda")
@@ -105,7 +108,6 @@ class PicardEngine:
             _lib.check(self._timed("picard_mlp", lambda: lib.scasml_picard_tree(
                 C.byref(prob), C.byref(plan), _lib.MODE_MLP, _lib.ptr(x), B, rng, None, None, _lib.ptr(out), None, s)), "picard_tree")
             return out, None, was_numpy
-        model = self.gp._device_model()
         uhat = torch.empty((B,), dtype=torch.float32, device="cuda")
         ppr = int(lib.scasml_points_per_root(C.byref(plan)))
         kp = int(lib.scasml_point_stride(d))
@@ -117,15 +119,14 @@ class PicardEngine:
         kinds = self.site_kinds(n, par, rank, world) if n > 0 else None
         for b0 in range(0, B, chunk):
             nb = min(chunk, B - b0)
-            rng_c = _lib.Rng(rng.seed, rng.stream, root0 + b0, rank, world)
+            rng_c = _lib.Rng(rng.seed, rng.stream, root0 + b0, rank, world, flags, 0)
             xc = x[b0:b0 + nb]
             if n > 0:
                 ob, ub = out[b0:b0 + nb], uhat[b0:b0 + nb]
                 _lib.check(self._timed("picard_generate", lambda: lib.scasml_picard_tree(
                     C.byref(prob), C.byref(plan), _lib.MODE_GENERATE, _lib.ptr(xc), nb, rng_c,
                     _lib.ptr(pts), None, None, None, s)), "picard_tree(generate)")
-                _lib.check(self._timed("gp_eval", lambda: lib.scasml_gp_eval_sites(
-                    C.byref(model), _lib.ptr(pts), nb * ppr, nb, _lib.ptr(kinds), _lib.ptr(vals), s)), "gp_eval")
+                self._timed("gp_eval", lambda: self.gp._eval_rows(pts, nb * ppr, nb, kinds, vals))
                 _lib.check(self._timed("picard_accumulate", lambda: lib.scasml_picard_tree(
                     C.byref(prob), C.byref(plan), _lib.MODE_ACCUMULATE, _lib.ptr(xc), nb, rng_c,
                     _lib.ptr(pts), _lib.ptr(vals), _lib.ptr(ob), _lib.ptr(ub), s)), "picard_tree(accumulate)")

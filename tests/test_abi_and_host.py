@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_struct_layouts_and_version(lib):
-    assert lib.scasml_abi_version() == 1
+    assert lib.scasml_abi_version() == _lib.ABI_VERSION == 2
     for which, st in enumerate((_lib.Problem, _lib.Rng, _lib.Term, _lib.Plan, _lib.GpModel)):
         assert lib.scasml_sizeof(which) == C.sizeof(st)
     assert C.sizeof(_lib.Plan) < 3900          # travels by value in the kernarg segment (4 KiB)
@@ -40,14 +40,14 @@ def test_struct_layouts_and_version(lib):
 def test_argument_errors_are_codes_not_crashes(lib):
     plan = tables.build_plan("quad", 2, 2, 0.5, True)
     prob = _lib.Problem(300, 0, 0.5, -0.1, 0.25, 1.0)            # d too large
-    rc = lib.scasml_picard_tree(C.byref(prob), C.byref(plan), 0, C.c_void_p(8), 4, _lib.Rng(0, 0, 0, 0, 1),
+    rc = lib.scasml_picard_tree(C.byref(prob), C.byref(plan), 0, C.c_void_p(8), 4, _lib.Rng(0, 0, 0, 0, 1, 0, 0),
                                 None, None, C.c_void_p(8), None, None)
     assert rc == -2 and b"d=300" in lib.scasml_last_error()
     prob.d = 20
-    rc = lib.scasml_picard_tree(C.byref(prob), C.byref(plan), 0, C.c_void_p(8), 4, _lib.Rng(0, 0, 0, 2, 2),
+    rc = lib.scasml_picard_tree(C.byref(prob), C.byref(plan), 0, C.c_void_p(8), 4, _lib.Rng(0, 0, 0, 2, 2, 0, 0),
                                 None, None, C.c_void_p(8), None, None)
     assert rc == -1 and b"rank" in lib.scasml_last_error()
-    assert lib.scasml_picard_tree(C.byref(prob), C.byref(plan), 0, None, 0, _lib.Rng(0, 0, 0, 0, 1), None, None, None, None, None) == 0
+    assert lib.scasml_picard_tree(C.byref(prob), C.byref(plan), 0, None, 0, _lib.Rng(0, 0, 0, 0, 1, 0, 0), None, None, None, None, None) == 0
     assert lib.scasml_points_per_root(C.byref(plan)) == 29
     assert lib.scasml_trsm_lower(C.c_void_p(8), 33, C.c_void_p(8), 1, 0, None) == -2
 

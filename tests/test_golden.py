@@ -54,7 +54,7 @@ def test_hip_hits_the_fixtures():
     lib = _lib.load()
     g = _load("oracle_rng.npz")
     out = torch.empty((64, 20), dtype=torch.float32, device="cuda")
-    _lib.check(lib.scasml_debug_normals(_lib.Rng(0, 0, 0, 0, 1), 0, 20, 64, _lib.ptr(out), _lib.stream_ptr()), "normals")
+    _lib.check(lib.scasml_debug_normals(_lib.Rng(0, 0, 0, 0, 1, 0, 0), 0, 20, 64, _lib.ptr(out), _lib.stream_ptr()), "normals")
     assert np.array_equal(out.cpu().numpy().view(np.uint32), g["normals_a"].view(np.uint32))
     m = _load("oracle_mlp_d6.npz")
     eq = Grad_Dependent_Nonlinear(7)

@@ -15,7 +15,7 @@ def test_normals_bit_identical(d, site, seed, stream, root0):
     lib = _lib.load()
     B = 4096
     out = torch.empty((B, d), dtype=torch.float32, device="cuda")
-    rng = _lib.Rng(seed, stream, root0, 0, 1)
+    rng = _lib.Rng(seed, stream, root0, 0, 1, 0, 0)
     _lib.check(lib.scasml_debug_normals(rng, site, d, B, _lib.ptr(out), _lib.stream_ptr()), "debug_normals")
     got = out.cpu().numpy()
     want = philox.normals(seed, stream, np.arange(root0, root0 + B), site, d)
