@@ -50,10 +50,12 @@ typedef struct {
     uint64_t seed;
     uint32_t stream;  /* advanced by the host once per solver call (replaces MLP.py:220 key splitting) */
     uint32_t root0;   /* global index of the first root in this call (root sharding)       */
-    int32_t rank;     /* Monte-Carlo sample sharding of the ROOT call: unit % world == rank */
+    int32_t rank;     /* Monte-Carlo sample sharding of the ROOT call: this rank's units (see unit_owner) */
     int32_t world;    /* 1 = no sample sharding; >1 => outputs are un-clipped partial sums  */
     uint32_t flags;   /* SCASML_RNG_*                                                       */
     uint32_t reserved;
+    const uint8_t *unit_owner;  /* DEVICE bytes, one per unit of the root call (terminal samples, then the sample paths of
+                                   level 0, 1, ...): the rank that owns it, from scasml_plan_deal_units.  NULL: unit % world. */
 } scasml_rng;
 
 /* scasml_rng.flags.  COMPAT_CRN reproduces the reference's key reuse as pure counter
@@ -191,10 +193,21 @@ int scasml_gp_eval_sites(const scasml_gp_model *gp_h, const float *points, int64
 
 /* Host helper: fill kinds_h[0 .. points_per_root) with 1 for sites whose GP value is used as u_hat only
  * (terminal samples and the trailing root row), 0 for Euler-Maruyama sites (u_hat, div, eps_PDE needed) and
- * 2 for sites of root-call units this rank does not own under Monte-Carlo sample sharding (unit % world !=
- * rank, as in scasml_rng): scasml_picard_tree neither writes nor reads those rows and scasml_gp_eval_sites
- * skips workgroups that lie entirely inside them.  world = 1: no site is skipped. */
-int scasml_plan_site_kinds(const scasml_plan *plan_h, int32_t rank, int32_t world, uint8_t *kinds_h);
+ * 2 for sites of root-call units this rank does not own under Monte-Carlo sample sharding (unit_owner_h[unit] !=
+ * rank, or unit % world != rank when unit_owner_h is NULL -- the same rule as scasml_rng): scasml_picard_tree
+ * neither writes nor reads those rows and scasml_gp_eval_sites skips workgroups that lie entirely inside them.
+ * world = 1: no site is skipped. */
+int scasml_plan_site_kinds(const scasml_plan *plan_h, int32_t rank, int32_t world, const uint8_t *unit_owner_h, uint8_t *kinds_h);
+
+/* Monte-Carlo sample sharding: the shardable units of the ROOT call are its mg[n] terminal
+ * samples and the mc sample paths of every level l < n, each path with all q nodes and their child subtrees (a path
+ * carries its W and X through its nodes, solvers/MLP.py:215-225).  Their costs are very unequal (at n = rho = 3: 27
+ * units of 1 site, 5 of 4, 3 of 30 and 2 of 264), so they are dealt by cost -- longest processing time first onto the
+ * least loaded rank -- not round-robin.  Cost of a unit = its Euler-Maruyama sites + 0.6 x its terminal sites (a
+ * terminal-time point needs u_hat only).  Returns the number of units (<0 on error); fills owner_h[0 .. units) (needs
+ * capacity >= units, world <= 255) and, if not NULL, load_h[0 .. world) with the cost dealt to every rank.  Philox is keyed by
+ * tree site, so the sum over ranks does not depend on the dealing. */
+int32_t scasml_plan_deal_units(const scasml_plan *plan_h, int32_t world, uint8_t *owner_h, int32_t capacity, double *load_h);
 
 /* Full gradient of the posterior mean, n_inf x (d+1), time last: GP.compute_gradient (:673-687). */
 int scasml_gp_gradient(const scasml_gp_model *gp_h, const float *points, int64_t n_inf,

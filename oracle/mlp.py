@@ -95,17 +95,18 @@ class PicardOracle:
         self.sites_executed = 0
 
     # reference call surface -------------------------------------------------
-    def uz_solve(self, n, par, x_t, root0=0, rank=0, world=1):
+    def uz_solve(self, n, par, x_t, root0=0, rank=0, world=1, owner=None):
         """par = rho (quad) or M (fh).  With world > 1 returns this rank's UN-CLIPPED partial
         sums: the units of the ROOT call (terminal samples, then the sample paths of each
-        level) are dealt round-robin, unit % world == rank; sum the
-        ranks' results and pass them to ``finalize``."""
+        level) are dealt to ranks by ``owner[unit]`` (round-robin, unit % world, if None;
+        SURVEY.md section 8(e)); sum the ranks' results and pass them to ``finalize``."""
         x_t = np.asarray(x_t, dtype=np.float32).astype(np.float64)
         self.par = int(par)
         self.tab = approx_parameters(self.par, self.T) if self.variant == "quad" else None
         B = x_t.shape[0]
         roots = np.arange(root0, root0 + B, dtype=np.uint64)
         self._shard = (rank, world)
+        self._owner = None if owner is None else np.asarray(owner)
         self.sites_executed = 0
         return self._uz(n, x_t[:, :-1].copy(), x_t[:, -1].copy(), roots, 0, top=True, cbase=0)
 
@@ -141,7 +142,9 @@ class PicardOracle:
 
     def _owned(self, top, unit):
         rank, world = self._shard
-        return (not top) or (unit % world == rank)
+        if not top or world == 1:
+            return True
+        return (unit % world == rank) if self._owner is None else (int(self._owner[unit]) == rank)
 
     def _finish(self, u, z, top):
         out = np.concatenate([u[:, None], z], axis=1)

@@ -21,7 +21,8 @@ class Problem(C.Structure):
 
 class Rng(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("stream", C.c_uint32), ("root0", C.c_uint32),
-                ("rank", C.c_int32), ("world", C.c_int32), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+                ("rank", C.c_int32), ("world", C.c_int32), ("flags", C.c_uint32), ("reserved", C.c_uint32),
+                ("unit_owner", C.c_void_p)]
 
 
 class Term(C.Structure):
@@ -65,7 +66,8 @@ SIGNATURES = {
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "scasml_gp_eval": (C.c_int, [C.POINTER(GpModel), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "scasml_gp_eval_sites": (C.c_int, [C.POINTER(GpModel), C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "scasml_plan_site_kinds": (C.c_int, [C.POINTER(Plan), C.c_int32, C.c_int32, C.c_void_p]),
+    "scasml_plan_site_kinds": (C.c_int, [C.POINTER(Plan), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "scasml_plan_deal_units": (C.c_int32, [C.POINTER(Plan), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "scasml_gp_gradient": (C.c_int, [C.POINTER(GpModel), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "scasml_gp_gram": (C.c_int, [C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "scasml_gp_newton_b": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),

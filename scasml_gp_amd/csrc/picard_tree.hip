@@ -33,6 +33,7 @@ struct TreeArgs {
     int64_t ppr;  // points per root = plan.sites[n] + 1
     uint32_t k0, k1, stream, root0;
     int32_t rank, world;
+    const uint8_t *owner;   // unit -> rank (scasml_plan_deal_units), or null: unit % world
     int32_t crn;  // SCASML_RNG_COMPAT_CRN: terminal draws keyed by the call's k = 0 position (reference key reuse, E-2/E-3)
     int32_t d, G, logG, kp;
     float T, mu, sigma, clip;
@@ -96,7 +97,7 @@ struct Walker {
     }
     __device__ __forceinline__ bool owned(bool top) {
         if (!top || a.world == 1) return true;
-        const bool mine = (unit % a.world) == a.rank;
+        const bool mine = a.owner ? (int)a.owner[unit] == a.rank : (unit % a.world) == a.rank;   // wave-uniform: scalar load
         ++unit;
         return mine;
     }
@@ -400,7 +401,55 @@ static void site_kinds_rec(const scasml_plan *p, int n, uint8_t *&out) {
     }
 }
 
-extern "C" int scasml_plan_site_kinds(const scasml_plan *plan_h, int32_t rank, int32_t world, uint8_t *kinds_h) {
+// cost of the subtree of a level-n call, in the units of scasml_plan_deal_units (Euler-Maruyama site 1, terminal site 0.6)
+static double subtree_cost(const scasml_plan *p, int n) {
+    if (n == 0) return 0.0;
+    double c = 0.6 * p->mg[n];
+    for (int l = 0; l < n; ++l) {
+        const scasml_term &t = p->term[n][l];
+        c += (double)t.mc * t.q * (1.0 + subtree_cost(p, l) + (l > 0 ? subtree_cost(p, l - 1) : 0.0));
+    }
+    return c;
+}
+
+extern "C" int32_t scasml_plan_deal_units(const scasml_plan *plan_h, int32_t world, uint8_t *owner_h, int32_t capacity, double *load_h) {
+    if (!plan_h || !owner_h || plan_h->n < 1 || plan_h->n > SCASML_MAX_LEVEL) return fail(SCASML_ERR_ARG, "plan_deal_units: bad argument");
+    if (world < 1 || world > 255) return fail(SCASML_ERR_ARG, "plan_deal_units: world must be 1..255");
+    const int n = plan_h->n;
+    int64_t units = plan_h->mg[n];
+    for (int l = 0; l < n; ++l) units += plan_h->term[n][l].mc;
+    if (units > capacity) return fail(SCASML_ERR_ARG, "plan_deal_units: %lld units exceed the capacity %d", (long long)units, capacity);
+    // unit costs in enumeration order; the levels come in blocks of equal cost, the most expensive level last
+    double *cost = new double[units];
+    int64_t u = 0;
+    for (int m = 0; m < plan_h->mg[n]; ++m) cost[u++] = 0.6;
+    for (int l = 0; l < n; ++l) {
+        const scasml_term &t = plan_h->term[n][l];
+        const double c = t.q * (1.0 + subtree_cost(plan_h, l) + (l > 0 ? subtree_cost(plan_h, l - 1) : 0.0));
+        for (int m = 0; m < t.mc; ++m) cost[u++] = c;
+    }
+    double *load = new double[world]();
+    bool *done = new bool[units]();
+    for (int64_t k = 0; k < units; ++k) {           // longest processing time first (ties: lower unit index, lower rank)
+        int64_t best = -1;
+        for (int64_t i = 0; i < units; ++i)
+            if (!done[i] && (best < 0 || cost[i] > cost[best])) best = i;
+        int r = 0;
+        for (int j = 1; j < world; ++j)
+            if (load[j] < load[r]) r = j;
+        done[best] = true;
+        owner_h[best] = (uint8_t)r;
+        load[r] += cost[best];
+    }
+    if (load_h)
+        for (int j = 0; j < world; ++j) load_h[j] = load[j];
+    delete[] cost;
+    delete[] load;
+    delete[] done;
+    return (int32_t)units;
+}
+
+extern "C" int scasml_plan_site_kinds(const scasml_plan *plan_h, int32_t rank, int32_t world, const uint8_t *unit_owner_h, uint8_t *kinds_h) {
     if (!plan_h || !kinds_h || plan_h->n < 0 || plan_h->n > SCASML_MAX_LEVEL) return fail(SCASML_ERR_ARG, "plan_site_kinds: bad argument");
     if (world < 1 || rank < 0 || rank >= world) return fail(SCASML_ERR_ARG, "plan_site_kinds: bad rank/world");
     uint8_t *w = kinds_h;
@@ -411,13 +460,14 @@ extern "C" int scasml_plan_site_kinds(const scasml_plan *plan_h, int32_t rank, i
         const int n = plan_h->n;
         int unit = 0;
         int64_t o = 0;
+        auto mine = [&](int un) { return unit_owner_h ? (int)unit_owner_h[un] == rank : un % world == rank; };
         for (int m = 0; m < plan_h->mg[n]; ++m, ++unit, ++o)
-            if (unit % world != rank) kinds_h[o] = 2;
+            if (!mine(unit)) kinds_h[o] = 2;
         for (int l = 0; l < n; ++l) {
             const scasml_term &t = plan_h->term[n][l];
             const int64_t span = (int64_t)t.q * (1 + t.sites_l + t.sites_lm1);
             for (int m = 0; m < t.mc; ++m, ++unit, o += span)
-                if (unit % world != rank)
+                if (!mine(unit))
                     for (int64_t k = 0; k < span; ++k) kinds_h[o + k] = 2;
         }
     }
@@ -473,6 +523,7 @@ extern "C" int scasml_picard_tree(const scasml_problem *prob, const scasml_plan 
     a.root0 = rng.root0;
     a.rank = rng.rank;
     a.world = rng.world;
+    a.owner = rng.world > 1 ? rng.unit_owner : nullptr;
     a.crn = (rng.flags & SCASML_RNG_COMPAT_CRN) ? 1 : 0;
     a.d = prob->d;
     a.kp = scasml_point_stride(prob->d);

@@ -33,10 +33,11 @@ class PicardEngine:
         self._events = []
         self._plans = {}
         self._kinds = {}
+        self._owners = {}
 
     def __getstate__(self):               # deep-copyable (tests/ComputingBudget.py:138): drop caches and events
         st = dict(self.__dict__)
-        st["_plans"], st["_events"], st["_kinds"] = {}, [], {}
+        st["_plans"], st["_events"], st["_kinds"], st["_owners"] = {}, [], {}, {}
         return st
 
     def _timed(self, name, fn):
@@ -67,6 +68,16 @@ class PicardEngine:
                                                  stale_delta_t=self.gp is None)
         return self._plans[key]
 
+    def unit_owners(self, n, par, world):
+        """(host uint8 owner per unit of the root call, device copy, per-rank load) from scasml_plan_deal_units: the
+        Monte-Carlo units dealt by cost (longest first onto the least loaded rank)."""
+        key = (n, par, world)
+        if key not in self._owners:
+            torch = _lib.require_gpu()
+            host, load = deal_units(self.plan(n, par), world)
+            self._owners[key] = (host, torch.from_numpy(host).cuda(), load)
+        return self._owners[key]
+
     def site_kinds(self, n, par, rank=0, world=1):
         """Device byte per tree site: 1 where only u_hat of the surrogate is consumed, 2 where the site belongs
         to a root-call unit another rank owns (scasml_plan_site_kinds)."""
@@ -76,7 +87,8 @@ class PicardEngine:
             plan = self.plan(n, par)
             ppr = int(_lib.load().scasml_points_per_root(C.byref(plan)))
             host = np.zeros(ppr, dtype=np.uint8)
-            _lib.check(_lib.load().scasml_plan_site_kinds(C.byref(plan), rank, world, host.ctypes.data_as(C.c_void_p)), "plan_site_kinds")
+            owner = self.unit_owners(n, par, world)[0].ctypes.data_as(C.c_void_p) if world > 1 and n > 0 else None
+            _lib.check(_lib.load().scasml_plan_site_kinds(C.byref(plan), rank, world, owner, host.ctypes.data_as(C.c_void_p)), "plan_site_kinds")
             self._kinds[key] = torch.from_numpy(host).cuda()
         return self._kinds[key]
 
@@ -99,7 +111,8 @@ class PicardEngine:
         B = x.shape[0]
         plan, prob = self.plan(n, par), self.problem()
         flags = _lib.RNG_COMPAT_CRN if self.compat_crn else 0
-        rng = _lib.Rng(self.seed, self.calls if stream_id is None else stream_id, root0, rank, world, flags, 0)
+        owner = self.unit_owners(n, par, world)[1].data_ptr() if world > 1 and n > 0 else None
+        rng = _lib.Rng(self.seed, self.calls if stream_id is None else stream_id, root0, rank, world, flags, 0, owner)
         if stream_id is None:
             self.calls += 1
         out = torch.empty((B, d + 1), dtype=torch.float32, device="cuda")
@@ -119,7 +132,7 @@ class PicardEngine:
         kinds = self.site_kinds(n, par, rank, world) if n > 0 else None
         for b0 in range(0, B, chunk):
             nb = min(chunk, B - b0)
-            rng_c = _lib.Rng(rng.seed, rng.stream, root0 + b0, rank, world, flags, 0)
+            rng_c = _lib.Rng(rng.seed, rng.stream, root0 + b0, rank, world, flags, 0, owner)
             xc = x[b0:b0 + nb]
             if n > 0:
                 ob, ub = out[b0:b0 + nb], uhat[b0:b0 + nb]
@@ -143,6 +156,19 @@ class PicardEngine:
 
     def evaluation_increment(self, n, par):
         return tables.reference_evaluation_count(self.variant, n, par, self.gp is not None, float(self.equation.T))
+
+
+def deal_units(plan, world):
+    """Host side of scasml_plan_deal_units: (owner uint8 per unit, load per rank)."""
+    lib = _lib.load()
+    n = plan.n
+    units = int(plan.mg[n]) + sum(int(plan.term[n][l].mc) for l in range(n))
+    owner = np.zeros(max(units, 1), dtype=np.uint8)
+    load = np.zeros(world, dtype=np.float64)
+    got = lib.scasml_plan_deal_units(C.byref(plan), world, owner.ctypes.data_as(C.c_void_p), units, load.ctypes.data_as(C.c_void_p))
+    if got != units:
+        raise _lib.ScasmlError("plan_deal_units failed (%d): %s" % (got, lib.scasml_last_error().decode()))
+    return owner[:units].copy(), load
 
 
 def deliver(t, was_numpy):

@@ -131,19 +131,24 @@ def test_equation_surface_and_sampler():
         Equation(3).f(None, None, None)
 
 
+@pytest.mark.parametrize("dealt", [False, True])
 @pytest.mark.parametrize("variant,n,par,world", [("quad", 3, 3, 3), ("quad", 2, 2, 2), ("fh", 3, 3, 8), ("quad", 3, 3, 1)])
-def test_site_kinds_partition_the_tree_under_sample_sharding(lib, variant, n, par, world):
+def test_site_kinds_partition_the_tree_under_sample_sharding(lib, variant, n, par, world, dealt):
     """scasml_plan_site_kinds: 1 = u_hat-only site, 0 = Euler-Maruyama site, 2 = owned by another rank; over the
-    ranks every site is owned exactly once and the root row by everyone."""
+    ranks every site is owned exactly once and the root row by everyone -- round-robin (owner table NULL) or dealt by
+    cost (scasml_plan_deal_units)."""
     from oracle.mlp import site_count
     from oracle.tables import approx_parameters
+    from scasml_gp_amd.solvers._picard import deal_units
     plan = tables.build_plan(variant, n, par, 0.5, False)
     ppr = lib.scasml_points_per_root(C.byref(plan))
     owners = np.zeros(ppr, dtype=int)
     base = None
+    table = deal_units(plan, world)[0] if dealt else None
+    tptr = table.ctypes.data_as(C.c_void_p) if dealt else None
     for r in range(world):
         k = np.zeros(ppr, dtype=np.uint8)
-        assert lib.scasml_plan_site_kinds(C.byref(plan), r, world, k.ctypes.data_as(C.c_void_p)) == 0
+        assert lib.scasml_plan_site_kinds(C.byref(plan), r, world, tptr, k.ctypes.data_as(C.c_void_p)) == 0
         owners += k != 2
         if world == 1:
             base = k
@@ -151,7 +156,33 @@ def test_site_kinds_partition_the_tree_under_sample_sharding(lib, variant, n, pa
     if base is not None:
         tab = approx_parameters(par) if variant == "quad" else None
         assert ppr == site_count(variant, n, par, tab) + 1 and base[-1] == 1 and set(base) <= {0, 1}
-    assert lib.scasml_plan_site_kinds(C.byref(plan), world, world, np.zeros(ppr, dtype=np.uint8).ctypes.data_as(C.c_void_p)) == -1
+    assert lib.scasml_plan_site_kinds(C.byref(plan), world, world, None, np.zeros(ppr, dtype=np.uint8).ctypes.data_as(C.c_void_p)) == -1
+
+
+def test_units_are_dealt_by_cost(lib):
+    """scasml_plan_deal_units: every unit gets an owner, the loads add up to the tree's cost, and longest-first dealing
+    beats round-robin where the units are unequal.  The figures quoted in DESIGN.md section 6."""
+    from scasml_gp_amd.solvers._picard import deal_units
+    from scasml_gp_amd.parallel import sample_units
+
+    quad = tables.build_plan("quad", 3, 3, 0.5, False)
+    owner, load = deal_units(quad, 2)
+    assert len(owner) == sample_units(quad) == 37 and set(owner) == {0, 1}
+    # cost = Euler-Maruyama sites + 0.6 x terminal sites: 665 sites at n = rho = 3, 234 of them terminal
+    assert abs(load.sum() - (665 - 234 + 0.6 * 234)) < 1e-9
+    assert load.max() / load.mean() < 1.01           # two ranks balance: the two big level-2 paths go to different ranks
+    owner8, load8 = deal_units(quad, 8)
+    assert load8.max() / load8.mean() > 3.0          # 8 ranks cannot: one level-2 path is 40 % of the tree (reported, not hidden)
+    fh = tables.build_plan("fh", 4, 3, 0.5, False)
+    o4, l4 = deal_units(fh, 4)
+    assert len(o4) == 201 and l4.max() / l4.mean() < 1.15
+    o8, l8 = deal_units(fh, 8)
+    assert 1.2 < l8.max() / l8.mean() < 1.6          # three level-3 paths of 18 % each over eight ranks
+    for world in (1, 2, 3, 8, 255):
+        o, l = deal_units(fh, world)
+        assert o.max() < world and abs(l.sum() - l4.sum()) < 1e-9
+    assert lib.scasml_plan_deal_units(C.byref(fh), 256, o.ctypes.data_as(C.c_void_p), 201, None) == -1
+    assert lib.scasml_plan_deal_units(C.byref(fh), 2, o.ctypes.data_as(C.c_void_p), 10, None) == -1
 
 
 def test_no_spills_inside_the_gp_tile_loops():

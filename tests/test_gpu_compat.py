@@ -164,3 +164,39 @@ def test_points_one_float16_ulp_below_terminal_time():
     hip = ScaSML(eq, gp, seed=5)
     got, want = hip.uz_solve(2, 2, xt), PicardOracle(ogp.eq, "quad", gp=ogp, seed=5, stream=0).uz_solve(2, 2, xt)
     assert np.all(np.abs(got - want) <= 5e-5 + 2e-4 * np.abs(want)), np.abs(got - want).max()
+
+
+def test_product_lands_in_the_logged_band_on_the_reference_protocol():
+    """tests/RepeatedExperiment.py:50-141 on the HIP path in the compat modes, d = 20: GP, MLP, SCaSML against
+    results/Grad_Dependent_Nonlinear/20d/RepeatedExperiment/RepeatedExperiment.log:9-22.  Bands as in
+    tests/test_oracle_compat_band.py (logged sigma + the training-set sigma measured in profiles/r02_repeated_experiment_compat.txt);
+    the SCaSML / GP ratio does not depend on the training set and is pinned to 0.474 +- 0.03."""
+    from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
+    from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
+    from scasml_gp_amd.solvers.MLP import MLP
+    from scasml_gp_amd.solvers.ScaSML import ScaSML
+    from scasml_gp_amd.solvers.ScaSML_full_history import ScaSML_full_history
+    from oracle.equation import rel_l2
+    d = 20
+    eq = Grad_Dependent_Nonlinear(d + 1)
+    errs = {"GP": [], "MLP": [], "ScaSML": [], "ScaSML_fh": []}
+    for ts, idx in ((1, [10, 19, 17, 0, 14]), (3, [4, 5, 3, 18, 10])):
+        np.random.seed(ts)
+        dom, bdy = eq.generate_data(1000, 200)
+        gp = GP_Grad_Dependent_Nonlinear(eq, compat="reference", laplacian_idx=idx)
+        gp.GPsolver(dom, bdy, GN_steps=20)
+        mlp, sc, scf = MLP(eq, compat_crn=True), ScaSML(eq, gp, compat_crn=True), ScaSML_full_history(eq, gp, compat_crn=True)
+        for rep in range(4):
+            np.random.seed(42 + rep)
+            xt = np.concatenate(eq.generate_test_data(1000, 200))
+            exact = eq.exact_solution(xt)
+            errs["GP"].append(rel_l2(gp.predict(xt), exact))
+            errs["MLP"].append(rel_l2(mlp.u_solve(2, 2, xt), exact))
+            errs["ScaSML"].append(rel_l2(sc.u_solve(2, 2, xt), exact))
+            errs["ScaSML_fh"].append(rel_l2(scf.u_solve(2, None, xt, 3), exact))
+    m = {k: float(np.mean(v)) for k, v in errs.items()}
+    assert abs(m["GP"] - 0.1456) <= 2 * 0.0028 + 0.004, m
+    assert abs(m["MLP"] - 0.1576) <= 2 * 0.0043, m
+    assert abs(m["ScaSML"] - 0.0690) <= 2 * 0.0024 + 0.002, m
+    assert abs(m["ScaSML_fh"] - 0.0616) <= 2 * 0.0021 + 0.002, m
+    assert abs(m["ScaSML"] / m["GP"] - 0.0690 / 0.1456) <= 0.03, m

@@ -92,7 +92,7 @@ def test_sample_sharding_partials_sum_to_the_unsharded_result():
     parts = [eng.solve(3, 3, xt, rank=r, world=3, stream_id=0)[0] for r in range(3)]
     ora = PicardOracle(GradDependentNonlinear(21), "quad", seed=4, stream=0)
     for r in range(3):
-        want = ora.uz_solve(3, 3, xt, rank=r, world=3)
+        want = ora.uz_solve(3, 3, xt, rank=r, world=3, owner=eng.unit_owners(3, 3, 3)[0])
         assert np.allclose(parts[r].cpu().numpy(), want, atol=1e-4, rtol=1e-4)
     summed = eng.finalize_partials(parts[0] + parts[1] + parts[2])
     assert torch.allclose(summed, full, atol=1e-4, rtol=1e-4)

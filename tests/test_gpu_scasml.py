@@ -137,5 +137,6 @@ def test_sample_sharded_scasml_partials(B):
     full, _, _ = eng.solve(3, 3, xt, stream_id=0)
     parts = [eng.solve(3, 3, xt, rank=r, world=2, stream_id=0)[0] for r in range(2)]
     for r in range(2):
-        assert np.allclose(parts[r].cpu().numpy(), ora.uz_solve(3, 3, xt, rank=r, world=2), atol=2e-4, rtol=2e-4)
+        want = ora.uz_solve(3, 3, xt, rank=r, world=2, owner=eng.unit_owners(3, 3, 2)[0])
+        assert np.allclose(parts[r].cpu().numpy(), want, atol=2e-4, rtol=2e-4)
     assert torch.allclose(eng.finalize_partials(parts[0] + parts[1]), full, atol=1e-4, rtol=1e-4)

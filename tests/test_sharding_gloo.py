@@ -22,7 +22,10 @@ def _worker(rank, world, port, q):
         ora = PicardOracle(GradDependentNonlinear(d + 1), "quad", seed=2, stream=0)
         full = ora.uz_solve(2, 2, xt)
         # (i) Monte-Carlo sample sharding + one all-reduce
-        part = torch.from_numpy(ora.uz_solve(2, 2, xt, rank=rank, world=world))
+        from scasml_gp_amd import tables
+        from scasml_gp_amd.solvers._picard import deal_units
+        owner, _ = deal_units(tables.build_plan("quad", 2, 2, 0.5, True), world)     # the product's dealing of the units
+        part = torch.from_numpy(ora.uz_solve(2, 2, xt, rank=rank, world=world, owner=owner))
         summed = parallel.allreduce_partial_sums(part)
         ok_samples = np.allclose(ora.finalize(summed.numpy()), full, atol=1e-12)
         # (ii) root sharding, ragged (11 roots over 2 ranks) + all_gather
