@@ -8,8 +8,13 @@ Multi-GPU: one process per GPU, evaluation points (independent objects) are shar
 ranks -- no data-path collective; weak scaling.  Prints ONE JSON line on rank 0.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus N ...            (plain invocation: spawns the N ranks itself, before anything touches a GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+
+With N > 1 the line also carries "samples_sharding": the north-star split -- the Monte-Carlo units of the root call dealt
+over `sample_ranks` ranks by cost (scasml_plan_deal_units), ONE RCCL all-reduce of the (B, 1+d) partial estimators per
+step -- timed on the same workload right after the root-sharded leg (strong scaling: the B roots of one GPU are shared).
 """
 import argparse
 import json
@@ -45,6 +50,9 @@ def parse():
                     help="roots: each rank its own B roots, no collective (weak scaling, default); samples: every rank the same "
                          "B roots and 1/world of the Monte-Carlo units of the root call, ONE all-reduce of the partial estimators "
                          "(strong scaling; BASELINE.json north_star)")
+    ap.add_argument("--max-imbalance", type=float, default=1.15,
+                    help="samples leg: use the largest number of sample ranks (a divisor of the rank count) whose dealt load "
+                         "max/mean stays below this; the remaining factor shards roots")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development only: all ranks share cuda:0 and rendezvous over gloo (a 1-GPU box cannot host RCCL ranks)")
@@ -90,8 +98,40 @@ def cpu_baseline(args, eq, gp, eng, n, par, x_t, x_dev, x_dom, x_bdy, steps_exec
             "max_abs_diff_gpu_vs_cpu": float(np.nanmax(np.abs(uz_gpu.cpu().numpy() - uz_cpu)))}
 
 
+def spawn_ranks(n):
+    """Plain `python bench.py --gpus N`: start the N ranks as child processes (one per GPU, rendezvous on 127.0.0.1) and
+    return the worst exit code.  Nothing in this parent has touched a GPU (importing torch does not)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    return max(abs(p.wait()) for p in procs)
+
+
+def sample_split(eng, n, par, world, max_imbalance):
+    """(sample ranks S, root groups G, imbalance at S, imbalance if all `world` ranks shared the samples): the largest
+    divisor S of `world` whose cost-dealt load max/mean stays under the bound."""
+    from scasml_gp_amd.solvers._picard import deal_units
+    plan = eng.plan(n, par)
+    imb = {}
+    for s in range(1, world + 1):
+        if world % s == 0:
+            load = deal_units(plan, s)[1]
+            imb[s] = float(load.max() / load.mean())
+    best = max(s for s, v in imb.items() if v <= max_imbalance or s == 1)
+    return best, world // best, imb[best], imb[world]
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
     import torch
     import torch.distributed as dist
 
@@ -99,8 +139,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
-                         % (args.gpus, world, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.rehearse_on_one_gpu:
         local = 0
     torch.cuda.set_device(local)
@@ -143,9 +182,12 @@ def main():
         solver = (MLP if args.variant == "quad" else MLP_full_history)(eq, seed=0)
 
     # synthetic inputs: x ~ U[-0.5, 0.5]^d, t ~ U[0, 0.5), resident in HBM before timing
-    g = np.random.default_rng(1234 + (rank if args.shard == "roots" else 0))
-    x_t = np.concatenate([g.uniform(-0.5, 0.5, (B, d)), g.uniform(0.0, 0.5, (B, 1))], axis=1).astype(np.float32)
+    def synth(seed):
+        g = np.random.default_rng(seed)
+        return np.concatenate([g.uniform(-0.5, 0.5, (B, d)), g.uniform(0.0, 0.5, (B, 1))], axis=1).astype(np.float32)
+    x_t = synth(1234 + rank)                               # root sharding: every rank its own B roots
     x_dev = torch.from_numpy(x_t).cuda()
+    x_shared = x_dev if rank == 0 else torch.from_numpy(synth(1234)).cuda()   # sample sharding: the same B roots on every rank
     eng = solver._engine
     plan = eng.plan(n, par)
     steps_exec = tables.executed_path_steps(plan)
@@ -153,41 +195,77 @@ def main():
 
     from scasml_gp_amd import parallel
 
-    def one_step():
-        if args.shard == "samples" and world > 1:
-            sid = eng.calls
-            eng.calls += 1
-            out, uhat, _ = eng.solve(n, par, x_dev, rank=rank, world=world, stream_id=sid)
-            if args.rehearse_on_one_gpu:                     # gloo reduces host tensors
+    on_host = args.rehearse_on_one_gpu                       # gloo reduces host tensors
+
+    def timed_leg(step_fn):
+        """W untimed + K timed steps, barrier + synchronize on both sides, MAX over ranks (seconds)."""
+        for _ in range(args.warmup):
+            step_fn()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if on_host else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    # ---- the north-star split: Monte-Carlo units over S ranks (one all-reduce), roots over the G groups -----------
+    S, G, imb, imb_all = sample_split(eng, n, par, world, args.max_imbalance) if world > 1 else (1, 1, 1.0, 1.0)
+    my_group, my_srank = rank // S, rank % S
+    group = None
+    if world > 1 and S > 1:
+        for g in range(G):                                   # every rank creates every group (torch.distributed contract)
+            h = dist.new_group(list(range(g * S, (g + 1) * S)))
+            if g == my_group:
+                group = h
+    g_lo, g_cnt = parallel.root_slice(B, my_group, G)
+
+    def samples_step():
+        sid = eng.calls
+        eng.calls += 1
+        out, uhat, _ = eng.solve(n, par, x_shared[g_lo:g_lo + g_cnt], root0=g_lo, rank=my_srank, world=S, stream_id=sid)
+        if S > 1:
+            if on_host:
                 host = out.cpu()
-                parallel.allreduce_partial_sums(host)
+                parallel.allreduce_partial_sums(host, group)
                 out.copy_(host)
             else:
-                parallel.allreduce_partial_sums(out)         # the single RCCL all-reduce of the path
-            return eng.finalize_partials(out), uhat
-        out, uhat, _ = eng.solve(n, par, x_dev, root0=rank * B)
+                parallel.allreduce_partial_sums(out, group)  # the single RCCL all-reduce of the path
+            eng.finalize_partials(out)
         return out, uhat
 
-    for _ in range(args.warmup):
-        one_step()
-    eng.profile = True
+    def roots_step():
+        return eng.solve(n, par, x_dev, root0=rank * B)[:2]
+
+    main_step = samples_step if args.shard == "samples" and world > 1 else roots_step
     eng.kernel_ms = {}
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out, uhat = one_step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    for _ in range(args.warmup):
+        main_step()
+    eng.profile = True
+    saved_warmup, args.warmup = args.warmup, 0
+    elapsed = timed_leg(main_step)
+    args.warmup = saved_warmup
     eng.profile = False
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     kernel_ms = eng.collect_kernel_ms()                    # HIP-event durations, per kernel, averaged
+    samples_leg = None
+    if world > 1:
+        other = roots_step if main_step is samples_step else samples_step
+        t_other = timed_leg(other)
+        t_s, t_r = (elapsed, t_other) if main_step is samples_step else (t_other, elapsed)
+        samples_leg = {"sample_ranks": S, "root_groups": G, "unit_load_imbalance_max_over_mean": round(imb, 3),
+                       "imbalance_if_all_ranks_shared_samples": round(imb_all, 3), "collective": "1 all-reduce of (B/G, 1+d) f32 per step over %d ranks" % S,
+                       "scaling": "strong", "roots_total": B, "ms_per_step": round(t_s / args.steps * 1e3, 3),
+                       "value": round(B * steps_exec * args.steps / t_s, 1),
+                       "roots_leg": {"scaling": "weak", "roots_total": world * B, "ms_per_step": round(t_r / args.steps * 1e3, 3),
+                                     "value": round(world * B * steps_exec * args.steps / t_r, 1)}}
 
     if rank != 0:
         if world > 1:
@@ -232,7 +310,8 @@ def main():
     if gp_ms:
         ach = flops / (gp_ms * 1e-3) / 1e12
         split = int(gp.eval_split)
-        kp = (d + 2 + 15) // 16 * 16
+        from scasml_gp_amd import _lib
+        kp = int(_lib.load().scasml_point_stride(d))       # the kernels' padded row length (round_up(d + 4, 16))
         n_pad = (n_colloc + 31) // 32 * 32
         products = {0: 1, 2: 3, 3: 6, 22: 2 if getattr(gp, "_colloc_is_f16", False) else 3}[split]
         issued = products * 2.0 * n_inf * n_pad * kp / (gp_ms * 1e-3) / 1e12      # MFMA flops actually issued
@@ -263,21 +342,22 @@ def main():
             ("scasml", "fh"): "solvers.ScaSML_full_history n=%d M=%d" % (n, args.M),
             ("mlp", "quad"): "solvers.MLP n=rho=%d" % n,
             ("mlp", "fh"): "solvers.MLP_full_history n=%d M=%d" % (n, args.M)}[(args.solver, args.variant)]
-    work_ranks = world if args.shard == "roots" else 1       # samples: all ranks share the same B roots
+    work_ranks = world if main_step is roots_step else 1     # samples: all ranks share the same B roots
     value = work_ranks * B * steps_exec * args.steps / elapsed
     line = {
         "metric": "Euler-Maruyama path-steps/sec + L2 rel-error, Grad_Dependent_Nonlinear d=%d n=%d" % (d, n),
         "value": round(value, 1), "unit": "path-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-        "scaling": "weak" if args.shard == "roots" else "strong",
+        "scaling": "weak" if main_step is roots_step else "strong", "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+        "backend": (dist.get_backend() if world > 1 else None), "samples_sharding": samples_leg,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "Grad_Dependent_Nonlinear d=%d, %s, B=%d roots/GPU%s" % (
                        d, name, B, " (BASELINE.json configs[2])" if (args.solver, args.variant, d, n) == ("scasml", "quad", 100, 3) else ""),
                    "roots_per_gpu": B, "gp_collocation": ("%d+%d" % (args.train_domain, args.train_boundary)) if gp is not None else None,
                    "path_steps_per_root": steps_exec, "path_steps_per_root_reference_count": steps_ref,
                    "gp_point_evals_per_root": ppr,
-                   "sharding": "roots across ranks, no collective" if args.shard == "roots" else
-                               "Monte-Carlo units of the root call across ranks, one all-reduce of (B, 1+d) partial sums",
+                   "sharding": "roots across ranks, no collective" if main_step is roots_step else
+                               "Monte-Carlo units of the root call over %d ranks (dealt by cost), one all-reduce of (B, 1+d) partial sums; roots over %d groups" % (S, G),
                    "note": "value counts only EXECUTED path-steps (the reference's discarded n=0 terminal draws are not "
                            "performed); with the reference's own count the same run is value_reference_count"},
         "value_reference_count": round(work_ranks * B * steps_ref * args.steps / elapsed, 1),

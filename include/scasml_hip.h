@@ -156,6 +156,11 @@ typedef struct {
                                     deepxde float16 points are): split = 22 then needs 2 instead of 3 MFMAs per K-step */
     const float *coef;           /* scasml_gp_coef_floats(): n_pad x 16 per-row constants (a*sum y, a*t_y, c0, cL, ct, cS, ..., |y|^2) for
                                     the FP32 kernel, then n_pad x 16 in the exponent-scaled form of the 16-bit kernels */
+    float x_bound;               /* PRECONDITION of split = 22: every coordinate of every evaluation row satisfies |x_k| <= x_bound
+                                    (0 = 2.0, which covers the unit cube plus any path of this equation: 0.5 + |mu| T + 5.8 sigma sqrt(T)
+                                    = 1.6).  The fp16 planes carry 0.72 a |x|^2; the call is refused if that could leave the fp16 range
+                                    under the stated bound.  Rows beyond the bound overflow to inf / NaN: use split = 3 for them. */
+    int32_t reserved;
 } scasml_gp_model;
 
 /* Build `coef` and the padded `colloc` from points and right_vector (models/GP.py:599-600):
@@ -245,6 +250,15 @@ int scasml_gemv(const double *A, int64_t M, int64_t lda, const double *x, double
 int scasml_gp_newton_system(int32_t eq_id, int32_t d, double sigma, const double *A, int64_t lda, int32_t n_dom,
                             int32_t n_bdy, const double *sol, const double *Ab, double *grad, double *H, int64_t ldh,
                             int gauss_newton, void *stream);
+/* The same Newton iteration without K_p^-1 in memory (distributed fits: products with K_p^-1 are two triangular solves):
+ *   scasml_gp_newton_jv    out (4*n_dom + n_bdy) = J v,   J = d b / d sol at `sol`, v of length 3*n_dom
+ *   scasml_gp_newton_jtv   out (3*n_dom) = scale * (J^T w  [+ the second-derivative term of F: with Ab = K_p^-1 b and a
+ *                          direction v (both may be NULL = omitted): -sigma^2 Ab[F_i] v5_i on z1_i, -sigma^2 Ab[F_i] v1_i on z5_i])
+ * so that  grad = jtv(Ab, scale 2)  and  H v = jtv(K_p^-1 jv(v), Ab, v, scale 2). */
+int scasml_gp_newton_jv(int32_t eq_id, int32_t d, double sigma, const double *sol, const double *v, int32_t n_dom, int32_t n_bdy,
+                        double *out, void *stream);
+int scasml_gp_newton_jtv(int32_t eq_id, int32_t d, double sigma, const double *sol, const double *w, const double *Ab,
+                         const double *v, double scale, int32_t n_dom, int32_t n_bdy, double *out, void *stream);
 
 /* ------------------------------------------------------------------ reference-compat surrogate
  * The reference's surrogate AS CODED differs from the operators it documents:
@@ -271,6 +285,27 @@ int scasml_gp_compat_pack(int32_t d, const float *x_dom, int32_t n_dom, const fl
 int scasml_gp_eval_compat(int32_t d, double a, double sigma_eq, const double *colloc_t, int32_t n_dom, int32_t n_bdy,
                           int64_t ldc, const double *rv, const int32_t *idx_h, int32_t round16, const float *points,
                           int64_t n_inf, int32_t kp, float *out4, float *lap, void *stream);
+
+/* ------------------------------------------------------------------ block-row distributed Gram / Cholesky / solves
+ * For collocation sets whose K(phi, phi) does not fit one GPU (BASELINE configs[4]: 1e5 points, M = 350 000, 980 GB float64)
+ * the matrix is cut into block rows of SCASML_DIST_BLOCK feature rows, block row i owned by rank i % world and stored as a
+ * row-major panel of its lower-triangle columns; scasml_gp_amd/dist_gp.py sequences these kernels and the RCCL broadcasts /
+ * all-gathers between them.  Replaces models/GP.py:182-268 and the solve of :599 at that size.  All float64.
+ *   scasml_gp_gram_rows    rows [row0, row0 + nrows) x columns [0, ncols) of K(phi, phi) into out (leading dimension ld),
+ *                          block order as scasml_gp_gram
+ *   scasml_gemm_nt_sub     C (rows x cols, ldc) -= A (rows x K, lda) * B (cols x K, ldb)^T on the FP64 matrix cores; K % 32 == 0.
+ *                          tri_stride > 0: C is a stack of block rows of a lower-triangular matrix -- local row block lb is global
+ *                          block row tri_row0 + lb * tri_stride, column block cb is global block column tri_col0 + cb -- and the
+ *                          64 x 64 tiles strictly above the block diagonal are skipped
+ *   scasml_trsm_right_lt   X (rows x nb, ldx) <- X * L^-T, L lower triangular nb x nb (ldl), nb % 32 == 0: the panel solve
+ *   scasml_gemv_sub        trans == 0: y (rows) -= A (rows x cols, lda) x (cols);  trans != 0: y (cols) -= A^T x (rows) */
+#define SCASML_DIST_BLOCK 256
+int scasml_gp_gram_rows(int32_t d, double a, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy,
+                        int64_t row0, int32_t nrows, int64_t ncols, double *out, int64_t ld, void *stream);
+int scasml_gemm_nt_sub(double *C, int64_t ldc, int64_t rows, int64_t cols, const double *A, int64_t lda, const double *B,
+                       int64_t ldb, int64_t K, int64_t tri_row0, int64_t tri_stride, int64_t tri_col0, void *stream);
+int scasml_trsm_right_lt(const double *L, int64_t ldl, int64_t nb, double *X, int64_t ldx, int64_t rows, void *stream);
+int scasml_gemv_sub(const double *A, int64_t lda, int64_t rows, int64_t cols, const double *x, double *y, int trans, void *stream);
 
 #ifdef __cplusplus
 }

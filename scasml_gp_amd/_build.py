@@ -8,7 +8,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libscasml_hip.so")
-SOURCES = ["abi.hip", "picard_tree.hip", "gp_eval.hip", "gp_eval_bf16.hip", "gp_train.hip", "gp_compat.hip"]
+SOURCES = ["abi.hip", "picard_tree.hip", "gp_eval.hip", "gp_eval_bf16.hip", "gp_train.hip", "gp_compat.hip", "dist_linalg.hip"]
 # -ffp-contract=off: the RNG transform is specified in separately rounded IEEE mul/add
 # (philox_normal.hpp); every fused multiply-add elsewhere is written as fmaf() explicitly.
 # -fno-slp-vectorize: hipcc otherwise packs the scalar f32 epilogue into v_pk_fma_f32 / v_pk_mul_f32 plus

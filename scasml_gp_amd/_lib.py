@@ -7,6 +7,7 @@ MAX_LEVEL = 5
 MAX_Q = 6
 MAX_DIM = 252
 GP_TILE = 32
+DIST_BLOCK = 256
 ABI_VERSION = 2
 
 MODE_MLP, MODE_GENERATE, MODE_ACCUMULATE = 0, 1, 2
@@ -40,7 +41,7 @@ class GpModel(C.Structure):
     _fields_ = [("d", C.c_int32), ("n_dom", C.c_int32), ("n_bdy", C.c_int32), ("n_pad", C.c_int32),
                 ("kp", C.c_int32), ("split", C.c_int32), ("a", C.c_float), ("sigma_eq", C.c_float),
                 ("colloc", C.c_void_p), ("colloc_frag", C.c_void_p), ("colloc_bf16", C.c_void_p), ("colloc_is_f16", C.c_int32),
-                ("coef", C.c_void_p)]
+                ("coef", C.c_void_p), ("x_bound", C.c_float), ("reserved", C.c_int32)]
 
 
 _STRUCTS = (Problem, Rng, Term, Plan, GpModel)
@@ -81,6 +82,15 @@ SIGNATURES = {
     "scasml_gp_compat_pack": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "scasml_gp_eval_compat": (C.c_int, [C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p,
                                         C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "scasml_gp_gram_rows": (C.c_int, [C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int64,
+                                      C.c_void_p, C.c_int64, C.c_void_p]),
+    "scasml_gemm_nt_sub": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
+                                     C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
+    "scasml_gp_newton_jv": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "scasml_gp_newton_jtv": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
+                                       C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "scasml_trsm_right_lt": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "scasml_gemv_sub": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "scasml_cholesky": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_void_p]),
     "scasml_cholesky_inverse": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "scasml_trsm_lower": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),

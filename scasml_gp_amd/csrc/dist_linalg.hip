@@ -1,0 +1,260 @@
+// Building blocks of the block-row DISTRIBUTED Gram / Cholesky / triangular solves (scasml_gp_amd/dist_gp.py; BASELINE
+// configs[4]: 1e5 collocation points -> M = 350 000 features, 980 GB float64 -- only the 8 GPUs of a node together hold it).
+// Replaces models/GP.py:182-268 (kernel_phi_phi + factor) and the solve of :599 at sizes one GPU cannot hold.
+//
+// Storage: K (and then L) is cut into block rows of kDistBlock = 256 feature rows; block row i is owned by rank i % world
+// (1-D block-cyclic) and stored as a dense row-major panel of 256 x (i + 1) * 256 doubles -- the lower triangle only.
+// Everything here works on such panels through (pointer, leading dimension) pairs, so the same kernels serve any layout:
+//   scasml_gp_gram_rows    feature rows [row0, row0 + nrows) x feature columns [0, ncols) of K(phi, phi)
+//   scasml_gemm_nt_sub     C -= A B^T              (FP64 MFMA, v_mfma_f64_16x16x4_f64, 64 x 64 tile per workgroup)
+//   scasml_trsm_right_lt   X <- X L^-T             (the panel solve of the right-looking factorisation)
+//   scasml_gemv_sub        y -= A x  or  y -= A^T x  (the block steps of the distributed substitutions)
+#include "common.hpp"
+
+namespace scasml {
+
+constexpr int kNB = 32;
+
+// ---------------------------------------------------------------------------------- Gram rows
+// One thread per (feature row, collocation point j): the pair geometry once, then the entries of that row against the 1 or
+// 4 operators of point j.  Closed forms: SURVEY.md Appendix C (the same table as gp_gram_kernel in gp_train.hip).
+__global__ void gp_gram_rows_kernel(int d, double a, const float *x_dom, int n_dom, const float *x_bdy, int n_bdy, int64_t row0,
+                                    int nrows, int64_t ncols, double *out, int64_t ld) {
+    const int N = n_dom + n_bdy;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int rr = blockIdx.y * blockDim.y + threadIdx.y;
+    if (rr >= nrows || j >= N) return;
+    const int64_t row = row0 + rr;
+    // feature row -> (operator, point): u(dom) | u(bdy) | Lap(dom) | dt(dom) | div(dom)
+    int ox, i;
+    if (row < N) {
+        ox = 0;
+        i = (int)row;
+    } else {
+        const int64_t q = row - N;
+        ox = 1 + (int)(q / n_dom);
+        i = (int)(q % n_dom);
+    }
+    const float *xi = i < n_dom ? x_dom + (int64_t)i * (d + 1) : x_bdy + (int64_t)(i - n_dom) * (d + 1);
+    const float *yj = j < n_dom ? x_dom + (int64_t)j * (d + 1) : x_bdy + (int64_t)(j - n_dom) * (d + 1);
+    double r2 = 0.0, S = 0.0;
+    for (int k = 0; k < d; ++k) {
+        const double r = (double)xi[k] - (double)yj[k];
+        r2 = fma(r, r, r2);
+        S += r;
+    }
+    const double rt = (double)xi[d] - (double)yj[d];
+    const double rho2 = r2;
+    r2 = fma(rt, rt, r2);
+    const double kap = exp(-0.5 * a * r2);
+    const double lap = a * a * rho2 - a * d;
+    double P[4];   // this row's operator against I, Lap, dt, div in y
+    if (ox == 0) {
+        P[0] = 1.0; P[1] = lap; P[2] = a * rt; P[3] = a * S;
+    } else if (ox == 1) {
+        P[0] = lap;
+        P[1] = a * a * a * a * rho2 * rho2 - (2.0 * d + 4.0) * a * a * a * rho2 + ((double)d * d + 2.0 * d) * a * a;
+        P[2] = a * rt * lap;
+        P[3] = a * S * lap - 2.0 * a * a * S;
+    } else if (ox == 2) {
+        P[0] = -a * rt; P[1] = -a * rt * lap; P[2] = a - a * a * rt * rt; P[3] = -a * a * rt * S;
+    } else {
+        P[0] = -a * S; P[1] = -(a * S * lap - 2.0 * a * a * S); P[2] = -a * a * rt * S; P[3] = a * d - a * a * S * S;
+    }
+    const int nops_j = j < n_dom ? 4 : 1;
+    for (int oy = 0; oy < nops_j; ++oy) {
+        const int64_t col = oy == 0 ? j : (int64_t)N + (int64_t)(oy - 1) * n_dom + j;
+        if (col < ncols) out[(int64_t)rr * ld + col] = P[oy] * kap;
+    }
+}
+
+// ---------------------------------------------------------------------------------- C -= A B^T
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+constexpr int kLDP = kNB + 2;   // padded LDS leading dimension (gp_train.hip)
+
+// 64 x 64 tile per 256-thread workgroup, wave w owns quadrant (w >> 1, w & 1) as 2 x 2 MFMA tiles; the K dimension is
+// streamed through LDS 32 at a time, double-buffered (global loads of chunk k+1 in flight while chunk k feeds the matrix cores).
+// A: rows x K (lda), B: cols x K (ldb), C: rows x cols (ldc).  K must be a multiple of 32.
+// Triangular skipping for block-cyclic row panels: local row block lb (of SCASML_DIST_BLOCK rows) is global block row
+// tri_row0 + lb * tri_stride, tile column block cb is global block column tri_col0 + cb; tiles strictly above the block
+// diagonal are not touched (tri_stride = 0: no skipping).
+struct TriMap {
+    int64_t row0, stride, col0;
+};
+
+__global__ __launch_bounds__(256) void gemm_nt_sub_kernel(double *C, int64_t ldc, int64_t rows, int64_t cols, const double *A,
+                                                          int64_t lda, const double *B, int64_t ldb, int64_t K, TriMap tri) {
+    __shared__ double Pa[2][64][kLDP];
+    __shared__ double Pb[2][64][kLDP];
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    if (tri.stride > 0 && tri.col0 + c0 / SCASML_DIST_BLOCK > tri.row0 + (r0 / SCASML_DIST_BLOCK) * tri.stride) return;   // block-uniform
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wr = (wv >> 1) * 32, wc = (wv & 1) * 32;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    double ra[8], rb[8];
+    auto fetch = [&](int64_t kk) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int idx = threadIdx.x + e * 256, rr = idx / kNB, cc = idx % kNB;
+            ra[e] = r0 + rr < rows ? A[(r0 + rr) * lda + kk + cc] : 0.0;
+            rb[e] = c0 + rr < cols ? B[(c0 + rr) * ldb + kk + cc] : 0.0;
+        }
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int idx = threadIdx.x + e * 256, rr = idx / kNB, cc = idx % kNB;
+            Pa[buf][rr][cc] = ra[e];
+            Pb[buf][rr][cc] = rb[e];
+        }
+    };
+    fetch(0);
+    park(0);
+    __syncthreads();
+    int cur = 0;
+    for (int64_t kk = 0; kk < K; kk += kNB) {
+        const bool more = kk + kNB < K;
+        if (more) fetch(kk + kNB);
+#pragma unroll
+        for (int k0 = 0; k0 < kNB; k0 += 4) {
+            double av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i] = Pa[cur][wr + 16 * i + l15][k0 + l4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[j] = Pb[cur][wc + 16 * j + l15][k0 + l4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) park(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t r = r0 + wr + 16 * i + l4 + 4 * e, c = c0 + wc + 16 * j + l15;
+                if (r < rows && c < cols) C[r * ldc + c] -= acc[i][j][e];
+            }
+}
+
+// ---------------------------------------------------------------------------------- X <- X L^-T (32 columns at a time)
+// one thread per row of X: x L_kk^T = rhs with the 32 x 32 lower-triangular L_kk at (L, ldl)
+__global__ __launch_bounds__(256) void trsm_right_lt32_kernel(const double *L, int64_t ldl, double *X, int64_t ldx, int64_t rows) {
+    __shared__ double Lk[kNB][kNB + 1];
+    for (int idx = threadIdx.x; idx < kNB * kNB; idx += blockDim.x) Lk[idx / kNB][idx % kNB] = L[(int64_t)(idx / kNB) * ldl + idx % kNB];
+    __syncthreads();
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    double x[kNB];
+#pragma unroll
+    for (int j = 0; j < kNB; ++j) x[j] = X[r * ldx + j];
+#pragma unroll
+    for (int j = 0; j < kNB; ++j) {
+        double v = x[j];
+#pragma unroll
+        for (int p = 0; p < j; ++p) v = fma(-x[p], Lk[j][p], v);
+        x[j] = v / Lk[j][j];
+    }
+#pragma unroll
+    for (int j = 0; j < kNB; ++j) X[r * ldx + j] = x[j];
+}
+
+// ---------------------------------------------------------------------------------- y -= A x, y -= A^T x
+__global__ __launch_bounds__(256) void gemv_sub_kernel(const double *A, int64_t lda, int64_t rows, int64_t cols, const double *x, double *y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    double acc = 0.0;
+    for (int64_t k = lane; k < cols; k += 64) acc = fma(A[row * lda + k], x[k], acc);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) y[row] -= acc;
+}
+
+// y[c] -= sum_r A[r][c] x[r]: one thread per column, rows split over blockIdx.y, partial sums combined with atomics
+__global__ __launch_bounds__(256) void gemv_t_sub_kernel(const double *A, int64_t lda, int64_t rows, int64_t cols, const double *x, double *y,
+                                                         int64_t rows_per_block) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    const int64_t rb = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t re = rb + rows_per_block < rows ? rb + rows_per_block : rows;
+    double acc = 0.0;
+    for (int64_t r = rb; r < re; ++r) acc = fma(A[r * lda + c], x[r], acc);
+    if (gridDim.y == 1) y[c] -= acc;     // single writer: deterministic (the distributed solves use 256-row blocks)
+    else atomicAdd(&y[c], -acc);
+}
+
+}  // namespace scasml
+
+using namespace scasml;
+
+extern "C" int scasml_gp_gram_rows(int32_t d, double a, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy,
+                                   int64_t row0, int32_t nrows, int64_t ncols, double *out, int64_t ld, void *stream) {
+    if (!x_dom || !out || (n_bdy > 0 && !x_bdy)) return fail(SCASML_ERR_ARG, "gp_gram_rows: null argument");
+    const int64_t M = 4 * (int64_t)n_dom + n_bdy;
+    if (d < 1 || n_dom < 1 || n_bdy < 0 || row0 < 0 || nrows < 0 || row0 + nrows > M || ncols < 0 || ncols > M || ld < ncols)
+        return fail(SCASML_ERR_ARG, "gp_gram_rows: bad sizes");
+    if (nrows == 0 || ncols == 0) return 0;
+    const int N = n_dom + n_bdy;
+    const unsigned gy = (unsigned)((nrows + 3) / 4);
+    if (gy > 65535) return fail(SCASML_ERR_UNSUPPORTED, "gp_gram_rows: more than 262140 rows per call");
+    hipLaunchKernelGGL(gp_gram_rows_kernel, dim3((N + 63) / 64, gy), dim3(64, 4), 0, (hipStream_t)stream, d, a, x_dom, n_dom, x_bdy,
+                       n_bdy, row0, nrows, ncols, out, ld);
+    return check_launch("gp_gram_rows launch");
+}
+
+extern "C" int scasml_gemm_nt_sub(double *C, int64_t ldc, int64_t rows, int64_t cols, const double *A, int64_t lda, const double *B,
+                                  int64_t ldb, int64_t K, int64_t tri_row0, int64_t tri_stride, int64_t tri_col0, void *stream) {
+    if (!C || !A || !B || rows < 0 || cols < 0 || K < 0 || ldc < cols || lda < K || ldb < K) return fail(SCASML_ERR_ARG, "gemm_nt_sub: bad argument");
+    if (K % kNB) return fail(SCASML_ERR_UNSUPPORTED, "gemm_nt_sub: K=%lld is not a multiple of %d", (long long)K, kNB);
+    if (rows == 0 || cols == 0 || K == 0) return 0;
+    const int64_t gx = (cols + 63) / 64, gy = (rows + 63) / 64;
+    if (gy > 65535) return fail(SCASML_ERR_UNSUPPORTED, "gemm_nt_sub: too many rows for one launch");
+    hipLaunchKernelGGL(gemm_nt_sub_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, C, ldc, rows, cols, A, lda, B, ldb, K,
+                       TriMap{tri_row0, tri_stride, tri_col0});
+    return check_launch("gemm_nt_sub launch");
+}
+
+extern "C" int scasml_trsm_right_lt(const double *L, int64_t ldl, int64_t nb, double *X, int64_t ldx, int64_t rows, void *stream) {
+    if (!L || !X || nb < 1 || rows < 0 || ldl < nb || ldx < nb) return fail(SCASML_ERR_ARG, "trsm_right_lt: bad argument");
+    if (nb % kNB) return fail(SCASML_ERR_UNSUPPORTED, "trsm_right_lt: nb=%lld is not a multiple of %d", (long long)nb, kNB);
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned gb = (unsigned)((rows + 255) / 256);
+    for (int64_t j = 0; j < nb; j += kNB) {
+        // X[:, j:j+32] <- X[:, j:j+32] L_jj^-T, then X[:, j+32:] -= X[:, j:j+32] L[j+32:, j:j+32]^T
+        hipLaunchKernelGGL(trsm_right_lt32_kernel, dim3(gb), dim3(256), 0, s, L + j * ldl + j, ldl, X + j, ldx, rows);
+        const int64_t rest = nb - j - kNB;
+        if (rest > 0) {
+            const int64_t gy = (rows + 63) / 64;
+            if (gy > 65535) return fail(SCASML_ERR_UNSUPPORTED, "trsm_right_lt: too many rows for one launch");
+            hipLaunchKernelGGL(gemm_nt_sub_kernel, dim3((unsigned)((rest + 63) / 64), (unsigned)gy), dim3(256), 0, s, X + j + kNB, ldx, rows, rest,
+                               X + j, ldx, L + (j + kNB) * ldl + j, ldl, (int64_t)kNB, TriMap{0, 0, 0});
+        }
+    }
+    return check_launch("trsm_right_lt launch");
+}
+
+extern "C" int scasml_gemv_sub(const double *A, int64_t lda, int64_t rows, int64_t cols, const double *x, double *y, int trans, void *stream) {
+    if (!A || !x || !y || rows < 0 || cols < 0 || lda < cols) return fail(SCASML_ERR_ARG, "gemv_sub: bad argument");
+    if (rows == 0 || cols == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (!trans) {
+        hipLaunchKernelGGL(gemv_sub_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, A, lda, rows, cols, x, y);
+    } else {
+        const int64_t rpb = rows <= 512 ? rows : 64;
+        const int64_t gy = (rows + rpb - 1) / rpb;
+        if (gy > 65535) return fail(SCASML_ERR_UNSUPPORTED, "gemv_sub: too many rows for one launch");
+        hipLaunchKernelGGL(gemv_t_sub_kernel, dim3((unsigned)((cols + 255) / 256), (unsigned)gy), dim3(256), 0, s, A, lda, rows, cols, x, y, rpb);
+    }
+    return check_launch("gemv_sub launch");
+}

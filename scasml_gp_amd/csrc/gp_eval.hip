@@ -398,15 +398,22 @@ static int gp_eval_impl(const scasml_gp_model *m, const float *points, int64_t n
     g.d = m->d;
     g.a = m->a;
     g.sigma = m->sigma_eq;
+#ifdef SCASML_ABLATION   // development builds only: phases of the 16-bit kernels switched off through the environment
     const char *dbg = getenv("SCASML_GP_DBG");
     g.dbg = dbg ? atoi(dbg) : 0;
+#else
+    g.dbg = 0;
+#endif
     hipStream_t s = (hipStream_t)stream;
     if (m->split == 2 || m->split == 3 || m->split == 22) {
         if (!m->colloc_bf16) return fail(SCASML_ERR_ARG, "gp_eval: split=%d needs colloc_bf16", m->split);
-        // fp16 planes carry k1 a^2 |x|^2 = -0.72 a |x|^2 itself: with |x_k| <= 2 that stays far inside the fp16 range for
-        // the reference's length scale (a = 16 / d: 46) but not for an arbitrarily small GP.sigma
-        if (m->split == 22 && 0.7213f * m->a * 4.0f * (float)(m->d + 1) > 3.0e4f)
-            return fail(SCASML_ERR_UNSUPPORTED, "gp_eval: a = 1/sigma^2 = %g is outside the range of the fp16x2 mode at d = %d; use split = 3", (double)m->a, m->d);
+        // fp16 planes carry k1 a^2 |x|^2 = -0.72 a |x|^2 itself and 2 a^2 q x_k = 1.44 a x_k: the caller states a bound on the
+        // coordinates (scasml_gp_model.x_bound, 0 = the default 2) and the mode is refused where that bound would leave the
+        // fp16 range -- rows outside the bound are the caller's breach of the precondition (scasml_hip.h)
+        const float xb = m->x_bound > 0.0f ? m->x_bound : 2.0f;
+        if (m->split == 22 && 0.7213f * m->a * xb * xb * (float)(m->d + 1) > 3.0e4f)
+            return fail(SCASML_ERR_UNSUPPORTED, "gp_eval: a = 1/sigma^2 = %g with |x_k| <= %g is outside the range of the fp16x2 mode at d = %d; use split = 3",
+                        (double)m->a, (double)xb, m->d);
         return launch_gp_eval_bf16(g, m->split, s);
     }
     if (m->split != 0) return fail(SCASML_ERR_ARG, "gp_eval: split must be 0, 2, 3 or 22");

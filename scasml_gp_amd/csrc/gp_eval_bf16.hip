@@ -278,19 +278,28 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
     }
     uonly = __builtin_amdgcn_readfirstlane((int)uonly) != 0;
     f32x16 acc;
+    uint32_t region;
+    asm volatile("s_mov_b32 %0, -1" : "=s"(region));   // see tile(): basic-block boundaries, never false
     // the whole sweep is instantiated twice (full / u-only epilogue) and the wave-uniform choice is made once,
     // outside the tile loops: a branch inside them costs registers (the allocator then spills the point tile)
     auto sweep = [&](auto uo) {
         constexpr bool UO = decltype(uo)::value;
         constexpr int AHEAD = NSLOT == 4 ? 2 : 1;
         auto tile = [&](int jt, auto kind) {
-            // The three tests of the (runtime) ablation switches below are load-bearing: they end a basic block after the
-            // staging and after the MFMAs.  Made compile-time constants, the tile body becomes one scheduling region,
-            // the register allocator interleaves the point planes with the epilogue's temporaries and spills 624 B per
-            // lane inside the loop (measured: 72 ms instead of 8; tests/test_abi_and_host.py fails on the spills).
+            // Three basic blocks per tile -- staging, MFMAs, epilogue -- behind a scalar the optimiser cannot see through
+            // (`region`, always all ones).  As one block the register allocator interleaves the point planes with the
+            // epilogue's temporaries and spills 450-620 B per lane inside the loop (72 ms instead of 8, round 1);
+            // __builtin_amdgcn_sched_barrier between the phases does not prevent that (tried: same spills), separate
+            // blocks do.  tests/test_abi_and_host.py fails the build on scratch instructions inside these loops.
+#ifdef SCASML_ABLATION     // development builds only (tools/gp_eval_ablation.sh): phases switched off by g.dbg, results are garbage
             if (jt + AHEAD < n_tiles && !(g.dbg & 8)) stage(jt + AHEAD, (jt + AHEAD) % NSLOT);
             if (!(g.dbg & 1)) gp_mfma_tile_bf16<KS, SPLIT, PF, F16, YEXACT>(a_of(jt % NSLOT), xb, acc, lane);
             if (!(g.dbg & 2)) gp_epilogue_scaled<decltype(kind)::value, PF>(view(jt % NSLOT), acc, half, sx, tx, au, at, ad, al);
+#else
+            if (jt + AHEAD < n_tiles) stage(jt + AHEAD, (jt + AHEAD) % NSLOT);
+            if (region & 1) gp_mfma_tile_bf16<KS, SPLIT, PF, F16, YEXACT>(a_of(jt % NSLOT), xb, acc, lane);
+            if (region & 2) gp_epilogue_scaled<decltype(kind)::value, PF>(view(jt % NSLOT), acc, half, sx, tx, au, at, ad, al);
+#endif
             rendezvous(jt + AHEAD < n_tiles);
         };
         const int nb0 = g.first_bdy_tile < n_tiles ? g.first_bdy_tile : n_tiles;

@@ -351,6 +351,42 @@ __global__ void gp_newton_system_kernel(int d, double s2, const double *A, int64
     if (j == 0) grad[i] = 2.0 * (Ab[ri] + dFi * Ab[r4i]);
 }
 
+// J v and J^T w for the matrix-free Newton iteration (J = d b / d sol; b = [z1, g, z3, F, z5])
+__global__ void gp_newton_jv_kernel(int d, double s2, const double *sol, const double *v, int N, int Nb, double *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int M = 4 * N + Nb;
+    if (i >= M) return;
+    double r;
+    if (i < N) r = v[i];
+    else if (i < N + Nb) r = 0.0;
+    else if (i < 2 * N + Nb) r = v[N + (i - N - Nb)];
+    else if (i < 3 * N + Nb) {
+        const int k = i - 2 * N - Nb;
+        const double c5 = 1.0 / d + 0.5 * s2;
+        r = -s2 * sol[2 * N + k] * v[k] - 0.5 * s2 * v[N + k] + (-s2 * sol[k] + c5) * v[2 * N + k];
+    } else r = v[2 * N + (i - 3 * N - Nb)];
+    out[i] = r;
+}
+
+__global__ void gp_newton_jtv_kernel(int d, double s2, const double *sol, const double *w, const double *Ab, const double *v,
+                                     double scale, int N, int Nb, double *out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    const double c5 = 1.0 / d + 0.5 * s2;
+    const double w4 = w[2 * N + Nb + k];
+    double o1 = w[k] + (-s2 * sol[2 * N + k]) * w4;
+    double o3 = w[N + Nb + k] - 0.5 * s2 * w4;
+    double o5 = w[3 * N + Nb + k] + (-s2 * sol[k] + c5) * w4;
+    if (Ab && v) {
+        const double q = -s2 * Ab[2 * N + Nb + k];
+        o1 += q * v[2 * N + k];
+        o5 += q * v[k];
+    }
+    out[k] = scale * o1;
+    out[N + k] = scale * o3;
+    out[2 * N + k] = scale * o5;
+}
+
 __global__ void add_diag_kernel(double *A, int64_t M, double v) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < M) A[i * M + i] += v;
@@ -494,6 +530,24 @@ extern "C" int scasml_gp_newton_b(int32_t eq_id, int32_t d, double sigma, const 
     const int M = 4 * n_dom + n_bdy;
     hipLaunchKernelGGL(gp_newton_b_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, d, sigma * sigma, sol, bdy_g, n_dom, n_bdy, b);
     return check_launch("gp_newton_b launch");
+}
+
+extern "C" int scasml_gp_newton_jv(int32_t eq_id, int32_t d, double sigma, const double *sol, const double *v, int32_t n_dom, int32_t n_bdy,
+                                   double *out, void *stream) {
+    if (eq_id != SCASML_EQ_GRAD_DEPENDENT_NONLINEAR) return fail(SCASML_ERR_UNSUPPORTED, "gp_newton_jv: unknown equation id %d", eq_id);
+    if (!sol || !v || !out || n_dom < 1 || n_bdy < 0) return fail(SCASML_ERR_ARG, "gp_newton_jv: bad argument");
+    const int M = 4 * n_dom + n_bdy;
+    hipLaunchKernelGGL(gp_newton_jv_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, d, sigma * sigma, sol, v, n_dom, n_bdy, out);
+    return check_launch("gp_newton_jv launch");
+}
+
+extern "C" int scasml_gp_newton_jtv(int32_t eq_id, int32_t d, double sigma, const double *sol, const double *w, const double *Ab,
+                                    const double *v, double scale, int32_t n_dom, int32_t n_bdy, double *out, void *stream) {
+    if (eq_id != SCASML_EQ_GRAD_DEPENDENT_NONLINEAR) return fail(SCASML_ERR_UNSUPPORTED, "gp_newton_jtv: unknown equation id %d", eq_id);
+    if (!sol || !w || !out || n_dom < 1 || n_bdy < 0) return fail(SCASML_ERR_ARG, "gp_newton_jtv: bad argument");
+    hipLaunchKernelGGL(gp_newton_jtv_kernel, dim3((n_dom + 255) / 256), dim3(256), 0, (hipStream_t)stream, d, sigma * sigma, sol, w, Ab, v,
+                       scale, n_dom, n_bdy, out);
+    return check_launch("gp_newton_jtv launch");
 }
 
 extern "C" int scasml_gemv(const double *A, int64_t M, int64_t lda, const double *x, double *y, void *stream) {

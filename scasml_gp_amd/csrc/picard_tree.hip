@@ -214,7 +214,9 @@ struct Walker {
             u_out = 0.0f;
             z_out = f4(0.0f);
         } else {
-            const float tau = a.T - t;
+            // a child's time t + U (T - t) can round up to (or one ulp past) T in binary32: its horizon is then 0, not negative
+            // (sqrt of a negative horizon would poison the whole root with NaN: seen once per ~1e7 full-history draws)
+            const float tau = fmaxf(a.T - t, 0.0f);
             const int mg = a.plan.mg[N];
             const float drift = a.mu * tau, vol = a.sigma * sqrt_fast(tau);
             float su = 0.0f;
@@ -269,7 +271,10 @@ struct Walker {
             const float inv_mg = rcp_fast((float)mg);
             float u = su * inv_mg;
             const float zs = inv_mg * rcp_fast(VAR == 0 ? tau + 1e-6f : tau);   // MLP.py:201 / MLP_full_history.py:122
-            float4 z = make_float4(sz.x * zs, sz.y * zs, sz.z * zs, sz.w * zs);
+            // padding dims carry sz = 0: at T - t = 0 the full-history scale is 1/0 (MLP_full_history.py:122 has no epsilon) and
+            // 0 * inf would put a NaN into the padding that dim_sum's 0 * NaN then spreads to the whole root
+            float4 z = make_float4(mask.x != 0.0f ? sz.x * zs : 0.0f, mask.y != 0.0f ? sz.y * zs : 0.0f,
+                                   mask.z != 0.0f ? sz.z * zs : 0.0f, mask.w != 0.0f ? sz.w * zs : 0.0f);
             uint32_t o = (uint32_t)mg;
             level<N, 0, TOP>(x, t, tau, base, cbase, o, u, z);
             if (!(TOP && a.world > 1)) {                         // MLP.py:272-274

@@ -1,0 +1,322 @@
+"""Block-row distributed Gram / Cholesky / solves and the matrix-free Newton fit on top of them, for collocation sets
+whose feature Gram does not fit one GPU (BASELINE.json configs[4]: d = 250, 1e5 collocation points -> M = 350 000 features,
+K(phi, phi) = 980 GB float64).  Replaces models/GP.py:182-268 (kernel_phi_phi + factor), :487-604 (GPsolver) and the solve
+of :599 at that size.  One process per GPU, torch.distributed ("nccl" = RCCL over xGMI; "gloo" in rehearsals and tests).
+
+Layout.  K is cut into block rows of B = 256 feature rows; block row i belongs to rank i % world (1-D block-cyclic, so every
+rank holds the same share of the lower triangle) and a rank stores its block rows stacked in ONE row-major panel
+``R`` of (owned * 256) x Mp float64 (Mp = M rounded up to 256, identity padding).  Only columns <= the block's own are ever
+touched.  Memory at M = 350 000 on 8 GPUs: 171 block rows x 256 x 350 208 x 8 B = 122.6 GB per GPU (61 GB of it is the
+lower triangle) + 0.7 GB of replicated diagonal blocks + 0.7 GB for the broadcast panel of a step: fits the 288 GB of a MI355X
+more than twice over; the same fit on 4 GPUs (245 GB) still fits.
+
+Right-looking factorisation, per block column k (1367 steps at M = 350 000):
+  1. owner(k) factors its 256 x 256 diagonal block (scasml_cholesky) and BROADCASTS it (512 KB);
+  2. every rank solves its blocks of column k against it (scasml_trsm_right_lt on one strided view of R: its block rows > k
+     are a suffix of the stack);
+  3. ONE all-gather assembles the column panel (all blocks (i, k), i > k, in global order: (nb - k - 1) * 512 KB);
+  4. every rank updates its trailing block rows with ONE launch: R[suffix, k+1:] -= P_mine P_all^T on the FP64 matrix cores,
+     tiles above the block diagonal skipped (scasml_gemm_nt_sub with its triangular map).
+Collective volume: the panel of step k reaches every rank once, M^2 / 2 * 8 B = 490 GB per rank over the whole run -- over
+xGMI rings (7 links x ~50 GB/s effective each way) a few seconds against ~60 s of FP64 MFMA work (M^3 / 3 = 1.4e16 flop / 8 GPUs).
+
+Substitutions (K_p^-1 z is two of them; the explicit inverse the single-GPU path forms is never built): the diagonal blocks are
+replicated (they were broadcast in step 1), the right-hand side is replicated.  Forward: per block k the owner's up-to-date
+b_k is broadcast (2 KB), everyone solves y_k and updates its own rows.  Backward: owner(i) folds x_i into a local
+accumulator over its whole block row (one transposed gemv), one all-reduce of 256 doubles per block gives the right-hand side.
+
+Newton (models/GP.py:501-588) without K_p^-1 and without the (3 N_dom)^2 Hessian (500 GB at this size): the damped Newton
+system (H + 1e-4 I) delta = -g is solved INEXACTLY by conjugate gradients with H v = 2 J^T K_p^-1 J v + second-derivative
+term (scasml_gp_newton_jv / _jtv), one distributed solve per product; where CG meets negative curvature the step falls back
+to the Gauss-Newton operator, as the single-GPU path does.  H inherits the conditioning of K_p (1e6 at the reference's
+sizes) and CG is not preconditioned, so a step is cut off after `cg_max` products and the outer iteration absorbs the
+inexactness (more Newton steps than the dense solve needs, same stationary point: tests/test_gpu_dist_gp.py).  A
+preconditioner built from K_p = L L^T products (two collectives each instead of two per block) is the known next step.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+BLK = _lib.DIST_BLOCK
+
+
+class Comm:
+    """The three collectives the path uses, on CUDA tensors; gloo groups (rehearsal on one GPU, tests) go through the host."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.on else 1
+        self.rank = dist.get_rank(group) if self.on else 0
+        self.host = self.on and dist.get_backend(group) == "gloo"
+        self.bytes_moved = 0
+
+    def _via(self, t, fn):
+        if not self.host:
+            fn(t)
+            return t
+        h = t.cpu()
+        fn(h)
+        t.copy_(h)
+        return t
+
+    def broadcast(self, t, src):
+        if self.world > 1:
+            self.bytes_moved += t.numel() * t.element_size()
+            self._via(t, lambda x: self.dist.broadcast(x, src=src if self.group is None else self.dist.get_global_rank(self.group, src), group=self.group))
+        return t
+
+    def all_reduce(self, t):
+        if self.world > 1:
+            self.bytes_moved += 2 * t.numel() * t.element_size()
+            self._via(t, lambda x: self.dist.all_reduce(x, group=self.group))
+        return t
+
+    def all_gather(self, t):
+        """-> (world, *t.shape) tensor; every rank passes the same shape."""
+        import torch
+        if self.world == 1:
+            return t.unsqueeze(0)
+        self.bytes_moved += self.world * t.numel() * t.element_size()
+        if self.host:
+            h = t.cpu()
+            out = [torch.empty_like(h) for _ in range(self.world)]
+            self.dist.all_gather(out, h, group=self.group)
+            return torch.stack(out).to(t.device)
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        self.dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+        return out
+
+
+def owned_blocks(nblk, rank, world):
+    """Global block-row indices of ``rank`` (1-D block-cyclic)."""
+    return list(range(rank, nblk, world))
+
+
+class DistCholesky:
+    """K(phi, phi) + nugget I, block-row distributed: build(), factor(), solve(b)."""
+
+    def __init__(self, d, a, x_dom, x_bdy, nugget, comm=None):
+        torch = _lib.require_gpu()
+        self.lib = _lib.load()
+        self.comm = comm or Comm()
+        self.d, self.a, self.nugget = int(d), float(a), float(nugget)
+        self.xd = torch.from_numpy(np.ascontiguousarray(np.asarray(x_dom), dtype=np.float32)).cuda()
+        self.xb = torch.from_numpy(np.ascontiguousarray(np.asarray(x_bdy), dtype=np.float32)).cuda()
+        self.n_dom, self.n_bdy = self.xd.shape[0], self.xb.shape[0]
+        self.M = 4 * self.n_dom + self.n_bdy
+        self.nblk = (self.M + BLK - 1) // BLK
+        self.Mp = self.nblk * BLK
+        self.mine = owned_blocks(self.nblk, self.comm.rank, self.comm.world)
+        self.R = None
+        self.diag = [None] * self.nblk          # replicated 256 x 256 diagonal factors
+        self.info = torch.zeros(1, dtype=torch.int32, device="cuda")
+
+    # -------------------------------------------------------------------------------------------- helpers
+    def _slot0(self, k):
+        """First local slot whose global block row is > k (the owned block rows > k are a suffix of the stack)."""
+        r, w = self.comm.rank, self.comm.world
+        return 0 if k < r else (k - r) // w + 1
+
+    def _ptr(self, t, row, col, ld):
+        return C.c_void_p(t.data_ptr() + 8 * (row * ld + col))
+
+    def memory_bytes(self):
+        return len(self.mine) * BLK * self.Mp * 8
+
+    # -------------------------------------------------------------------------------------------- Gram
+    def build(self):
+        torch = _lib.require_gpu()
+        lib, s = self.lib, _lib.stream_ptr()
+        self.R = torch.zeros((len(self.mine) * BLK, self.Mp), dtype=torch.float64, device="cuda")
+        for slot, i in enumerate(self.mine):
+            row0 = i * BLK
+            nrows = max(0, min(BLK, self.M - row0))
+            ncols = min((i + 1) * BLK, self.M)
+            _lib.check(lib.scasml_gp_gram_rows(self.d, self.a, _lib.ptr(self.xd), self.n_dom, _lib.ptr(self.xb), self.n_bdy, row0, nrows,
+                                               ncols, self._ptr(self.R, slot * BLK, 0, self.Mp), self.Mp, s), "gp_gram_rows")
+            blk = self.R[slot * BLK:(slot + 1) * BLK, row0:row0 + BLK]
+            dg = blk.diagonal()
+            dg[:nrows] += self.nugget                     # K + nugget I (models/GP.py:260-267)
+            dg[nrows:] = 1.0                              # identity padding beyond M
+        return self
+
+    # -------------------------------------------------------------------------------------------- factor
+    def factor(self):
+        torch = _lib.require_gpu()
+        lib, s, cm = self.lib, _lib.stream_ptr(), self.comm
+        R, Mp, nb, w, rank = self.R, self.Mp, self.nblk, cm.world, cm.rank
+        for k in range(nb):
+            owner = k % w
+            Lkk = torch.empty((BLK, BLK), dtype=torch.float64, device="cuda")
+            if rank == owner:
+                slot = (k - rank) // w
+                Lkk.copy_(R[slot * BLK:(slot + 1) * BLK, k * BLK:(k + 1) * BLK])
+                _lib.check(lib.scasml_cholesky(_lib.ptr(Lkk), BLK, 0.0, _lib.ptr(self.info), s), "cholesky(diag)")
+                R[slot * BLK:(slot + 1) * BLK, k * BLK:(k + 1) * BLK] = Lkk
+            cm.broadcast(Lkk, owner)
+            self.diag[k] = Lkk
+            rest = nb - k - 1
+            if rest == 0:
+                break
+            s0 = self._slot0(k)
+            rows = (len(self.mine) - s0) * BLK
+            if rows:
+                _lib.check(lib.scasml_trsm_right_lt(_lib.ptr(Lkk), BLK, BLK, self._ptr(R, s0 * BLK, k * BLK, Mp), Mp, rows, s), "trsm_right_lt")
+            # all-gather the column panel in global block order: rank q = (k + 1 + j) % w holds blocks k + 1 + j, k + 1 + j + w, ...
+            cnt = (rest + w - 1) // w
+            send = torch.zeros((cnt * BLK, BLK), dtype=torch.float64, device="cuda")
+            if rows:
+                send[:rows] = R[s0 * BLK:, k * BLK:(k + 1) * BLK]
+            got = cm.all_gather(send).view(w, cnt, BLK, BLK)
+            order = [(k + 1 + j) % w for j in range(w)]
+            P = got[order].transpose(0, 1).reshape(cnt * w * BLK, BLK)[:rest * BLK].contiguous()
+            if rows:
+                first = self.mine[s0]
+                _lib.check(lib.scasml_gemm_nt_sub(self._ptr(R, s0 * BLK, (k + 1) * BLK, Mp), Mp, rows, rest * BLK,
+                                                  self._ptr(R, s0 * BLK, k * BLK, Mp), Mp, _lib.ptr(P), BLK, BLK,
+                                                  first, w, k + 1, s), "gemm_nt_sub")
+            del P, got, send
+        if int(self.info.item()) != 0:
+            raise ValueError("distributed Cholesky: K + nugget I is not positive definite")
+        return self
+
+    # -------------------------------------------------------------------------------------------- substitutions
+    def _local_rows(self, v):
+        """The owned block rows of a replicated vector of length Mp, stacked."""
+        torch = _lib.require_gpu()
+        return v.view(self.nblk, BLK)[torch.as_tensor(self.mine, device="cuda", dtype=torch.long)].reshape(-1).clone() if self.mine \
+            else v.new_zeros(0)
+
+    def solve(self, b):
+        """x = (L L^T)^-1 b for a replicated b (length M; a CUDA float64 tensor); returns x replicated."""
+        torch = _lib.require_gpu()
+        lib, s, cm = self.lib, _lib.stream_ptr(), self.comm
+        R, Mp, nb, w, rank = self.R, self.Mp, self.nblk, cm.world, cm.rank
+        bp = torch.zeros(Mp, dtype=torch.float64, device="cuda")
+        bp[:self.M] = b
+        loc = self._local_rows(bp)
+        y = torch.empty(Mp, dtype=torch.float64, device="cuda")
+        for k in range(nb):                                    # forward: L y = b, right-looking
+            owner = k % w
+            yk = y[k * BLK:(k + 1) * BLK]
+            if rank == owner:
+                slot = (k - rank) // w
+                yk.copy_(loc[slot * BLK:(slot + 1) * BLK])
+            cm.broadcast(yk, owner)
+            _lib.check(lib.scasml_trsm_lower(_lib.ptr(self.diag[k]), BLK, _lib.ptr(yk), 1, 0, s), "trsm(diag)")
+            s0 = self._slot0(k)
+            rows = (len(self.mine) - s0) * BLK
+            if rows:
+                _lib.check(lib.scasml_gemv_sub(self._ptr(R, s0 * BLK, k * BLK, Mp), Mp, rows, BLK, _lib.ptr(yk),
+                                               C.c_void_p(loc.data_ptr() + 8 * s0 * BLK), 0, s), "gemv_sub")
+        x = torch.empty(Mp, dtype=torch.float64, device="cuda")
+        acc = torch.zeros(Mp, dtype=torch.float64, device="cuda")   # this rank's share of sum_{i > k} L_ik^T x_i, all k
+        for k in range(nb - 1, -1, -1):                        # backward: L^T x = y
+            xk = x[k * BLK:(k + 1) * BLK]
+            xk.copy_(acc[k * BLK:(k + 1) * BLK])
+            cm.all_reduce(xk)
+            xk.add_(y[k * BLK:(k + 1) * BLK])                  # acc holds minus the sums
+            _lib.check(lib.scasml_trsm_lower(_lib.ptr(self.diag[k]), BLK, _lib.ptr(xk), 1, 1, s), "trsm^T(diag)")
+            if k % w == rank and k > 0:                        # fold x_k into the accumulator over this block row's columns < k
+                slot = (k - rank) // w
+                _lib.check(lib.scasml_gemv_sub(self._ptr(R, slot * BLK, 0, Mp), Mp, BLK, k * BLK, _lib.ptr(xk), _lib.ptr(acc), 1, s), "gemv_sub^T")
+        return x[:self.M].clone()
+
+    def gather_factor(self):
+        """The full lower factor on every rank (tests at small M only)."""
+        torch = _lib.require_gpu()
+        L = torch.zeros((self.Mp, self.Mp), dtype=torch.float64, device="cuda")
+        for slot, i in enumerate(self.mine):
+            L[i * BLK:(i + 1) * BLK, :(i + 1) * BLK] = self.R[slot * BLK:(slot + 1) * BLK, :(i + 1) * BLK]
+        self.comm.all_reduce(L)
+        return torch.tril(L)[:self.M, :self.M]
+
+
+class DistributedGP:
+    """GPsolver at sizes one GPU cannot hold: distributed factor + matrix-free Newton-CG.  After fit() every rank holds
+    right_vector (replicated, M doubles) and can hand it to GP.load_right_vector for the (root-sharded) evaluation."""
+
+    def __init__(self, gp, comm=None):
+        self.gp = gp
+        self.comm = comm or Comm()
+        self.cg_iterations = []
+        self.gauss_newton_steps = 0
+
+    def fit(self, x_t_domain, x_t_boundary, GN_steps=20, cg_tol=1e-8, cg_max=300):
+        torch = _lib.require_gpu()
+        lib, s = _lib.load(), _lib.stream_ptr()
+        gp = self.gp
+        eq_id, d, sig = int(gp.equation.eq_id), int(gp.d), float(gp.equation.sigma())
+        ch = DistCholesky(d, 1.0 / float(gp.sigma) ** 2, x_t_domain, x_t_boundary, gp.nugget, self.comm).build().factor()
+        self.chol = ch
+        N, Nb, M = ch.n_dom, ch.n_bdy, ch.M
+        bdy_g = torch.as_tensor(np.asarray(gp.bdy_g(np.asarray(x_t_boundary)), dtype=np.float64), device="cuda").contiguous()
+        sol = torch.zeros(3 * N, dtype=torch.float64, device="cuda")
+        b = torch.empty(M, dtype=torch.float64, device="cuda")
+        damping = 1e-4                                              # models/GP.py:490
+
+        def residual(sol_):
+            _lib.check(lib.scasml_gp_newton_b(eq_id, d, sig, _lib.ptr(sol_), _lib.ptr(bdy_g), N, Nb, _lib.ptr(b), s), "gp_newton_b")
+            Ab = ch.solve(b)
+            return float(torch.dot(b, Ab)), Ab
+
+        def jtv(w, Ab=None, v=None):
+            out = torch.empty(3 * N, dtype=torch.float64, device="cuda")
+            _lib.check(lib.scasml_gp_newton_jtv(eq_id, d, sig, _lib.ptr(sol), _lib.ptr(w), _lib.ptr(Ab), _lib.ptr(v), 2.0, N, Nb,
+                                                _lib.ptr(out), s), "gp_newton_jtv")
+            return out
+
+        def hess(v, Ab):
+            jv = torch.empty(M, dtype=torch.float64, device="cuda")
+            _lib.check(lib.scasml_gp_newton_jv(eq_id, d, sig, _lib.ptr(sol), _lib.ptr(v), N, Nb, _lib.ptr(jv), s), "gp_newton_jv")
+            return jtv(ch.solve(jv), Ab, v if Ab is not None else None) + damping * v
+
+        def cg(rhs, Ab):
+            """(H + damping I) x = rhs by conjugate gradients; None on negative curvature."""
+            x = torch.zeros_like(rhs)
+            r = rhs.clone()
+            p = r.clone()
+            rr = float(torch.dot(r, r))
+            stop = cg_tol ** 2 * rr
+            it = 0
+            while rr > stop and it < cg_max:
+                hp = hess(p, Ab)
+                php = float(torch.dot(p, hp))
+                if not php > 0.0:
+                    return None, it
+                alpha = rr / php
+                x.add_(p, alpha=alpha)
+                r.add_(hp, alpha=-alpha)
+                rr_new = float(torch.dot(r, r))
+                p.mul_(rr_new / rr).add_(r)
+                rr = rr_new
+                it += 1
+            return x, it
+
+        loss, Ab = residual(sol)
+        hist, self.grad_norms = [loss], []
+        for _ in range(GN_steps):                                       # models/GP.py:515-588
+            grad = jtv(Ab)
+            self.grad_norms.append(float(torch.linalg.vector_norm(grad)))
+            if self.grad_norms[-1] < 1e-5:                              # :521
+                break
+            step, it = cg(-grad, Ab)
+            if step is None:                                            # indefinite Hessian: Gauss-Newton operator instead
+                self.gauss_newton_steps += 1
+                step, it2 = cg(-grad, None)
+                it += it2
+            self.cg_iterations.append(it)
+            sol = sol + step                                            # alpha = 1, :541,573
+            loss, Ab = residual(sol)
+            hist.append(loss)
+        gp.loss_history = hist
+        gp.grad_norms = self.grad_norms
+        gp._sol = sol
+        rv = Ab                                                         # right_vector = K_p^-1 z at the final sol (:593-600)
+        gp.N_domain, gp.N_boundary, gp.phi_dim = N, Nb, M
+        gp.load_right_vector(x_t_domain, x_t_boundary, rv.cpu().numpy())
+        return gp

@@ -75,13 +75,22 @@ class GP(object):
         pts[:, :self.d + 1] = xt
         return pts, was_numpy
 
-    def _device_model(self):
+    def _split_for(self, x_bound):
+        """eval_split, demoted from the fp16 x 2 mode to the fp32-exact bf16 x 3 mode where the coordinates may leave the fp16
+        planes' range: 0.72 a |x|^2 with |x_k| <= x_bound must stay below 3e4 (include/scasml_hip.h, scasml_gp_model.x_bound)."""
+        split = int(self.eval_split)
+        if split == 22 and 0.7213 * (1.0 / float(self.sigma) ** 2) * x_bound * x_bound * (self.d + 1) > 3.0e4:
+            return 3
+        return split
+
+    def _device_model(self, x_bound=0.0):
         if self.right_vector is None:
             raise _lib.ScasmlError("GP is not trained: call GPsolver(x_domain, x_boundary) first")
         m = _lib.GpModel()
+        m.x_bound = float(x_bound)
         m.d, m.n_dom, m.n_bdy, m.n_pad = self.d, self.N_domain, self.N_boundary, self._n_pad
         m.kp = self._colloc.shape[1]
-        m.split = int(self.eval_split)
+        m.split = self._split_for(x_bound) if x_bound > 0 else int(self.eval_split)
         m.a = 1.0 / float(self.sigma) ** 2
         m.sigma_eq = float(self.equation.sigma())
         m.colloc, m.colloc_frag, m.coef = self._colloc.data_ptr(), self._frag.data_ptr(), self._coef.data_ptr()
@@ -90,12 +99,15 @@ class GP(object):
         return m
 
     def _eval_device(self, pts):
+        """Caller-supplied points: their coordinate bound is measured (one reduction + host read) so that far-out rows fall
+        back to the bf16 x 3 arithmetic instead of overflowing the fp16 planes."""
         torch = _lib.require_gpu()
         out = torch.empty((pts.shape[0], 4), dtype=torch.float32, device="cuda")
-        self._eval_rows(pts, pts.shape[0], 0, None, out)
+        xb = float(pts.abs().max()) if pts.shape[0] and int(self.eval_split) == 22 and self.compat is None else 0.0
+        self._eval_rows(pts, pts.shape[0], 0, None, out, x_bound=max(xb, 2.0) if xb > 0 else 0.0)
         return out
 
-    def _eval_rows(self, pts, n_rows, rows_per_site, kinds, out4):
+    def _eval_rows(self, pts, n_rows, rows_per_site, kinds, out4, x_bound=0.0):
         """(u_hat, div u_hat, eps_PDE, dt u_hat) of the first n_rows point rows into out4: the one place the solvers and
         predict / compute_PDE_loss reach the evaluation kernels (kinds: per-site byte of scasml_plan_site_kinds or None)."""
         lib = _lib.load()
@@ -108,7 +120,7 @@ class GP(object):
                                                  self.laplacian_idx.ctypes.data_as(C.c_void_p), 1, _lib.ptr(pts), n_rows,
                                                  pts.shape[1], _lib.ptr(out4), None, _lib.stream_ptr()), "gp_eval_compat")
             return
-        model = self._device_model()
+        model = self._device_model(x_bound)
         if kinds is None:
             _lib.check(lib.scasml_gp_eval(C.byref(model), _lib.ptr(pts), n_rows, _lib.ptr(out4), None, _lib.stream_ptr()), "gp_eval")
         else:
@@ -215,10 +227,12 @@ class GP(object):
             return float(torch.dot(b, Ab))                              # loss = b^T A b, :430-444
 
         hist = [residual(sol)]
+        self.grad_norms = []                                            # ||grad J|| at the start of every iteration (:518-519)
         for _ in range(GN_steps):                                       # :515-588
             _lib.check(lib.scasml_gp_newton_system(eq_id, d, sig, _lib.ptr(A), Mp, N, Nb, _lib.ptr(sol), _lib.ptr(Ab),
                                                    _lib.ptr(grad), _lib.ptr(H), npad, 0, s), "gp_newton_system")
-            if float(torch.linalg.vector_norm(grad)) < 1e-5:            # :521
+            self.grad_norms.append(float(torch.linalg.vector_norm(grad)))
+            if self.grad_norms[-1] < 1e-5:                              # :521
                 break
             step = self._chol_solve_padded(H, -grad, 3 * N, damping)   # :529-533 (H is overwritten by its factor)
             if step is None:

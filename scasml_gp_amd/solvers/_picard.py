@@ -34,10 +34,11 @@ class PicardEngine:
         self._plans = {}
         self._kinds = {}
         self._owners = {}
+        self._work = {}               # point / GP-value buffers, kept across calls (4.9 GB at the headline shape)
 
     def __getstate__(self):               # deep-copyable (tests/ComputingBudget.py:138): drop caches and events
         st = dict(self.__dict__)
-        st["_plans"], st["_events"], st["_kinds"], st["_owners"] = {}, [], {}, {}
+        st["_plans"], st["_events"], st["_kinds"], st["_owners"], st["_work"] = {}, [], {}, {}, {}
         return st
 
     def _timed(self, name, fn):
@@ -92,6 +93,15 @@ class PicardEngine:
             self._kinds[key] = torch.from_numpy(host).cuda()
         return self._kinds[key]
 
+    def path_bound(self):
+        """Bound on |coordinate| of every tree point, from the geometry (no device read): the cube's half-width plus the
+        largest drift and 5.8 standard deviations of the diffusion over [t0, T] -- the 24-bit Box-Muller radius cannot exceed
+        sqrt(-2 ln 2^-24) = 5.77.  Used as the stated precondition of the fp16 evaluation mode (scasml_gp_model.x_bound)."""
+        eq = self.equation
+        radius = float(getattr(eq, "radius", 0.5))
+        T = float(eq.T) - float(getattr(eq, "t0", 0.0))
+        return max(2.0, radius + abs(float(eq.mu())) * T + 5.8 * abs(float(eq.sigma())) * T ** 0.5)
+
     def problem(self):
         eq = self.equation
         p = _lib.Problem()
@@ -125,10 +135,9 @@ class PicardEngine:
         ppr = int(lib.scasml_points_per_root(C.byref(plan)))
         kp = int(lib.scasml_point_stride(d))
         chunk = max(1, min(B, POINT_BUFFER_BYTES // (ppr * kp * 4)))
-        pts = torch.empty((chunk * ppr, kp), dtype=torch.float32, device="cuda")
+        pts, vals = self._buffers(chunk * ppr, kp)
         if world > 1:
             pts.zero_()                    # rows of un-owned units are never written
-        vals = torch.empty((chunk * ppr, 4), dtype=torch.float32, device="cuda")
         kinds = self.site_kinds(n, par, rank, world) if n > 0 else None
         for b0 in range(0, B, chunk):
             nb = min(chunk, B - b0)
@@ -139,7 +148,7 @@ class PicardEngine:
                 _lib.check(self._timed("picard_generate", lambda: lib.scasml_picard_tree(
                     C.byref(prob), C.byref(plan), _lib.MODE_GENERATE, _lib.ptr(xc), nb, rng_c,
                     _lib.ptr(pts), None, None, None, s)), "picard_tree(generate)")
-                self._timed("gp_eval", lambda: self.gp._eval_rows(pts, nb * ppr, nb, kinds, vals))
+                self._timed("gp_eval", lambda: self.gp._eval_rows(pts, nb * ppr, nb, kinds, vals, x_bound=self.path_bound()))
                 _lib.check(self._timed("picard_accumulate", lambda: lib.scasml_picard_tree(
                     C.byref(prob), C.byref(plan), _lib.MODE_ACCUMULATE, _lib.ptr(xc), nb, rng_c,
                     _lib.ptr(pts), _lib.ptr(vals), _lib.ptr(ob), _lib.ptr(ub), s)), "picard_tree(accumulate)")
@@ -147,6 +156,17 @@ class PicardEngine:
                 out[b0:b0 + nb].zero_()
                 uhat[b0:b0 + nb] = self.gp._predict_device(xc)[:, 0]
         return out, uhat, was_numpy
+
+    def _buffers(self, rows, kp):
+        """The site-major point buffer and its GP values: owned by the engine and reused by later calls of the same
+        shape, so a step allocates nothing (the caching allocator hid this after the first call; a first call did not)."""
+        torch = _lib.require_gpu()
+        have = self._work.get("pts")
+        if have is None or have.shape[0] < rows or have.shape[1] != kp:
+            self._work.clear()
+            self._work["pts"] = torch.empty((rows, kp), dtype=torch.float32, device="cuda")
+            self._work["vals"] = torch.empty((rows, 4), dtype=torch.float32, device="cuda")
+        return self._work["pts"][:rows], self._work["vals"][:rows]
 
     def finalize_partials(self, summed):
         """Clip all-reduced partial sums of a sample-sharded solve (MLP.py:272-274)."""

@@ -32,3 +32,55 @@ def test_bench_prints_one_contract_line(extra):
     cpu = j["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["unit"] == "path-steps/s" and cpu["sample"]
     assert cpu["max_abs_diff_gpu_vs_cpu"] < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks,variant,level,expect_s", [(4, "fh", "3", 4), (4, "quad", "3", 2), (2, "quad", "2", 1)])
+def test_plain_invocation_spawns_its_ranks_and_reports_both_shardings(ranks, variant, level, expect_s):
+    """`python bench.py --gpus N` with no launcher around it: the parent spawns the N ranks (here sharing the one GPU of
+    the test box and meeting over gloo: --rehearse-on-one-gpu), rank 0 prints the one line, which carries the root-sharded
+    (weak) headline and the samples_sharding block of the north-star split with its dealt-load imbalance."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--batch", "96",
+           "--train-domain", "96", "--train-boundary", "32", "--d", "20", "--variant", variant, "--level", level,
+           "--rehearse-on-one-gpu"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == ranks and j["rccl_ranks"] == ranks and j["scaling"] == "weak" and j["cpu_baseline"] is None
+    s = j["samples_sharding"]
+    assert s["sample_ranks"] == expect_s and s["sample_ranks"] * s["root_groups"] == ranks
+    assert s["unit_load_imbalance_max_over_mean"] <= 1.15 or s["sample_ranks"] == 1
+    assert s["imbalance_if_all_ranks_shared_samples"] >= s["unit_load_imbalance_max_over_mean"] - 1e-9
+    assert s["value"] > 0 and s["roots_leg"]["value"] > 0 and s["scaling"] == "strong"
+    assert abs(s["roots_leg"]["value"] - j["value"]) / j["value"] < 0.5      # same leg, timed twice
+
+
+@pytest.mark.gpu
+def test_sample_sharded_result_does_not_depend_on_the_rank_count():
+    """World = 8 rehearsal of the north-star split on one GPU: the partial estimators of 8 sample ranks (units dealt by
+    cost) add up to the single-rank result -- ScaSML_full_history n = 4, M = 3 (BASELINE configs[3] at a small batch)."""
+    import numpy as np
+    import torch
+    from oracle.equation import sample_points
+    from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
+    from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
+    from scasml_gp_amd.solvers.ScaSML_full_history import ScaSML_full_history
+    d = 100
+    dom, bdy = sample_points(np.random.default_rng(0), d, 96, 32)
+    eq = Grad_Dependent_Nonlinear(d + 1)
+    gp = GP_Grad_Dependent_Nonlinear(eq)
+    gp.GPsolver(dom, bdy)
+    eng = ScaSML_full_history(eq, gp, seed=1)._engine
+    xt = np.concatenate(sample_points(np.random.default_rng(1), d, 24, 8))
+    full, _, _ = eng.solve(4, 3, xt, stream_id=0)
+    for world in (2, 8):
+        total = None
+        for r in range(world):
+            part, _, _ = eng.solve(4, 3, xt, rank=r, world=world, stream_id=0)
+            total = part.clone() if total is None else total + part
+        assert torch.allclose(eng.finalize_partials(total), full, atol=2e-5, rtol=1e-5), world
+    owner, _, load = eng.unit_owners(4, 3, 8)
+    assert len(owner) == 201 and load.max() / load.mean() < 1.5
