@@ -32,9 +32,14 @@ extern "C" {
 
 enum { SCASML_ERR_ARG = -1, SCASML_ERR_UNSUPPORTED = -2, SCASML_ERR_HIP = -3 };
 
-/* equations/equations.py:232-417 `Grad_Dependent_Nonlinear`: f = sigma*u*sum(z),
- * g = 1 - 1/(1+exp(t+sum x)), mu = -1/d - sigma^2/2, sigma = 0.25. */
-enum { SCASML_EQ_GRAD_DEPENDENT_NONLINEAR = 0 };
+/* Equation registry (equations/equations.py:15-230 is the reference's plug-in base).  The kernels cover the family
+ *   u_t + mu sum_i d_i u + sigma^2/2 Lap u + f(u, sum_i z_i) = 0,  z = sigma grad u,  u(T, x) = g(x),  mu and sigma constant,
+ * one device functor set per id (csrc/equations.hpp):
+ *   0  equations/equations.py:232-417 `Grad_Dependent_Nonlinear`: f = sigma*u*sum(z), g = 1 - 1/(1+exp(t+sum x)),
+ *      mu = -1/d - sigma^2/2, sigma = 0.25
+ *   1  `Cubic_Reaction_Diffusion` (no reference counterpart): f = -u (1-u) (1 + (sigma^2 d/2)(1-2u)), mu = 0, same g;
+ *      exact solution 1 - 1/(1+exp(t+sum x)) */
+enum { SCASML_EQ_GRAD_DEPENDENT_NONLINEAR = 0, SCASML_EQ_CUBIC_REACTION_DIFFUSION = 1 };
 
 typedef struct {
     int32_t d;        /* spatial dimension (n_input - 1)                                    */
@@ -148,6 +153,8 @@ typedef struct {
                                     22 = fp16 MFMA on two fp16 planes (22-bit products, 3 MFMAs per K-step) */
     float a;                     /* 1/sigma_k^2, sigma_k = 0.25*sqrt(d) (models/GP.py:25)    */
     float sigma_eq;              /* equation sigma (models/GP.py:748)                        */
+    float mu_eq;                 /* equation mu: the PDE residual is dt + mu div + sigma^2/2 Lap + f(u, sigma div)  */
+    int32_t eq_id;               /* SCASML_EQ_*: which f closes the residual (models/GP.py:767-768 for id 0)      */
     const float *colloc;         /* n_pad x kp   collocation points, domain first, zero pad  */
     const float *colloc_frag;    /* the same, in fp32 MFMA A-fragment order [tile][kp/8][64][4] */
     const uint16_t *colloc_bf16; /* scasml_gp_plane_halfwords(): 3 truncated-bf16 planes [tile][plane][kp/16][64][8], then 2 fp16
@@ -239,15 +246,16 @@ int scasml_cholesky_inverse(const double *L, int64_t M, double *A, void *stream)
 
 /* Newton iteration on J(sol) = b(sol)^T K_p^-1 b(sol), sol = [z1, z3, z5] (3*n_dom), float64: the pieces of
  * GP.GPsolver's loop (models/GP.py:510-588) that the reference obtains by autodiff of loss_function (:430-444).
+ * eq_id / sigma / mu select and parametrise F = -mu z5 - sigma^2/2 z3 - f(z1, sigma z5) (csrc/equations.hpp).
  *   scasml_gp_newton_b       b = [z1, g, z3, F(sol), z5]  (4*n_dom + n_bdy), F = time_der_rep (:705-719)
  *   scasml_gemv              y = A x, A row-major M x M with leading dimension lda (A b, and right_vector = A z, :599)
  *   scasml_gp_newton_system  grad (3*n_dom) and the full Hessian, written into an ldh x ldh buffer whose padding
  *                            beyond 3*n_dom is the identity (ldh a multiple of 32: ready for scasml_cholesky);
  *                            gauss_newton != 0 omits the second-derivative term of F (always positive semidefinite) */
-int scasml_gp_newton_b(int32_t eq_id, int32_t d, double sigma, const double *sol, const double *bdy_g, int32_t n_dom,
+int scasml_gp_newton_b(int32_t eq_id, int32_t d, double sigma, double mu, const double *sol, const double *bdy_g, int32_t n_dom,
                        int32_t n_bdy, double *b, void *stream);
 int scasml_gemv(const double *A, int64_t M, int64_t lda, const double *x, double *y, void *stream);
-int scasml_gp_newton_system(int32_t eq_id, int32_t d, double sigma, const double *A, int64_t lda, int32_t n_dom,
+int scasml_gp_newton_system(int32_t eq_id, int32_t d, double sigma, double mu, const double *A, int64_t lda, int32_t n_dom,
                             int32_t n_bdy, const double *sol, const double *Ab, double *grad, double *H, int64_t ldh,
                             int gauss_newton, void *stream);
 /* The same Newton iteration without K_p^-1 in memory (distributed fits: products with K_p^-1 are two triangular solves):
@@ -255,9 +263,9 @@ int scasml_gp_newton_system(int32_t eq_id, int32_t d, double sigma, const double
  *   scasml_gp_newton_jtv   out (3*n_dom) = scale * (J^T w  [+ the second-derivative term of F: with Ab = K_p^-1 b and a
  *                          direction v (both may be NULL = omitted): -sigma^2 Ab[F_i] v5_i on z1_i, -sigma^2 Ab[F_i] v1_i on z5_i])
  * so that  grad = jtv(Ab, scale 2)  and  H v = jtv(K_p^-1 jv(v), Ab, v, scale 2). */
-int scasml_gp_newton_jv(int32_t eq_id, int32_t d, double sigma, const double *sol, const double *v, int32_t n_dom, int32_t n_bdy,
+int scasml_gp_newton_jv(int32_t eq_id, int32_t d, double sigma, double mu, const double *sol, const double *v, int32_t n_dom, int32_t n_bdy,
                         double *out, void *stream);
-int scasml_gp_newton_jtv(int32_t eq_id, int32_t d, double sigma, const double *sol, const double *w, const double *Ab,
+int scasml_gp_newton_jtv(int32_t eq_id, int32_t d, double sigma, double mu, const double *sol, const double *w, const double *Ab,
                          const double *v, double scale, int32_t n_dom, int32_t n_bdy, double *out, void *stream);
 
 /* ------------------------------------------------------------------ reference-compat surrogate
@@ -282,7 +290,7 @@ int scasml_round16_diag(double *A, int64_t M, int64_t lda, double nugget, void *
 int scasml_round16(double *v, int64_t n, void *stream);
 int scasml_gp_compat_pack(int32_t d, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy,
                           double *colloc_t, int64_t ldc, void *stream);
-int scasml_gp_eval_compat(int32_t d, double a, double sigma_eq, const double *colloc_t, int32_t n_dom, int32_t n_bdy,
+int scasml_gp_eval_compat(int32_t d, double a, double sigma_eq, double mu_eq, int32_t eq_id, const double *colloc_t, int32_t n_dom, int32_t n_bdy,
                           int64_t ldc, const double *rv, const int32_t *idx_h, int32_t round16, const float *points,
                           int64_t n_inf, int32_t kp, float *out4, float *lap, void *stream);
 

@@ -89,9 +89,10 @@ class OracleGP:
 
     # ---------------------------------------------------------------- operator F (models/GP.py:705-743)
     def time_der_rep(self, sol):
-        N, d, s = self.N_domain, self.d, self.sigma_eq
-        z1, z3, z5 = sol[:N], sol[N:2 * N], sol[2 * N:]
-        return -s ** 2 * z1 * z5 + (1 / d + s ** 2 / 2) * z5 - (s ** 2 / 2) * z3
+        """F(z) of models/GP.py:705-719: for Grad_Dependent_Nonlinear -s^2 z1 z5 + (1/d + s^2/2) z5 - (s^2/2) z3; in general
+        u_t = -mu div u - sigma^2/2 Lap u - f(u, sigma div u) (oracle/equation.py, F_parts)."""
+        N = self.N_domain
+        return self.eq.F_parts(sol[:N], sol[N:2 * N], sol[2 * N:])[0]
 
     def _b(self, sol, bdy_g):
         N = self.N_domain
@@ -126,13 +127,10 @@ class OracleGP:
 
         hist.append(loss(sol))
         for _ in range(GN_steps):                           # :515-588
-            z1, z5 = sol[:N], sol[2 * N:]
             b = self._b(sol, bdy_g)
             Ab = A @ b
             # Jacobian of b w.r.t. (z1, z3, z5): identity blocks + diagonal blocks from F (:722-743)
-            dF1 = -s ** 2 * z5
-            dF3 = -(s ** 2 / 2) * np.ones(N)
-            dF5 = -s ** 2 * z1 + (1 / d + s ** 2 / 2)
+            _, (dF1, dF3, dF5), (F11, F15, F55) = self.eq.F_parts(sol[:N], sol[N:2 * N], sol[2 * N:])
             grad = 2.0 * np.concatenate([Ab[r1] + dF1 * Ab[r4], Ab[r3] + dF3 * Ab[r4], Ab[r5] + dF5 * Ab[r4]])
             if np.linalg.norm(grad) < 1e-5:                 # :521
                 break
@@ -144,10 +142,13 @@ class OracleGP:
                     blk = (A[rows[i], rows[j]] + dF[i][:, None] * A[r4, rows[j]]
                            + A[rows[i], r4] * dF[j][None, :] + dF[i][:, None] * A[r4, r4] * dF[j][None, :])
                     H[i * N:(i + 1) * N, j * N:(j + 1) * N] = 2.0 * blk
-            # second-order term: d2F_i/(dz1_i dz5_i) = -sigma^2, weighted by 2*(A b)_{F_i}
+            # second-order terms: the Hessian of F_i in (z1_i, z5_i) (for Grad_Dependent_Nonlinear only the mixed one, -sigma^2),
+            # weighted by 2*(A b)_{F_i}
             idx = np.arange(N)
-            H[idx, 2 * N + idx] += 2.0 * (-s ** 2) * Ab[r4]
-            H[2 * N + idx, idx] += 2.0 * (-s ** 2) * Ab[r4]
+            H[idx, idx] += 2.0 * F11 * Ab[r4]
+            H[idx, 2 * N + idx] += 2.0 * F15 * Ab[r4]
+            H[2 * N + idx, idx] += 2.0 * F15 * Ab[r4]
+            H[2 * N + idx, 2 * N + idx] += 2.0 * F55 * Ab[r4]
             step = np.linalg.solve(H + damping * np.eye(3 * N), -grad)   # :529-533
             sol = sol + step                                # alpha = 1, :541,573
             hist.append(loss(sol))
@@ -169,10 +170,12 @@ class OracleGP:
         return (self._features("dt", X) @ rv, self._features("div", X) @ rv, self._features("lap", X) @ rv)
 
     def compute_PDE_loss(self, X):
-        s, d = self.sigma_eq, self.d
+        """dt u + mu div u + sigma^2/2 Lap u + f(u, sigma div u); for Grad_Dependent_Nonlinear this is models/GP.py:767-768,
+        dt + (s^2 u - 1/d - s^2/2) div + s^2/2 lap."""
+        s = self.sigma_eq
         dt, div, lap = self.pde_parts(X)
         sol = self.predict(X)
-        return dt + (s ** 2 * sol - 1 / d - s ** 2 / 2) * div + (s ** 2 / 2) * lap   # :767-768
+        return dt + self.eq.mu() * div + (s ** 2 / 2) * lap + self.eq.f_parts(sol, s * div)[0]
 
     def compute_gradient(self, X, sol=None):
         """Full gradient (N, d+1) of the posterior mean, time derivative last (:673-687).

@@ -13,6 +13,7 @@ ABI_VERSION = 2
 MODE_MLP, MODE_GENERATE, MODE_ACCUMULATE = 0, 1, 2
 RNG_COMPAT_CRN = 1
 EQ_GRAD_DEPENDENT_NONLINEAR = 0
+EQ_CUBIC_REACTION_DIFFUSION = 1
 
 
 class Problem(C.Structure):
@@ -40,6 +41,7 @@ class Plan(C.Structure):
 class GpModel(C.Structure):
     _fields_ = [("d", C.c_int32), ("n_dom", C.c_int32), ("n_bdy", C.c_int32), ("n_pad", C.c_int32),
                 ("kp", C.c_int32), ("split", C.c_int32), ("a", C.c_float), ("sigma_eq", C.c_float),
+                ("mu_eq", C.c_float), ("eq_id", C.c_int32),
                 ("colloc", C.c_void_p), ("colloc_frag", C.c_void_p), ("colloc_bf16", C.c_void_p), ("colloc_is_f16", C.c_int32),
                 ("coef", C.c_void_p), ("x_bound", C.c_float), ("reserved", C.c_int32)]
 
@@ -71,23 +73,23 @@ SIGNATURES = {
     "scasml_plan_deal_units": (C.c_int32, [C.POINTER(Plan), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "scasml_gp_gradient": (C.c_int, [C.POINTER(GpModel), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "scasml_gp_gram": (C.c_int, [C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
-    "scasml_gp_newton_b": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "scasml_gp_newton_b": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "scasml_gemv": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "scasml_gp_newton_system": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
+    "scasml_gp_newton_system": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "scasml_gp_gram_compat": (C.c_int, [C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                         C.c_void_p, C.c_void_p]),
     "scasml_round16_diag": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_double, C.c_void_p]),
     "scasml_round16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "scasml_gp_compat_pack": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
-    "scasml_gp_eval_compat": (C.c_int, [C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p,
+    "scasml_gp_eval_compat": (C.c_int, [C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p,
                                         C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "scasml_gp_gram_rows": (C.c_int, [C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int64,
                                       C.c_void_p, C.c_int64, C.c_void_p]),
     "scasml_gemm_nt_sub": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
                                      C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
-    "scasml_gp_newton_jv": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
-    "scasml_gp_newton_jtv": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
+    "scasml_gp_newton_jv": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "scasml_gp_newton_jtv": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
                                        C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "scasml_trsm_right_lt": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "scasml_gemv_sub": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

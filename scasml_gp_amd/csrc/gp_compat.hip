@@ -12,6 +12,7 @@
 //   xs: r = x' - y     lap_x of kappa, dt_y kappa, div_y kappa
 // idx[5] indexes the SHIFTED vector (0 <= i < d): component i of x', i.e. original coordinate i+1.
 #include "common.hpp"
+#include "equations.hpp"
 
 namespace scasml {
 
@@ -168,7 +169,7 @@ __global__ void round16_vec_kernel(double *v, int64_t n) {
 // Feature rows (models/GP.py:326-411, 630-651): with (c0, cL, ct, cS) the right_vector entries of the u / Lap / dt / div
 // features of a domain point and c0 that of a boundary point,
 //   L^x u_hat = sum_j c0 P[x][0] + cL P[x][1] + ct P[x][2] + cS P[x][3],   x in {I, dt, div, lap}.
-__global__ __launch_bounds__(256) void gp_eval_compat_kernel(int d, double a, double sigma, const double *colloc_t, int n_dom,
+__global__ __launch_bounds__(256) void gp_eval_compat_kernel(int d, double a, double sigma, double mu, int eq_id, const double *colloc_t, int n_dom,
                                                              int n_bdy, int64_t ldc, const double *rv, CompatIdx ix, int r16,
                                                              const float *points, int64_t n_inf, int kp, float4 *out4,
                                                              float *lap_out) {
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256) void gp_eval_compat_kernel(int d, double a, do
     if (valid && lane == 0) {
         const double s2 = sigma * sigma;
         const double u = acc[0], lp = acc[1], dt = acc[2], dv = acc[3];
-        const double eps = dt + (s2 * u - 1.0 / d - 0.5 * s2) * dv + 0.5 * s2 * lp;      // models/GP.py:767-768
+        const double eps = dt + mu * dv + 0.5 * s2 * lp + eq_f<double>(eq_id, u, sigma * dv, sigma, (double)d);   // models/GP.py:767-768
         out4[row] = make_float4((float)u, (float)dv, (float)eps, (float)dt);
         if (lap_out) lap_out[row] = (float)lp;
     }
@@ -269,19 +270,20 @@ extern "C" int scasml_gp_compat_pack(int32_t d, const float *x_dom, int32_t n_do
     return check_launch("gp_compat_pack launch");
 }
 
-extern "C" int scasml_gp_eval_compat(int32_t d, double a, double sigma_eq, const double *colloc_t, int32_t n_dom, int32_t n_bdy,
+extern "C" int scasml_gp_eval_compat(int32_t d, double a, double sigma_eq, double mu_eq, int32_t eq_id, const double *colloc_t, int32_t n_dom, int32_t n_bdy,
                                      int64_t ldc, const double *rv, const int32_t *idx_h, int32_t round16, const float *points,
                                      int64_t n_inf, int32_t kp, float *out4, float *lap, void *stream) {
     if (n_inf == 0) return 0;
     if (!colloc_t || !rv || !points || !out4 || n_inf < 0) return fail(SCASML_ERR_ARG, "gp_eval_compat: bad argument");
     if (d < kMC || d > SCASML_MAX_DIM || n_dom < 1 || n_bdy < 0 || ldc < n_dom + n_bdy || kp < d + 1)
         return fail(SCASML_ERR_ARG, "gp_eval_compat: bad sizes");
+    if (!eq_known(eq_id)) return fail(SCASML_ERR_UNSUPPORTED, "gp_eval_compat: unknown equation id %d", eq_id);
     CompatIdx ix;
     if (int rc = check_idx(idx_h, d, ix, "gp_eval_compat")) return rc;
     const int64_t blocks = (n_inf + 3) / 4;
     if (blocks > 0x7FFFFFFF) return fail(SCASML_ERR_UNSUPPORTED, "gp_eval_compat: too many points");
     const size_t lds = 4 * (size_t)(d + 1) * sizeof(double);
-    hipLaunchKernelGGL(gp_eval_compat_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, d, a, sigma_eq, colloc_t,
+    hipLaunchKernelGGL(gp_eval_compat_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, d, a, sigma_eq, mu_eq, eq_id, colloc_t,
                        n_dom, n_bdy, ldc, rv, ix, round16, points, n_inf, kp, reinterpret_cast<float4 *>(out4), lap);
     return check_launch("gp_eval_compat launch");
 }

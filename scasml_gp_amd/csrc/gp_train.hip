@@ -7,6 +7,7 @@
 //
 // Block order of K (models/GP.py:251-258): [u(dom), u(bdy), Lap(dom), dt(dom), div(dom)].
 #include "common.hpp"
+#include "equations.hpp"
 
 namespace scasml {
 
@@ -296,7 +297,12 @@ __global__ __launch_bounds__(256) void trsm_update_kernel(const double *L, int64
 // ---------------------------------------------------------------------------------- Newton system
 // Unknowns sol = [z1, z3, z5] (values of u, Lap u, div u at the N domain points); feature vector
 // b(sol) = [z1, g, z3, F(sol), z5] with F = -s2 z1 z5 + (1/d + s2/2) z5 - (s2/2) z3 (models/GP.py:430-444, 705-719).
-__global__ void gp_newton_b_kernel(int d, double s2, const double *sol, const double *bdy_g, int N, int Nb, double *b) {
+struct EqArgs {
+    int eq_id;
+    double d, sigma, mu;
+};
+
+__global__ void gp_newton_b_kernel(EqArgs q, const double *sol, const double *bdy_g, int N, int Nb, double *b) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int M = 4 * N + Nb;
     if (i >= M) return;
@@ -306,8 +312,7 @@ __global__ void gp_newton_b_kernel(int d, double s2, const double *sol, const do
     else if (i < 2 * N + Nb) v = sol[N + (i - N - Nb)];
     else if (i < 3 * N + Nb) {
         const int k = i - 2 * N - Nb;
-        const double z1 = sol[k], z3 = sol[N + k], z5 = sol[2 * N + k];
-        v = -s2 * z1 * z5 + (1.0 / d + 0.5 * s2) * z5 - 0.5 * s2 * z3;
+        v = eq_F(q.eq_id, sol[k], sol[N + k], sol[2 * N + k], q.mu, q.sigma, q.d).F;
     } else v = sol[2 * N + (i - 3 * N - Nb)];
     b[i] = v;
 }
@@ -329,7 +334,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const double *A, int64_t M, i
 //   grad_i = 2 (Ab[r_i] + dF_i Ab[r4_i]),
 //   H_ij   = 2 (A[r_i,r_j] + dF_i A[r4_i,r_j] + A[r_i,r4_j] dF_j + dF_i A[r4_i,r4_j] dF_j)
 //            + 2 (-s2) Ab[r4_i] on the (z1_i, z5_i) / (z5_i, z1_i) pairs          (second derivative of F).
-__global__ void gp_newton_system_kernel(int d, double s2, const double *A, int64_t lda, int N, int Nb, const double *sol,
+__global__ void gp_newton_system_kernel(EqArgs q, const double *A, int64_t lda, int N, int Nb, const double *sol,
                                         const double *Ab, double *grad, double *H, int64_t ldh, int gauss_newton) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t i = (int64_t)blockIdx.y * blockDim.y + threadIdx.y;
@@ -342,17 +347,19 @@ __global__ void gp_newton_system_kernel(int d, double s2, const double *A, int64
     const int bi = (int)(i / N), ii = (int)(i % N), bj = (int)(j / N), jj = (int)(j % N);
     const int64_t off[3] = {0, (int64_t)N + Nb, (int64_t)3 * N + Nb};
     const int64_t ri = off[bi] + ii, rj = off[bj] + jj, r4i = 2 * (int64_t)N + Nb + ii, r4j = 2 * (int64_t)N + Nb + jj;
-    const double c5 = 1.0 / d + 0.5 * s2;
-    const double dFi = bi == 0 ? -s2 * sol[2 * N + ii] : (bi == 1 ? -0.5 * s2 : -s2 * sol[ii] + c5);
-    const double dFj = bj == 0 ? -s2 * sol[2 * N + jj] : (bj == 1 ? -0.5 * s2 : -s2 * sol[jj] + c5);
+    const FOp Fi = eq_F(q.eq_id, sol[ii], sol[N + ii], sol[2 * N + ii], q.mu, q.sigma, q.d);
+    const FOp Fj = eq_F(q.eq_id, sol[jj], sol[N + jj], sol[2 * N + jj], q.mu, q.sigma, q.d);
+    const double dFi = bi == 0 ? Fi.d1 : (bi == 1 ? Fi.d3 : Fi.d5);
+    const double dFj = bj == 0 ? Fj.d1 : (bj == 1 ? Fj.d3 : Fj.d5);
     double h = 2.0 * (A[ri * lda + rj] + dFi * A[r4i * lda + rj] + A[ri * lda + r4j] * dFj + dFi * A[r4i * lda + r4j] * dFj);
-    if (!gauss_newton && ii == jj && ((bi == 0 && bj == 2) || (bi == 2 && bj == 0))) h += 2.0 * (-s2) * Ab[r4i];
+    if (!gauss_newton && ii == jj && bi != 1 && bj != 1)     // the Hessian of F_i in (z1_i, z5_i), weighted by 2 (K_p^-1 b)_{F_i}
+        h += 2.0 * (bi == 0 && bj == 0 ? Fi.F11 : (bi == 2 && bj == 2 ? Fi.F55 : Fi.F15)) * Ab[r4i];
     H[i * ldh + j] = h;
     if (j == 0) grad[i] = 2.0 * (Ab[ri] + dFi * Ab[r4i]);
 }
 
 // J v and J^T w for the matrix-free Newton iteration (J = d b / d sol; b = [z1, g, z3, F, z5])
-__global__ void gp_newton_jv_kernel(int d, double s2, const double *sol, const double *v, int N, int Nb, double *out) {
+__global__ void gp_newton_jv_kernel(EqArgs q, const double *sol, const double *v, int N, int Nb, double *out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int M = 4 * N + Nb;
     if (i >= M) return;
@@ -362,25 +369,25 @@ __global__ void gp_newton_jv_kernel(int d, double s2, const double *sol, const d
     else if (i < 2 * N + Nb) r = v[N + (i - N - Nb)];
     else if (i < 3 * N + Nb) {
         const int k = i - 2 * N - Nb;
-        const double c5 = 1.0 / d + 0.5 * s2;
-        r = -s2 * sol[2 * N + k] * v[k] - 0.5 * s2 * v[N + k] + (-s2 * sol[k] + c5) * v[2 * N + k];
+        const FOp F = eq_F(q.eq_id, sol[k], sol[N + k], sol[2 * N + k], q.mu, q.sigma, q.d);
+        r = F.d1 * v[k] + F.d3 * v[N + k] + F.d5 * v[2 * N + k];
     } else r = v[2 * N + (i - 3 * N - Nb)];
     out[i] = r;
 }
 
-__global__ void gp_newton_jtv_kernel(int d, double s2, const double *sol, const double *w, const double *Ab, const double *v,
+__global__ void gp_newton_jtv_kernel(EqArgs q, const double *sol, const double *w, const double *Ab, const double *v,
                                      double scale, int N, int Nb, double *out) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= N) return;
-    const double c5 = 1.0 / d + 0.5 * s2;
+    const FOp F = eq_F(q.eq_id, sol[k], sol[N + k], sol[2 * N + k], q.mu, q.sigma, q.d);
     const double w4 = w[2 * N + Nb + k];
-    double o1 = w[k] + (-s2 * sol[2 * N + k]) * w4;
-    double o3 = w[N + Nb + k] - 0.5 * s2 * w4;
-    double o5 = w[3 * N + Nb + k] + (-s2 * sol[k] + c5) * w4;
+    double o1 = w[k] + F.d1 * w4;
+    double o3 = w[N + Nb + k] + F.d3 * w4;
+    double o5 = w[3 * N + Nb + k] + F.d5 * w4;
     if (Ab && v) {
-        const double q = -s2 * Ab[2 * N + Nb + k];
-        o1 += q * v[2 * N + k];
-        o5 += q * v[k];
+        const double ab = Ab[2 * N + Nb + k];
+        o1 += ab * (F.F11 * v[k] + F.F15 * v[2 * N + k]);
+        o5 += ab * (F.F15 * v[k] + F.F55 * v[2 * N + k]);
     }
     out[k] = scale * o1;
     out[N + k] = scale * o3;
@@ -523,29 +530,29 @@ extern "C" int scasml_trsm_lower(const double *L, int64_t M, double *Bmat, int64
     return check_launch("trsm launch");
 }
 
-extern "C" int scasml_gp_newton_b(int32_t eq_id, int32_t d, double sigma, const double *sol, const double *bdy_g, int32_t n_dom,
+extern "C" int scasml_gp_newton_b(int32_t eq_id, int32_t d, double sigma, double mu, const double *sol, const double *bdy_g, int32_t n_dom,
                                   int32_t n_bdy, double *b, void *stream) {
-    if (eq_id != SCASML_EQ_GRAD_DEPENDENT_NONLINEAR) return fail(SCASML_ERR_UNSUPPORTED, "gp_newton_b: unknown equation id %d", eq_id);
+    if (!eq_known(eq_id)) return fail(SCASML_ERR_UNSUPPORTED, "gp_newton_b: unknown equation id %d", eq_id);
     if (!sol || !b || n_dom < 1 || n_bdy < 0 || (n_bdy > 0 && !bdy_g)) return fail(SCASML_ERR_ARG, "gp_newton_b: bad argument");
     const int M = 4 * n_dom + n_bdy;
-    hipLaunchKernelGGL(gp_newton_b_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, d, sigma * sigma, sol, bdy_g, n_dom, n_bdy, b);
+    hipLaunchKernelGGL(gp_newton_b_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, EqArgs{eq_id, (double)d, sigma, mu}, sol, bdy_g, n_dom, n_bdy, b);
     return check_launch("gp_newton_b launch");
 }
 
-extern "C" int scasml_gp_newton_jv(int32_t eq_id, int32_t d, double sigma, const double *sol, const double *v, int32_t n_dom, int32_t n_bdy,
+extern "C" int scasml_gp_newton_jv(int32_t eq_id, int32_t d, double sigma, double mu, const double *sol, const double *v, int32_t n_dom, int32_t n_bdy,
                                    double *out, void *stream) {
-    if (eq_id != SCASML_EQ_GRAD_DEPENDENT_NONLINEAR) return fail(SCASML_ERR_UNSUPPORTED, "gp_newton_jv: unknown equation id %d", eq_id);
+    if (!eq_known(eq_id)) return fail(SCASML_ERR_UNSUPPORTED, "gp_newton_jv: unknown equation id %d", eq_id);
     if (!sol || !v || !out || n_dom < 1 || n_bdy < 0) return fail(SCASML_ERR_ARG, "gp_newton_jv: bad argument");
     const int M = 4 * n_dom + n_bdy;
-    hipLaunchKernelGGL(gp_newton_jv_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, d, sigma * sigma, sol, v, n_dom, n_bdy, out);
+    hipLaunchKernelGGL(gp_newton_jv_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, EqArgs{eq_id, (double)d, sigma, mu}, sol, v, n_dom, n_bdy, out);
     return check_launch("gp_newton_jv launch");
 }
 
-extern "C" int scasml_gp_newton_jtv(int32_t eq_id, int32_t d, double sigma, const double *sol, const double *w, const double *Ab,
+extern "C" int scasml_gp_newton_jtv(int32_t eq_id, int32_t d, double sigma, double mu, const double *sol, const double *w, const double *Ab,
                                     const double *v, double scale, int32_t n_dom, int32_t n_bdy, double *out, void *stream) {
-    if (eq_id != SCASML_EQ_GRAD_DEPENDENT_NONLINEAR) return fail(SCASML_ERR_UNSUPPORTED, "gp_newton_jtv: unknown equation id %d", eq_id);
+    if (!eq_known(eq_id)) return fail(SCASML_ERR_UNSUPPORTED, "gp_newton_jtv: unknown equation id %d", eq_id);
     if (!sol || !w || !out || n_dom < 1 || n_bdy < 0) return fail(SCASML_ERR_ARG, "gp_newton_jtv: bad argument");
-    hipLaunchKernelGGL(gp_newton_jtv_kernel, dim3((n_dom + 255) / 256), dim3(256), 0, (hipStream_t)stream, d, sigma * sigma, sol, w, Ab, v,
+    hipLaunchKernelGGL(gp_newton_jtv_kernel, dim3((n_dom + 255) / 256), dim3(256), 0, (hipStream_t)stream, EqArgs{eq_id, (double)d, sigma, mu}, sol, w, Ab, v,
                        scale, n_dom, n_bdy, out);
     return check_launch("gp_newton_jtv launch");
 }
@@ -556,15 +563,15 @@ extern "C" int scasml_gemv(const double *A, int64_t M, int64_t lda, const double
     return check_launch("gemv launch");
 }
 
-extern "C" int scasml_gp_newton_system(int32_t eq_id, int32_t d, double sigma, const double *A, int64_t lda, int32_t n_dom,
+extern "C" int scasml_gp_newton_system(int32_t eq_id, int32_t d, double sigma, double mu, const double *A, int64_t lda, int32_t n_dom,
                                        int32_t n_bdy, const double *sol, const double *Ab, double *grad, double *H, int64_t ldh,
                                        int gauss_newton, void *stream) {
-    if (eq_id != SCASML_EQ_GRAD_DEPENDENT_NONLINEAR) return fail(SCASML_ERR_UNSUPPORTED, "gp_newton_system: unknown equation id %d", eq_id);
+    if (!eq_known(eq_id)) return fail(SCASML_ERR_UNSUPPORTED, "gp_newton_system: unknown equation id %d", eq_id);
     if (!A || !sol || !Ab || !grad || !H || n_dom < 1 || ldh < 3 * (int64_t)n_dom || lda < 4 * (int64_t)n_dom + n_bdy)
         return fail(SCASML_ERR_ARG, "gp_newton_system: bad argument");
     const unsigned gx = (unsigned)((ldh + 15) / 16);
     if (gx > 65535) return fail(SCASML_ERR_UNSUPPORTED, "gp_newton_system: system too large for this build");
-    hipLaunchKernelGGL(gp_newton_system_kernel, dim3(gx, gx), dim3(16, 16), 0, (hipStream_t)stream, d, sigma * sigma, A, lda, n_dom,
+    hipLaunchKernelGGL(gp_newton_system_kernel, dim3(gx, gx), dim3(16, 16), 0, (hipStream_t)stream, EqArgs{eq_id, (double)d, sigma, mu}, A, lda, n_dom,
                        n_bdy, sol, Ab, grad, H, ldh, gauss_newton);
     return check_launch("gp_newton_system launch");
 }

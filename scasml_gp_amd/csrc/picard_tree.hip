@@ -18,6 +18,7 @@
 // back (recovering the normals from them; it replays Philox only where that would be inaccurate, see
 // kReadbackMinVol, and for the full-history draws) and consumes (u_hat, div u_hat, eps_PDE) per point.
 #include "common.hpp"
+#include "equations.hpp"
 #include "philox_normal.hpp"
 
 namespace scasml {
@@ -60,7 +61,7 @@ __device__ __forceinline__ float exp_fast(float v) { return __builtin_amdgcn_exp
 // volatility (sigma sqrt(T-t) < 1e-2, i.e. T - t < 1.6e-3 at sigma = 0.25) the normals are replayed instead.
 constexpr float kReadbackMinVol = 1e-2f;
 
-template <int VAR, int MODE>
+template <int VAR, int MODE, int EQ>
 struct Walker {
     const TreeArgs &a;
     float4 mask;       // 1 on this lane's live spatial dims, 0 on padding
@@ -102,21 +103,22 @@ struct Walker {
         return mine;
     }
 
-    // equations/equations.py:248-261 at time T; ScaSML.py:61-63 subtracts the surrogate
+    // Equation.g at time T (equations/equations.py:146-162, 248-261) through the registry; ScaSML.py:61-63 subtracts the surrogate
     __device__ __forceinline__ float g_terminal(float4 XT, float u_hat) const {
-        const float s = a.T + dim_sum(XT);
-        float g = 1.0f - rcp_fast(1.0f + exp_fast(s));
+        float g = EqDef<EQ>::G(dim_sum(EqDef<EQ>::phi(XT)), a.T);
         if constexpr (MODE == SCASML_MODE_ACCUMULATE) g -= u_hat;
         return g;
     }
-    // equations/equations.py:290-304 (MLP.py:27-41) / ScaSML.py:29-47
+    // Equation.f (equations/equations.py:290-304, MLP.py:27-41); ScaSML.py:29-47: f(u_hat + u, sigma grad u_hat + z) - f(u_hat, sigma grad u_hat),
+    // where f sees the gradient through its sum only, sum_i sigma d_i u_hat = sigma div u_hat
     __device__ __forceinline__ float f_eval(float uc, float4 zc, float4 gp) const {
         const float sz = dim_sum(zc);
+        const float fd = (float)a.d;
         if constexpr (MODE == SCASML_MODE_ACCUMULATE) {
-            const float sg = a.sigma * gp.y;  // sum_i sigma * d_i u_hat
-            return a.sigma * (uc + gp.x) * (sg + sz) - a.sigma * gp.x * sg;
+            const float sg = a.sigma * gp.y;
+            return EqDef<EQ>::f(uc + gp.x, sg + sz, a.sigma, fd) - EqDef<EQ>::f(gp.x, sg, a.sigma, fd);
         } else {
-            return a.sigma * uc * sz;
+            return EqDef<EQ>::f(uc, sz, a.sigma, fd);
         }
     }
 
@@ -287,17 +289,30 @@ struct Walker {
     }
 };
 
-template <int VAR, int MODE, int N>
+template <int VAR, int MODE, int N, int EQ>
 __global__ __launch_bounds__(256) void picard_tree_kernel(const TreeArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * (blockDim.x >> 6)) + (threadIdx.x >> 6);
-    const int rpw = 64 >> a.logG;
-    int64_t local = (int64_t)wave * rpw + (lane >> a.logG);
+    int64_t local;
+    uint32_t gl;
+    if constexpr (MODE == SCASML_MODE_GENERATE) {
+        // GENERATE takes no sum over dims: lanes need not form power-of-two groups.  Flat (root, quad) mapping over the
+        // kp / 4 float4 of a row, so no lane idles through the Philox + Box-Muller work (at d = 100: 28 lanes per root
+        // instead of 32, 25 of them drawing normals)
+        const int64_t flat = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const int quads = a.kp >> 2;
+        local = flat / quads;
+        gl = (uint32_t)(flat - local * quads);
+    } else {
+        const int rpw = 64 >> a.logG;
+        local = (int64_t)wave * rpw + (lane >> a.logG);
+        gl = (uint32_t)(lane & (a.G - 1));
+    }
     const bool valid = local < a.B;
-    if (!valid) local = a.B - 1;  // idle groups shadow the last root; their stores are masked
+    if (!valid) local = a.B - 1;  // idle lanes shadow the last root; their stores are masked
 
-    Walker<VAR, MODE> w{a};
-    w.gl = (uint32_t)(lane & (a.G - 1));
+    Walker<VAR, MODE, EQ> w{a};
+    w.gl = gl;
     w.root = a.root0 + (uint32_t)local;
     w.local = local;
     w.unit = 0;
@@ -306,7 +321,7 @@ __global__ __launch_bounds__(256) void picard_tree_kernel(const TreeArgs a) {
                          dim0 + 2 < a.d ? 1.0f : 0.0f, dim0 + 3 < a.d ? 1.0f : 0.0f);
     w.tmask = make_float4(dim0 + 0 == a.d ? 1.0f : 0.0f, dim0 + 1 == a.d ? 1.0f : 0.0f,
                           dim0 + 2 == a.d ? 1.0f : 0.0f, dim0 + 3 == a.d ? 1.0f : 0.0f);
-    w.row_lane = dim0 < a.kp;
+    w.row_lane = dim0 < a.kp && (MODE != SCASML_MODE_GENERATE || valid);
     w.row_off4 = (uint32_t)((local * a.kp + (dim0 < a.kp ? dim0 : 0)) >> 2);   // a chunk's point buffer is < 2^32 floats per site block
     w.gp_off = (uint32_t)local;
     const float *row = a.x_t + local * (a.d + 1);
@@ -340,25 +355,26 @@ __global__ __launch_bounds__(256) void picard_tree_kernel(const TreeArgs a) {
     }
 }
 
-template <int VAR, int MODE>
+template <int VAR, int MODE, int EQ>
 static int launch_level(const TreeArgs &a, int n, dim3 grid, hipStream_t s) {
     switch (n) {
-        case 1: hipLaunchKernelGGL((picard_tree_kernel<VAR, MODE, 1>), grid, dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL((picard_tree_kernel<VAR, MODE, 2>), grid, dim3(256), 0, s, a); break;
-        case 3: hipLaunchKernelGGL((picard_tree_kernel<VAR, MODE, 3>), grid, dim3(256), 0, s, a); break;
-        case 4: hipLaunchKernelGGL((picard_tree_kernel<VAR, MODE, 4>), grid, dim3(256), 0, s, a); break;
-        case 5: hipLaunchKernelGGL((picard_tree_kernel<VAR, MODE, 5>), grid, dim3(256), 0, s, a); break;
+        case 1: hipLaunchKernelGGL((picard_tree_kernel<VAR, MODE, 1, EQ>), grid, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((picard_tree_kernel<VAR, MODE, 2, EQ>), grid, dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL((picard_tree_kernel<VAR, MODE, 3, EQ>), grid, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((picard_tree_kernel<VAR, MODE, 4, EQ>), grid, dim3(256), 0, s, a); break;
+        case 5: hipLaunchKernelGGL((picard_tree_kernel<VAR, MODE, 5, EQ>), grid, dim3(256), 0, s, a); break;
         default: return fail(SCASML_ERR_UNSUPPORTED, "picard_tree: level n=%d outside 1..%d", n, SCASML_MAX_LEVEL);
     }
     return check_launch("picard_tree launch");
 }
 
-template <int VAR>
+template <int VAR, int EQ>
 static int launch_mode(const TreeArgs &a, int mode, int n, dim3 grid, hipStream_t s) {
     switch (mode) {
-        case SCASML_MODE_MLP: return launch_level<VAR, SCASML_MODE_MLP>(a, n, grid, s);
-        case SCASML_MODE_GENERATE: return launch_level<VAR, SCASML_MODE_GENERATE>(a, n, grid, s);
-        case SCASML_MODE_ACCUMULATE: return launch_level<VAR, SCASML_MODE_ACCUMULATE>(a, n, grid, s);
+        case SCASML_MODE_MLP: return launch_level<VAR, SCASML_MODE_MLP, EQ>(a, n, grid, s);
+        // GENERATE evaluates neither f nor g: one instantiation (equation 0) serves every equation
+        case SCASML_MODE_GENERATE: return launch_level<VAR, SCASML_MODE_GENERATE, SCASML_EQ_GRAD_DEPENDENT_NONLINEAR>(a, n, grid, s);
+        case SCASML_MODE_ACCUMULATE: return launch_level<VAR, SCASML_MODE_ACCUMULATE, EQ>(a, n, grid, s);
     }
     return fail(SCASML_ERR_ARG, "picard_tree: unknown mode %d", mode);
 }
@@ -490,8 +506,7 @@ extern "C" int scasml_picard_tree(const scasml_problem *prob, const scasml_plan 
     if (!x_t) return fail(SCASML_ERR_ARG, "picard_tree: x_t is null");
     if (prob->d < 1 || prob->d > SCASML_MAX_DIM)
         return fail(SCASML_ERR_UNSUPPORTED, "picard_tree: d=%d outside 1..%d", prob->d, SCASML_MAX_DIM);
-    if (prob->eq_id != SCASML_EQ_GRAD_DEPENDENT_NONLINEAR)
-        return fail(SCASML_ERR_UNSUPPORTED, "picard_tree: unknown equation id %d", prob->eq_id);
+    if (!eq_known(prob->eq_id)) return fail(SCASML_ERR_UNSUPPORTED, "picard_tree: unknown equation id %d", prob->eq_id);
     if (plan->variant != 0 && plan->variant != 1) return fail(SCASML_ERR_ARG, "picard_tree: variant %d", plan->variant);
     if (plan->n < 0 || plan->n > SCASML_MAX_LEVEL)
         return fail(SCASML_ERR_UNSUPPORTED, "picard_tree: level n=%d outside 0..%d", plan->n, SCASML_MAX_LEVEL);
@@ -540,11 +555,13 @@ extern "C" int scasml_picard_tree(const scasml_problem *prob, const scasml_plan 
     a.sigma = prob->sigma;
     a.clip = prob->clip;
     const int rpw = 64 / a.G;
-    const int64_t waves = (B + rpw - 1) / rpw;
+    const int64_t waves = mode == SCASML_MODE_GENERATE ? (B * (a.kp / 4) + 63) / 64 : (B + rpw - 1) / rpw;   // GENERATE: flat (root, quad) lanes
     const int64_t blocks = (waves + 3) / 4;
     if (blocks > 0x7FFFFFFF) return fail(SCASML_ERR_UNSUPPORTED, "picard_tree: batch too large");
     const dim3 grid((unsigned)blocks);
-    return plan->variant == 0 ? launch_mode<0>(a, mode, plan->n, grid, s) : launch_mode<1>(a, mode, plan->n, grid, s);
+    int rc = SCASML_ERR_UNSUPPORTED;
+    SCASML_EQ_SWITCH(prob->eq_id, rc = (plan->variant == 0 ? launch_mode<0, EQ>(a, mode, plan->n, grid, s) : launch_mode<1, EQ>(a, mode, plan->n, grid, s)));
+    return rc;
 }
 
 extern "C" int scasml_clip(float *uz, int64_t count, float clip, void *stream) {

@@ -250,7 +250,7 @@ class DistributedGP:
         torch = _lib.require_gpu()
         lib, s = _lib.load(), _lib.stream_ptr()
         gp = self.gp
-        eq_id, d, sig = int(gp.equation.eq_id), int(gp.d), float(gp.equation.sigma())
+        eq_id, d, sig, mu = int(gp.equation.eq_id), int(gp.d), float(gp.equation.sigma()), float(gp.equation.mu())
         ch = DistCholesky(d, 1.0 / float(gp.sigma) ** 2, x_t_domain, x_t_boundary, gp.nugget, self.comm).build().factor()
         self.chol = ch
         N, Nb, M = ch.n_dom, ch.n_bdy, ch.M
@@ -260,19 +260,19 @@ class DistributedGP:
         damping = 1e-4                                              # models/GP.py:490
 
         def residual(sol_):
-            _lib.check(lib.scasml_gp_newton_b(eq_id, d, sig, _lib.ptr(sol_), _lib.ptr(bdy_g), N, Nb, _lib.ptr(b), s), "gp_newton_b")
+            _lib.check(lib.scasml_gp_newton_b(eq_id, d, sig, mu, _lib.ptr(sol_), _lib.ptr(bdy_g), N, Nb, _lib.ptr(b), s), "gp_newton_b")
             Ab = ch.solve(b)
             return float(torch.dot(b, Ab)), Ab
 
         def jtv(w, Ab=None, v=None):
             out = torch.empty(3 * N, dtype=torch.float64, device="cuda")
-            _lib.check(lib.scasml_gp_newton_jtv(eq_id, d, sig, _lib.ptr(sol), _lib.ptr(w), _lib.ptr(Ab), _lib.ptr(v), 2.0, N, Nb,
+            _lib.check(lib.scasml_gp_newton_jtv(eq_id, d, sig, mu, _lib.ptr(sol), _lib.ptr(w), _lib.ptr(Ab), _lib.ptr(v), 2.0, N, Nb,
                                                 _lib.ptr(out), s), "gp_newton_jtv")
             return out
 
         def hess(v, Ab):
             jv = torch.empty(M, dtype=torch.float64, device="cuda")
-            _lib.check(lib.scasml_gp_newton_jv(eq_id, d, sig, _lib.ptr(sol), _lib.ptr(v), N, Nb, _lib.ptr(jv), s), "gp_newton_jv")
+            _lib.check(lib.scasml_gp_newton_jv(eq_id, d, sig, mu, _lib.ptr(sol), _lib.ptr(v), N, Nb, _lib.ptr(jv), s), "gp_newton_jv")
             return jtv(ch.solve(jv), Ab, v if Ab is not None else None) + damping * v
 
         def cg(rhs, Ab):

@@ -93,6 +93,8 @@ class GP(object):
         m.split = self._split_for(x_bound) if x_bound > 0 else int(self.eval_split)
         m.a = 1.0 / float(self.sigma) ** 2
         m.sigma_eq = float(self.equation.sigma())
+        m.mu_eq = float(self.equation.mu())
+        m.eq_id = int(self.equation.eq_id)
         m.colloc, m.colloc_frag, m.coef = self._colloc.data_ptr(), self._frag.data_ptr(), self._coef.data_ptr()
         m.colloc_bf16 = self._bf16.data_ptr()
         m.colloc_is_f16 = int(self._colloc_is_f16)
@@ -116,7 +118,7 @@ class GP(object):
         if self.compat == "reference":
             N = self.N_domain + self.N_boundary
             _lib.check(lib.scasml_gp_eval_compat(self.d, 1.0 / float(self.sigma) ** 2, float(self.equation.sigma()),
-                                                 _lib.ptr(self._colloc_t), self.N_domain, self.N_boundary, N, _lib.ptr(self._rv_dev),
+                                                 float(self.equation.mu()), int(self.equation.eq_id), _lib.ptr(self._colloc_t), self.N_domain, self.N_boundary, N, _lib.ptr(self._rv_dev),
                                                  self.laplacian_idx.ctypes.data_as(C.c_void_p), 1, _lib.ptr(pts), n_rows,
                                                  pts.shape[1], _lib.ptr(out4), None, _lib.stream_ptr()), "gp_eval_compat")
             return
@@ -209,7 +211,7 @@ class GP(object):
         L = self._L_pad
         Mp = L.shape[0]
         s = _lib.stream_ptr()
-        eq_id, d, sig = int(self.equation.eq_id), int(self.d), float(self.equation.sigma())
+        eq_id, d, sig, mu = int(self.equation.eq_id), int(self.d), float(self.equation.sigma()), float(self.equation.mu())
         A = torch.empty((Mp, Mp), dtype=torch.float64, device="cuda")   # -> K_p^-1 = L^-T L^-1
         _lib.check(lib.scasml_cholesky_inverse(_lib.ptr(L), Mp, _lib.ptr(A), s), "cholesky_inverse")
         bdy_g = torch.as_tensor(np.asarray(self.bdy_g(self.x_t_boundary), dtype=np.float64), device="cuda").contiguous()
@@ -222,14 +224,14 @@ class GP(object):
         damping = 1e-4                                                  # models/GP.py:490
 
         def residual(sol_):
-            _lib.check(lib.scasml_gp_newton_b(eq_id, d, sig, _lib.ptr(sol_), _lib.ptr(bdy_g), N, Nb, _lib.ptr(b), s), "gp_newton_b")
+            _lib.check(lib.scasml_gp_newton_b(eq_id, d, sig, mu, _lib.ptr(sol_), _lib.ptr(bdy_g), N, Nb, _lib.ptr(b), s), "gp_newton_b")
             _lib.check(lib.scasml_gemv(_lib.ptr(A), M, Mp, _lib.ptr(b), _lib.ptr(Ab), s), "gemv")
             return float(torch.dot(b, Ab))                              # loss = b^T A b, :430-444
 
         hist = [residual(sol)]
         self.grad_norms = []                                            # ||grad J|| at the start of every iteration (:518-519)
         for _ in range(GN_steps):                                       # :515-588
-            _lib.check(lib.scasml_gp_newton_system(eq_id, d, sig, _lib.ptr(A), Mp, N, Nb, _lib.ptr(sol), _lib.ptr(Ab),
+            _lib.check(lib.scasml_gp_newton_system(eq_id, d, sig, mu, _lib.ptr(A), Mp, N, Nb, _lib.ptr(sol), _lib.ptr(Ab),
                                                    _lib.ptr(grad), _lib.ptr(H), npad, 0, s), "gp_newton_system")
             self.grad_norms.append(float(torch.linalg.vector_norm(grad)))
             if self.grad_norms[-1] < 1e-5:                              # :521
@@ -239,7 +241,7 @@ class GP(object):
                 # the full Hessian (:511) is indefinite at this iterate (large collocation sets): the reference's LU
                 # solve would take the step regardless; use the Gauss-Newton part, which is positive semidefinite
                 self.gauss_newton_steps = getattr(self, "gauss_newton_steps", 0) + 1
-                _lib.check(lib.scasml_gp_newton_system(eq_id, d, sig, _lib.ptr(A), Mp, N, Nb, _lib.ptr(sol), _lib.ptr(Ab),
+                _lib.check(lib.scasml_gp_newton_system(eq_id, d, sig, mu, _lib.ptr(A), Mp, N, Nb, _lib.ptr(sol), _lib.ptr(Ab),
                                                        _lib.ptr(grad), _lib.ptr(H), npad, 1, s), "gp_newton_system(GN)")
                 step = self._chol_solve_padded(H, -grad, 3 * N, damping)
             if step is None:
@@ -358,20 +360,32 @@ class GP(object):
         raise NotImplementedError
 
 
-class GP_Grad_Dependent_Nonlinear(GP):
-    '''Gaussian Kernel Solver for the Grad_Dependent_Nonlinear (models/GP.py:693-769)'''
+class GP_Semilinear(GP):
+    '''The surrogate for any registered equation of the family u_t + mu div u + sigma^2/2 Lap u + f(u, sum z) = 0
+    (csrc/equations.hpp): the reference has one concrete subclass per PDE (models/GP.py:693-769 for
+    Grad_Dependent_Nonlinear); here the equation's eq_id selects F and f inside the kernels.'''
 
     def rhs_f(self, x_t):
         return np.zeros((np.asarray(x_t).shape[0],), dtype=np.float64)     # :700-702
 
     def time_der_rep(self, sol, rhs_f):
-        '''F(z) = -sigma^2 z1 z5 + (1/d + sigma^2/2) z5 - (sigma^2/2) z3 + rhs_f  (:705-719)'''
-        N, d, s = self.N_domain, self.d, self.equation.sigma()
-        z1, z3, z5 = sol[:N], sol[N:2 * N], sol[2 * N:]
-        return -s ** 2 * z1 * z5 + (1 / d + s ** 2 / 2) * z5 - (s ** 2 / 2) * z3 + rhs_f
+        '''F(z) = -mu z5 - (sigma^2/2) z3 - f(z1, sigma z5) + rhs_f; for Grad_Dependent_Nonlinear
+        -sigma^2 z1 z5 + (1/d + sigma^2/2) z5 - (sigma^2/2) z3 + rhs_f  (:705-719)'''
+        N = self.N_domain
+        sol = np.asarray(sol, dtype=np.float64)
+        return self.equation.F_parts(sol[:N], sol[N:2 * N], sol[2 * N:])[0] + rhs_f
 
     def compute_PDE_loss(self, x_t_infer):
-        '''dt u + (sigma^2 u - 1/d - sigma^2/2) div u + sigma^2/2 Lap u  (models/GP.py:746-769)'''
+        '''dt u + mu div u + sigma^2/2 Lap u + f(u, sigma div u); for Grad_Dependent_Nonlinear
+        dt u + (sigma^2 u - 1/d - sigma^2/2) div u + sigma^2/2 Lap u  (models/GP.py:746-769)'''
         pts, was_numpy = self._points_device(x_t_infer)
         out = self._eval_device(pts)[:, 2:3]
         return out.cpu().numpy() if was_numpy else out
+
+
+class GP_Grad_Dependent_Nonlinear(GP_Semilinear):
+    '''Gaussian Kernel Solver for the Grad_Dependent_Nonlinear (models/GP.py:693-769)'''
+
+
+class GP_Cubic_Reaction_Diffusion(GP_Semilinear):
+    '''The surrogate of equations.Cubic_Reaction_Diffusion (eq_id 1).'''
