@@ -54,6 +54,8 @@ def parse():
                     help="samples leg: use the largest number of sample ranks (a divisor of the rank count) whose dealt load "
                          "max/mean stays below this; the remaining factor shards roots")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gp-train-large", action="store_true",
+                    help="skip the M = 34 999 leg of the gp_train block (d = 250, 8333 + 1667 collocation points, ~30 GB, ~15 s)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development only: all ranks share cuda:0 and rendezvous over gloo (a 1-GPU box cannot host RCCL ranks)")
     return ap.parse_args()
@@ -96,6 +98,49 @@ def cpu_baseline(args, eq, gp, eng, n, par, x_t, x_dev, x_dom, x_bdy, steps_exec
             "sample": "%d of the %d roots, same inputs and Philox streams, NumPy float64 oracle (oracle/mlp.py%s), %.1f s"
                       % (ns, B, " + oracle/gp.py" if gp is not None else "", t_cpu),
             "max_abs_diff_gpu_vs_cpu": float(np.nanmax(np.abs(uz_gpu.cpu().numpy() - uz_cpu)))}
+
+
+FP64_MFMA_PEAK_TFLOPS = 78.6    # v_mfma_f64_16x16x4_f64 dense, MI355X_MICROARCH.md / SURVEY.md 8(d)
+
+
+def gp_train_block(d, n_dom, n_bdy):
+    """GP training stages (models/GP.py:182-268, 487-604) with their rooflines: Gram, Cholesky (M^3/3 flop), K_p^-1 from the
+    factor (2 M^3 / 3), the Newton iteration; HIP events per stage."""
+    import torch
+    from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
+    from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
+    eq = Grad_Dependent_Nonlinear(d + 1)
+    st = np.random.get_state()
+    np.random.seed(1234)
+    dom, bdy = eq.generate_data(n_dom, n_bdy)
+    np.random.set_state(st)
+    out = None
+    for rep in range(2):                                  # first pass warms code objects and the allocator
+        gp = GP_Grad_Dependent_Nonlinear(eq)
+        gp.profile = rep == 1
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gp.GPsolver(dom, bdy, GN_steps=20)
+        torch.cuda.synchronize()
+        fit_s = time.perf_counter() - t0
+        if rep == 1:
+            M = gp.phi_dim
+            ms = gp.stage_ms
+            chol_tf = M ** 3 / 3.0 / (ms["cholesky"] * 1e-3) / 1e12
+            inv_tf = 2.0 * M ** 3 / 3.0 / (ms["inverse"] * 1e-3) / 1e12
+            N = n_dom + n_bdy
+            gram_tf = (2.0 * N * N * (d + 1) + 8.0 * M * M) / (ms["gram"] * 1e-3) / 1e12
+            out = {"d": d, "collocation": "%d+%d" % (n_dom, n_bdy), "M": M, "K_gb_f64": round(M * M * 8 / 1e9, 2), "fit_s": round(fit_s, 3),
+                   "newton_steps": len(gp.loss_history) - 1,
+                   "gram_ms": round(ms["gram"], 3), "gram_tflops": round(gram_tf, 2),
+                   "cholesky_ms": round(ms["cholesky"], 3), "cholesky_tflops": round(chol_tf, 2),
+                   "cholesky_frac_of_fp64_mfma_peak": round(chol_tf / FP64_MFMA_PEAK_TFLOPS, 4),
+                   "inverse_ms": round(ms["inverse"], 3), "inverse_tflops": round(inv_tf, 2),
+                   "inverse_frac_of_fp64_mfma_peak": round(inv_tf / FP64_MFMA_PEAK_TFLOPS, 4),
+                   "peak_fp64_mfma_tflops": FP64_MFMA_PEAK_TFLOPS}
+        del gp
+        torch.cuda.empty_cache()
+    return out
 
 
 def spawn_ranks(n):
@@ -285,17 +330,25 @@ def main():
     n_inf = B * ppr
     flops = n_inf * (2.0 * n_colloc * (d + 1) + 10.0 * m_feat)     # 2 N_inf N (d+1) + 10 N_inf M
     gp_ms = kernel_ms.get("gp_eval")
-    traffic = None
-    # HBM bytes per launch come from separate rocprofv3 --pmc passes of this same command, condensed by
-    # profiles/summarize.py (they cannot be collected inside this process)
-    prof = os.path.join(ROOT, "profiles", "r01_gp_eval_pmc.json")
-    if os.path.exists(prof):
+    traffic, traffic_source, issue = None, None, None
+    # HBM bytes and issue-slot counters per launch come from separate rocprofv3 --pmc passes of this same command, condensed
+    # by profiles/summarize.py (they cannot be collected inside this process): NOT measured in this run, and labelled so
+    import glob
+    for prof in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gp_eval_pmc.json")), reverse=True):
         try:
             pj = json.load(open(prof))
-            if pj.get("n_inf") == n_inf and pj.get("d") == d and pj.get("split") == int(gp.eval_split):
+            if gp is not None and pj.get("n_inf") == n_inf and pj.get("d") == d and pj.get("split") == int(gp.eval_split):
                 traffic = pj.get("hbm_bytes_per_launch")
+                traffic_source = "%s (separate rocprofv3 --pmc passes of this command; FETCH_SIZE doubled per MI355X_MICROARCH.md)" % os.path.relpath(prof, ROOT)
+                if pj.get("valu_active_frac") is not None:
+                    issue = {"valu_active_frac": round(pj["valu_active_frac"], 3), "mfma_pipe_busy_frac": round(pj["mfma_pipe_busy_frac"], 3),
+                             "coexec_frac_of_mfma_busy": round(pj["coexec_frac_of_mfma_busy"], 3),
+                             "cycles_per_valu_instruction": round(pj["cycles_per_valu_instruction"], 2),
+                             "source": os.path.relpath(prof, ROOT), "note": "the kernel is VALU-bound: the vector ALUs are busy this "
+                             "fraction of the launch; the MFMA fraction quoted as `frac` is of a roof the kernel is not under"}
+                break
         except Exception:
-            traffic = None
+            continue
     roofline = None
     if kernel_ms.get("picard_mlp"):
         # plain MLP: the whole recursion is one kernel with no HBM traffic between the root row and the result;
@@ -318,7 +371,8 @@ def main():
         peak = MFMA_F32_PEAK_TFLOPS if split == 0 else MFMA_BF16_PEAK_TFLOPS
         roofline = {"kernel": "gp_eval_kernel (fp32 MFMA)" if split == 0 else ("gp_eval_bf16_kernel (2 fp16 planes, exponent-unit epilogue)" if split == 22 else "gp_eval_bf16_kernel (%d bf16 planes)" % split),
                     "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": traffic, "avg_launch_ms": round(gp_ms, 4),
+                    "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_source, "valu_issue": issue,
+                    "avg_launch_ms": round(gp_ms, 4),
                     "flops_per_launch": flops, "achieved_vs_fp32_mfma_peak": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
                     "mfma_issued_tflops": round(issued, 1), "mfma_issued_frac": round(issued / peak, 4),
                     "note": "achieved = algorithmic fp32 flops (SURVEY 8(d)); the split-precision kernel issues %dx as many "
@@ -332,6 +386,13 @@ def main():
         path_roof = {"kernels": "picard_tree generate+accumulate", "bound": "hbm", "achieved": round(gbs, 2),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                      "avg_launch_ms": round(path_ms, 4)}
+
+    # ---- GP training on record: the bench's own 1000 + 200 fit and the staged size of BASELINE configs[4] ----
+    gp_train = None
+    if world == 1 and gp is not None:
+        gp_train = [gp_train_block(d, args.train_domain, args.train_boundary)]
+        if not args.no_gp_train_large:
+            gp_train.append(gp_train_block(250, 8333, 1667))
 
     # ---- CPU baseline: the oracle restatement on a bounded sample of the same workload ----------
     cpu = None
@@ -366,7 +427,7 @@ def main():
                          "logged_reference_d20": "0.069 (results/.../20d/RepeatedExperiment.log:21)"},
         "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
         "gp_train_s": round(t_train, 2),
-        "roofline": roofline, "roofline_path": path_roof, "cpu_baseline": cpu,
+        "roofline": roofline, "roofline_path": path_roof, "gp_train": gp_train, "cpu_baseline": cpu,
     }
     print(json.dumps(line))
     if world > 1:

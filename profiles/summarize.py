@@ -22,7 +22,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def one(pattern):
-    f = glob.glob(pattern)
+    """First match of dir/*/*suffix or, for rocprofv3 runs with -o, dir/*suffix."""
+    f = glob.glob(pattern) or glob.glob(pattern.replace(os.sep + "*" + os.sep, os.sep, 1))
     return f[0] if f else None
 
 
@@ -63,6 +64,11 @@ def main():
             cyc = c["GRBM_GUI_ACTIVE"] / 8.0                      # sum over 8 XCDs
             out["mfma_pipe_busy_frac"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc)   # 1024 SIMDs
             out["effective_clock_ghz"] = cyc / (out["avg_ms_kernel_trace"] * 1e-3) / 1e9
+            if "SQ_ACTIVE_INST_VALU" in c:                        # quad-cycles (MI355X_MICROARCH.md, cycle constants)
+                out["valu_active_frac"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (1024 * cyc)
+                out["cycles_per_valu_instruction"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / c["SQ_INSTS_VALU"] if "SQ_INSTS_VALU" in c else None
+            if "SQ_VALU_MFMA_COEXEC_CYCLES" in c:
+                out["coexec_frac_of_mfma_busy"] = c["SQ_VALU_MFMA_COEXEC_CYCLES"] / c["SQ_VALU_MFMA_BUSY_CYCLES"]
         json.dump(out, open(os.path.join(HERE, tag + "_gp_eval_pmc.json"), "w"), indent=1)
         print(json.dumps(out, indent=1))
         # the two Picard-tree passes of the same step (bench-size launches = the largest grid of each kernel)

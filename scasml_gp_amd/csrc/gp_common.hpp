@@ -15,7 +15,6 @@ struct GpArgs {
     const uint16_t *colloc_f16;   // [n_tiles][2 planes][kp/16][64][8] fp16 planes (h, l = fp16(v - h), unscaled)
     const float *coef;         // [n_pad][16]  FP32-kernel constants
     const float *coef2;        // [n_pad][16]  exponent-scaled constants of the 16-bit kernels (gp_epilogue_scaled)
-    const float *coef3;        // the same constants, two rows interleaved, for the packed-f32 epilogue (gp_epilogue_packed)
     int32_t first_bdy_tile;    // collocation tiles from here on hold boundary (and padding) rows only: cL = ct = cS = 0
     float4 *out4;              // n_inf x (u, div, eps, dt)
     float *lap;                // n_inf or null
@@ -153,58 +152,6 @@ __device__ __forceinline__ void gp_epilogue_scaled(const GpStageView &st, const 
                 }
             }
         }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// The same epilogue on TWO collocation rows per instruction (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32: the lane's
-// accumulator registers 2p, 2p+1 are rows (2 (p & 1) + e) + 8 (p >> 1) + 4 half, e = 0, 1).  `coef3` holds per tile
-// [half][pair p][32 floats]: constant c of row e at 2 c + e, c = 0 a*sum y, 1 sqrt(q) a t_y, 2 e0, 3 eL, 4 et, 5 cS, 6 sqrt(q) a ct,
-// 7 2 a cL, 8 a d cS, 9 -4 a cL, 10 -2 a k1 cS, 11 2 a^2 d k1 cL (the constants of gp_epilogue_scaled).  The four sums
-// become two partial sums each (even / odd rows), added after the sweep.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-constexpr int kPairFloats = 32;
-
-template <int KIND>
-__device__ __forceinline__ void gp_epilogue_packed(const GpStageView &st, const f32x16 &acc, int half, f32x2 sx, f32x2 tx,
-                                                   f32x2 &au, f32x2 &at, f32x2 &ad, f32x2 &al) {
-    const float4 *cb = reinterpret_cast<const float4 *>(__builtin_assume_aligned(st.coef + 8 * kPairFloats * half, 16));
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        const float4 *q = cb + p * (kPairFloats / 4);
-        const f32x2 lam = {acc[2 * p], acc[2 * p + 1]};
-        const f32x2 kap = {__builtin_amdgcn_exp2f(lam.x), __builtin_amdgcn_exp2f(lam.y)};
-        const float4 q1 = q[1];
-        const f32x2 ve0 = {q1.x, q1.y}, veL = {q1.z, q1.w};
-        if constexpr (KIND == 3) {
-            au = __builtin_elementwise_fma(kap, ve0, au);
-        } else {
-            const float4 q0 = q[0];
-            const f32x2 vsy = {q0.x, q0.y}, vty = {q0.z, q0.w};
-            const f32x2 pp = tx - vty;
-            const f32x2 ss = sx - vsy;
-            const f32x2 Lh = __builtin_elementwise_fma(pp, pp, lam);
-            if constexpr (KIND == 2) {
-                const f32x2 w = kap * ve0;
-                au = __builtin_elementwise_fma(kap, ve0, au);   // the same rounding as KIND 3
-                at = __builtin_elementwise_fma(-pp, w, at);
-                ad = __builtin_elementwise_fma(-ss, w, ad);
-                al = __builtin_elementwise_fma(Lh, w, al);
-            } else {
-                const float4 q2 = q[2];
-                const f32x2 vet = {q2.x, q2.y}, vcS = {q2.z, q2.w};
-                const f32x2 E = __builtin_elementwise_fma(vcS, ss, __builtin_elementwise_fma(vet, pp, __builtin_elementwise_fma(veL, Lh, ve0)));
-                au = __builtin_elementwise_fma(kap, E, au);
-                if constexpr (KIND == 0) {
-                    const float4 q3 = q[3], q4 = q[4], q5 = q[5];
-                    const f32x2 act = {q3.x, q3.y}, c2 = {q3.z, q3.w}, c3 = {q4.x, q4.y}, c4 = {q4.z, q4.w}, c5 = {q5.x, q5.y}, c6 = {q5.z, q5.w};
-                    at = __builtin_elementwise_fma(kap, __builtin_elementwise_fma(-pp, E, act), at);
-                    ad = __builtin_elementwise_fma(kap, __builtin_elementwise_fma(-ss, E, __builtin_elementwise_fma(c2, ss, c3)), ad);
-                    al = __builtin_elementwise_fma(kap, __builtin_elementwise_fma(Lh, E + c4, __builtin_elementwise_fma(c5, ss, c6)), al);
-                }
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
     }
 }
 

@@ -322,12 +322,6 @@ __global__ void gp_pack_kernel(int d, float a, const float *x_dom, int n_dom, co
     c2[10] = -2.0f * a * k1 * cS;
     c2[11] = 2.0f * a * a * fd * k1 * cL;
     c2[12] = c2[13] = c2[14] = c2[15] = 0.0f;
-    // the same twelve constants, two rows interleaved, for the packed epilogue (gp_common.hpp, gp_epilogue_packed):
-    // row i of a tile is element e = i & 1 of pair p = 2 (i >> 3) + ((i >> 1) & 1) of half (i >> 2) & 1
-    const int e = i & 1, pr = ((i >> 3) << 1) | ((i >> 1) & 1), hf = (i >> 2) & 1;
-    float *c3 = coef + (int64_t)2 * n_pad * kCoefRow + (((int64_t)tile * 2 + hf) * 8 + pr) * kPairFloats;
-    for (int c = 0; c < 12; ++c) c3[2 * c + e] = c2[c];
-    for (int c = 12; c < 16; ++c) c3[2 * c + e] = 0.0f;
 }
 
 template <int NK4>
@@ -365,7 +359,7 @@ extern "C" int64_t scasml_gp_plane_halfwords(int32_t d, int32_t n_pad) {
     return (int64_t)n_pad * 5 * kp;
 }
 
-extern "C" int64_t scasml_gp_coef_floats(int32_t n_pad) { return (int64_t)n_pad * 3 * kCoefRow; }
+extern "C" int64_t scasml_gp_coef_floats(int32_t n_pad) { return (int64_t)n_pad * 2 * kCoefRow; }
 
 extern "C" int scasml_gp_pack(int32_t d, float a, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy,
                               const double *rv, float *colloc_out, float *colloc_frag_out, uint16_t *colloc_bf16_out,
@@ -395,7 +389,6 @@ static int gp_eval_impl(const scasml_gp_model *m, const float *points, int64_t n
     g.rows_per_site = rows_per_site;
     g.coef = m->coef;
     g.coef2 = m->coef + (int64_t)m->n_pad * kCoefRow;
-    g.coef3 = m->coef + (int64_t)2 * m->n_pad * kCoefRow;
     g.first_bdy_tile = (m->n_dom + SCASML_GP_TILE - 1) / SCASML_GP_TILE;
     g.out4 = reinterpret_cast<float4 *>(out4);
     g.lap = lap;

@@ -29,13 +29,6 @@
 
 #include "gp_common.hpp"
 
-#ifndef SCASML_GP_PRIO
-#define SCASML_GP_PRIO 0
-#endif
-#ifndef SCASML_GP_PACKED     // 1: epilogue on two collocation rows per instruction (packed f32 VALU), 0: one row per instruction
-#define SCASML_GP_PACKED 0
-#endif
-
 namespace scasml {
 
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -159,7 +152,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
     auto stage = [&](int tile, int slot) {
         const uint32_t dst = lds_base + (uint32_t)(slot * STAGE) * 4u;
         const float *srcA = reinterpret_cast<const float *>(F16 ? g.colloc_f16 : g.colloc_bf16) + (int64_t)tile * (F16 ? 2 : 3) * KS * 256;
-        const float *srcC = (SCASML_GP_PACKED ? g.coef3 : g.coef2) + (int64_t)tile * 512 - (int64_t)NPL * KS * 256;   // chunk c >= NPL*KS -> coef + (c - NPL*KS) KiB
+        const float *srcC = g.coef2 + (int64_t)tile * 512 - (int64_t)NPL * KS * 256;   // chunk c >= NPL*KS -> coef + (c - NPL*KS) KiB
         auto chunk = [&](int c) {
             const float *src = c < NPL * KS ? srcA : srcC;
             glds16_asm(src + c * 256, (uint32_t)lane * 16u, dst + (uint32_t)c * 1024u);
@@ -268,12 +261,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
         sx = g.a * (ps - pt);                 // the row sum includes t
         tx = sqrtf(qs) * g.a * pt;
     }
-#if SCASML_GP_PACKED
-    f32x2 au = {0.0f, 0.0f}, at = {0.0f, 0.0f}, ad = {0.0f, 0.0f}, al = {0.0f, 0.0f};
-    const f32x2 sx2 = {sx, sx}, tx2 = {tx, tx};
-#else
     float au = 0.0f, at = 0.0f, ad = 0.0f, al = 0.0f;
-#endif
 
     auto a_of = [&](int slot) { return reinterpret_cast<const float4 *>(lds + slot * STAGE); };
     auto view = [&](int slot) {
@@ -298,34 +286,21 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
         constexpr bool UO = decltype(uo)::value;
         constexpr int AHEAD = NSLOT == 4 ? 2 : 1;
         auto tile = [&](int jt, auto kind) {
+            // (Measured and rejected here, profiles/r02_gp_eval_experiments.txt: s_setprio around either phase -- no effect;
+            // a packed-f32 epilogue on two rows per instruction -- 45 % fewer VALU instructions, 6 % slower.)
             // Three basic blocks per tile -- staging, MFMAs, epilogue -- behind a scalar the optimiser cannot see through
             // (`region`, always all ones).  As one block the register allocator interleaves the point planes with the
             // epilogue's temporaries and spills 450-620 B per lane inside the loop (72 ms instead of 8, round 1);
             // __builtin_amdgcn_sched_barrier between the phases does not prevent that (tried: same spills), separate
             // blocks do.  tests/test_abi_and_host.py fails the build on scratch instructions inside these loops.
-#ifdef SCASML_ABLATION     // development builds only (tools/gp_eval_ablation.sh): phases switched off by g.dbg, results are garbage
+#ifdef SCASML_ABLATION     // development builds only (tools/build_variant.sh abl gp_eval_bf16.hip -DSCASML_ABLATION, and the same flag on gp_eval.hip): phases switched off by g.dbg, results are garbage
             if (jt + AHEAD < n_tiles && !(g.dbg & 8)) stage(jt + AHEAD, (jt + AHEAD) % NSLOT);
             if (!(g.dbg & 1)) gp_mfma_tile_bf16<KS, SPLIT, PF, F16, YEXACT>(a_of(jt % NSLOT), xb, acc, lane);
             if (!(g.dbg & 2)) gp_epilogue_scaled<decltype(kind)::value, PF>(view(jt % NSLOT), acc, half, sx, tx, au, at, ad, al);
 #else
             if (jt + AHEAD < n_tiles) stage(jt + AHEAD, (jt + AHEAD) % NSLOT);
-#if SCASML_GP_PRIO == 2     // experiment: the matrix phase at raised priority
-            __builtin_amdgcn_s_setprio(1);
-#endif
             if (region & 1) gp_mfma_tile_bf16<KS, SPLIT, PF, F16, YEXACT>(a_of(jt % NSLOT), xb, acc, lane);
-#if SCASML_GP_PRIO == 2
-            __builtin_amdgcn_s_setprio(0);
-#elif SCASML_GP_PRIO == 1   // experiment: the vector phase at raised priority (MI355X_MICROARCH.md, two waves per SIMD, item 2)
-            __builtin_amdgcn_s_setprio(1);
-#endif
-#if SCASML_GP_PACKED
-            if (region & 2) gp_epilogue_packed<decltype(kind)::value>(view(jt % NSLOT), acc, half, sx2, tx2, au, at, ad, al);
-#else
             if (region & 2) gp_epilogue_scaled<decltype(kind)::value, PF>(view(jt % NSLOT), acc, half, sx, tx, au, at, ad, al);
-#endif
-#if SCASML_GP_PRIO == 1
-            __builtin_amdgcn_s_setprio(0);
-#endif
 #endif
             rendezvous(jt + AHEAD < n_tiles);
         };
@@ -339,15 +314,10 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
 
     // undo the exponent units (gp_common.hpp): dt = sum / sqrt(q), lap = sum / k1 - a d u
     const float s2 = g.sigma * g.sigma;
-#if SCASML_GP_PACKED
-    const float su = au.x + au.y, st = at.x + at.y, sd = ad.x + ad.y, sl = al.x + al.y;
-#else
-    const float su = au, st = at, sd = ad, sl = al;
-#endif
-    const float u = su + __shfl_xor(su, 32);
-    const float dt = (st + __shfl_xor(st, 32)) / sqrtf(qs);
-    const float dv = sd + __shfl_xor(sd, 32);
-    const float lp = (sl + __shfl_xor(sl, 32)) / k1 - g.a * (float)g.d * u;
+    const float u = au + __shfl_xor(au, 32);
+    const float dt = (at + __shfl_xor(at, 32)) / sqrtf(qs);
+    const float dv = ad + __shfl_xor(ad, 32);
+    const float lp = (al + __shfl_xor(al, 32)) / k1 - g.a * (float)g.d * u;
     const int64_t row = p0 + col;
     if (half == 0 && row < g.n_inf) {
         const float eps = gp_pde_residual(g, u, dt, dv, lp);   // models/GP.py:767-768

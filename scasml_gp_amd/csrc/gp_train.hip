@@ -13,57 +13,6 @@ namespace scasml {
 
 constexpr int NB = 32;
 
-// ---------------------------------------------------------------------------------- Gram
-// One thread per ordered pair (i, j) of collocation points; writes the up-to-16 operator
-// combinations of that pair into their blocks.
-__global__ void gp_gram_kernel(int d, double a, const float *x_dom, int n_dom, const float *x_bdy, int n_bdy, double *K) {
-    const int N = n_dom + n_bdy;
-    const int i = blockIdx.y * blockDim.y + threadIdx.y;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N || j >= N) return;
-    const int64_t M = 4 * (int64_t)n_dom + n_bdy;
-    const float *xi = i < n_dom ? x_dom + (int64_t)i * (d + 1) : x_bdy + (int64_t)(i - n_dom) * (d + 1);
-    const float *yj = j < n_dom ? x_dom + (int64_t)j * (d + 1) : x_bdy + (int64_t)(j - n_dom) * (d + 1);
-    double r2 = 0.0, S = 0.0;
-    for (int k = 0; k < d; ++k) {
-        const double r = (double)xi[k] - (double)yj[k];
-        r2 = fma(r, r, r2);
-        S += r;
-    }
-    const double rt = (double)xi[d] - (double)yj[d];
-    const double rho2 = r2;
-    r2 = fma(rt, rt, r2);
-    const double kap = exp(-0.5 * a * r2);
-    const double lap = a * a * rho2 - a * d;
-    // operator polynomials P(opx, opy); ops: 0 = I, 1 = Lap, 2 = dt, 3 = div
-    double P[4][4];
-    P[0][0] = 1.0;
-    P[0][1] = lap;
-    P[0][2] = a * rt;
-    P[0][3] = a * S;
-    P[1][0] = lap;
-    P[1][1] = a * a * a * a * rho2 * rho2 - (2.0 * d + 4.0) * a * a * a * rho2 + ((double)d * d + 2.0 * d) * a * a;
-    P[1][2] = a * rt * lap;
-    P[1][3] = a * S * lap - 2.0 * a * a * S;
-    P[2][0] = -a * rt;
-    P[2][1] = -a * rt * lap;
-    P[2][2] = a - a * a * rt * rt;
-    P[2][3] = -a * a * rt * S;
-    P[3][0] = -a * S;
-    P[3][1] = -(a * S * lap - 2.0 * a * a * S);
-    P[3][2] = -a * a * rt * S;
-    P[3][3] = a * d - a * a * S * S;
-    // row / column index of (op, point): u(dom) | u(bdy) | Lap(dom) | dt(dom) | div(dom)
-    const int nops_i = i < n_dom ? 4 : 1, nops_j = j < n_dom ? 4 : 1;
-    for (int ox = 0; ox < nops_i; ++ox) {
-        const int64_t row = ox == 0 ? i : (int64_t)n_dom + n_bdy + (int64_t)(ox - 1) * n_dom + i;
-        for (int oy = 0; oy < nops_j; ++oy) {
-            const int64_t col = oy == 0 ? j : (int64_t)n_dom + n_bdy + (int64_t)(oy - 1) * n_dom + j;
-            K[row * M + col] = P[ox][oy] * kap;
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------- Cholesky
 // (1) factor the NB x NB diagonal block in LDS (adds the nugget to the diagonal first)
 __global__ __launch_bounds__(NB *NB) void chol_diag_kernel(double *A, int64_t M, int64_t k0, int32_t *info) {
@@ -205,6 +154,98 @@ __device__ __forceinline__ void mfma_tile_k_loop(double *smem, int64_t k_begin, 
         if (more) park(cur ^ 1);
         __syncthreads();
         cur ^= 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------- Gram on the FP64 matrix cores
+// K(phi, phi) (models/GP.py:182-258): the only O(N^2 d) part of a pair's 16 entries is x_i . y_j, so the pair geometry of a
+// 64 x 64 tile of collocation pairs is ONE tile of the GEMM X Y^T (v_mfma_f64_16x16x4_f64, K = d + 1 streamed through LDS as
+// in the Cholesky update) and everything else is the epilogue of SURVEY.md K5:  |x - y|^2 = |x|^2 + |y|^2 - 2 x.y,
+// r_t = t_x - t_y, S = sum x - sum y (per-point statistics, computed once per tile into LDS), kappa = exp(-a r^2 / 2) and the 16
+// operator polynomials of Appendix C, written straight into their blocks.  float64 throughout: the reference factors this
+// matrix in x64 (models/GP.py:258) and the norm expansion loses ~1e-15 of r^2.
+__global__ __launch_bounds__(256) void gp_gram_mfma_kernel(int d, double a, const float *x_dom, int n_dom, const float *x_bdy, int n_bdy,
+                                                           double *K) {
+    constexpr int NT = 2, TBX = 32 * NT, PER = TBX * NB / 256;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double stat[2 * TBX][4];          // (|x|^2 with t, sum of the spatial coordinates, t) of the tile's 64 + 64 points
+    const int N = n_dom + n_bdy;
+    const int64_t M = 4 * (int64_t)n_dom + n_bdy;
+    const int i0 = blockIdx.y * TBX, j0 = blockIdx.x * TBX;
+    auto row_of = [&](int p) { return p < n_dom ? x_dom + (int64_t)p * (d + 1) : x_bdy + (int64_t)(p - n_dom) * (d + 1); };
+    {   // two threads per point, even / odd coordinates, combined with one shuffle
+        const int q = threadIdx.x >> 1, par = threadIdx.x & 1;
+        const int p = q < TBX ? i0 + q : j0 + q - TBX;
+        double n = 0.0, sx = 0.0, tt = 0.0;
+        if (p < N) {
+            const float *x = row_of(p);
+            for (int k = par; k < d; k += 2) {
+                const double v = (double)x[k];
+                n = fma(v, v, n);
+                sx += v;
+            }
+            tt = (double)x[d];
+        }
+        n += __shfl_xor(n, 1);
+        sx += __shfl_xor(sx, 1);
+        if (par == 0) {
+            stat[q][0] = fma(tt, tt, n);
+            stat[q][1] = sx;
+            stat[q][2] = tt;
+        }
+    }   // visible to everyone after the barriers of the K loop below
+    TileAcc<NT> t;
+    mfma_tile_zero(t);
+    const int64_t kend = ((int64_t)d + 1 + NB - 1) / NB * NB;
+    mfma_tile_k_loop<NT>(smem, 0, kend, [&](int64_t kk, double (&ra)[PER], double (&rb)[PER]) {
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int idx = threadIdx.x + e * 256, rr = idx / NB, cc = idx % NB;
+            const int k = (int)kk + cc;
+            ra[e] = (i0 + rr < N && k <= d) ? (double)row_of(i0 + rr)[k] : 0.0;
+            rb[e] = (j0 + rr < N && k <= d) ? (double)row_of(j0 + rr)[k] : 0.0;
+        }
+    }, t);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wr = (wv >> 1) * (16 * NT), wc = (wv & 1) * (16 * NT);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const double fd = (double)d;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+        const int j = j0 + wc + 16 * jt + l15;
+        if (j >= N) continue;
+        const double nj = stat[TBX + j - j0][0], sj = stat[TBX + j - j0][1], tj = stat[TBX + j - j0][2];
+        const int nops_j = j < n_dom ? 4 : 1;
+#pragma unroll
+        for (int it = 0; it < NT; ++it)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = i0 + wr + 16 * it + l4 + 4 * e;
+                if (i >= N) continue;
+                const double ni = stat[i - i0][0], si = stat[i - i0][1], ti = stat[i - i0][2];
+                double r2 = fma(-2.0, t.v[it][jt][e], ni + nj);
+                r2 = r2 < 0.0 ? 0.0 : r2;
+                const double rt = ti - tj, S = si - sj;
+                double rho2 = fma(-rt, rt, r2);
+                rho2 = rho2 < 0.0 ? 0.0 : rho2;
+                const double kap = exp(-0.5 * a * r2);
+                const double lap = a * a * rho2 - a * fd;
+                const int nops_i = i < n_dom ? 4 : 1;
+                // operator polynomials P(opx, opy); ops: 0 = I, 1 = Lap, 2 = dt, 3 = div (the table of gp_gram_rows_kernel)
+                const double aS = a * S, art = a * rt, mix = aS * lap - 2.0 * a * aS;
+                const double P[4][4] = {
+                    {1.0, lap, art, aS},
+                    {lap, a * a * a * a * rho2 * rho2 - (2.0 * fd + 4.0) * a * a * a * rho2 + (fd * fd + 2.0 * fd) * a * a, art * lap, mix},
+                    {-art, -art * lap, a - art * art, -art * aS},
+                    {-aS, -mix, -art * aS, a * fd - aS * aS}};
+                for (int ox = 0; ox < nops_i; ++ox) {
+                    const int64_t row = ox == 0 ? i : (int64_t)N + (int64_t)(ox - 1) * n_dom + i;
+                    for (int oy = 0; oy < nops_j; ++oy) {
+                        const int64_t col = oy == 0 ? j : (int64_t)N + (int64_t)(oy - 1) * n_dom + j;
+                        K[row * M + col] = P[ox][oy] * kap;
+                    }
+                }
+            }
     }
 }
 
@@ -421,16 +462,6 @@ __global__ void zero_upper_kernel(double *A, int64_t M) {
 
 using namespace scasml;
 
-extern "C" int scasml_gp_gram(int32_t d, double a, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy,
-                              double *K, void *stream) {
-    if (!x_dom || !K || (n_bdy > 0 && !x_bdy)) return fail(SCASML_ERR_ARG, "gp_gram: null argument");
-    if (d < 1 || n_dom < 1 || n_bdy < 0) return fail(SCASML_ERR_ARG, "gp_gram: bad sizes");
-    const int N = n_dom + n_bdy;
-    hipLaunchKernelGGL(gp_gram_kernel, dim3((N + 15) / 16, (N + 15) / 16), dim3(16, 16), 0, (hipStream_t)stream, d, a, x_dom,
-                       n_dom, x_bdy, n_bdy, K);
-    return check_launch("gp_gram launch");
-}
-
 // ---- launch helpers ------------------------------------------------------------------------------------------
 template <class Kern>
 static bool reserve_lds(Kern kern, size_t bytes) {
@@ -612,3 +643,16 @@ extern "C" int scasml_cholesky_inverse(const double *L, int64_t M, double *A, vo
     hipLaunchKernelGGL(mirror_lower_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)M), dim3(256), 0, s, A, M);
     return check_launch("cholesky_inverse launch");
 }
+
+extern "C" int scasml_gp_gram(int32_t d, double a, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy,
+                              double *K, void *stream) {
+    if (!x_dom || !K || (n_bdy > 0 && !x_bdy)) return fail(SCASML_ERR_ARG, "gp_gram: null argument");
+    if (d < 1 || n_dom < 1 || n_bdy < 0) return fail(SCASML_ERR_ARG, "gp_gram: bad sizes");
+    const int N = n_dom + n_bdy;
+    const unsigned gt = (unsigned)((N + 63) / 64);
+    if (gt > 65535) return fail(SCASML_ERR_UNSUPPORTED, "gp_gram: too many collocation points for one launch");
+    if (!reserve_lds(gp_gram_mfma_kernel, tile_lds_bytes<2>())) return fail(SCASML_ERR_HIP, "gp_gram: cannot reserve LDS");
+    hipLaunchKernelGGL(gp_gram_mfma_kernel, dim3(gt, gt), dim3(256), tile_lds_bytes<2>(), (hipStream_t)stream, d, a, x_dom, n_dom, x_bdy, n_bdy, K);
+    return check_launch("gp_gram launch");
+}
+

@@ -60,6 +60,21 @@ class GP(object):
         # (products exact to fp32), 22 = two fp16 planes (22-bit products, half the MFMAs), 2 = two bf16
         # planes (~2^-16 per product), 0 = fp32-input MFMA
         self.eval_split = int(os.environ.get("SCASML_GP_SPLIT", "22"))
+        self.profile = False            # bench.py: HIP-event time of every training stage into self.stage_ms
+        self.stage_ms = {}
+
+    def _stage(self, name, fn):
+        """Run one training stage; with self.profile bracket it with HIP events on the launch stream."""
+        if not self.profile:
+            return fn()
+        torch = _lib.require_gpu()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        e1.synchronize()
+        self.stage_ms[name] = self.stage_ms.get(name, 0.0) + e0.elapsed_time(e1)
+        return out
 
     # ------------------------------------------------------------------ device helpers
     def _points_device(self, x):
@@ -147,17 +162,17 @@ class GP(object):
         s = _lib.stream_ptr()
         K = torch.empty((M, M), dtype=torch.float64, device="cuda")
         if self.compat == "reference":
-            _lib.check(lib.scasml_gp_gram_compat(self.d, 1.0 / float(self.sigma) ** 2, _lib.ptr(xd), self.N_domain, _lib.ptr(xb),
-                                                 self.N_boundary, self.laplacian_idx.ctypes.data_as(C.c_void_p), 1, _lib.ptr(K), s),
-                       "gp_gram_compat")
+            self._stage("gram", lambda: _lib.check(lib.scasml_gp_gram_compat(
+                self.d, 1.0 / float(self.sigma) ** 2, _lib.ptr(xd), self.N_domain, _lib.ptr(xb), self.N_boundary,
+                self.laplacian_idx.ctypes.data_as(C.c_void_p), 1, _lib.ptr(K), s), "gp_gram_compat"))
         else:
-            _lib.check(lib.scasml_gp_gram(self.d, 1.0 / float(self.sigma) ** 2, _lib.ptr(xd), self.N_domain,
-                                          _lib.ptr(xb), self.N_boundary, _lib.ptr(K), s), "gp_gram")
+            self._stage("gram", lambda: _lib.check(lib.scasml_gp_gram(
+                self.d, 1.0 / float(self.sigma) ** 2, _lib.ptr(xd), self.N_domain, _lib.ptr(xb), self.N_boundary, _lib.ptr(K), s), "gp_gram"))
         Mp = _round_up(M, 32)
         L = torch.eye(Mp, dtype=torch.float64, device="cuda")
         L[:M, :M] = K
         info = torch.zeros(1, dtype=torch.int32, device="cuda")
-        _lib.check(lib.scasml_cholesky(_lib.ptr(L), Mp, float(self.nugget), _lib.ptr(info), s), "cholesky")
+        self._stage("cholesky", lambda: _lib.check(lib.scasml_cholesky(_lib.ptr(L), Mp, float(self.nugget), _lib.ptr(info), s), "cholesky"))
         if int(info.item()) != 0 or bool(torch.isnan(L).any()):
             raise ValueError("Cholesky decomposition resulted in NaN values.")        # models/GP.py:264-265
         self._L_pad = L
@@ -213,7 +228,7 @@ class GP(object):
         s = _lib.stream_ptr()
         eq_id, d, sig, mu = int(self.equation.eq_id), int(self.d), float(self.equation.sigma()), float(self.equation.mu())
         A = torch.empty((Mp, Mp), dtype=torch.float64, device="cuda")   # -> K_p^-1 = L^-T L^-1
-        _lib.check(lib.scasml_cholesky_inverse(_lib.ptr(L), Mp, _lib.ptr(A), s), "cholesky_inverse")
+        self._stage("inverse", lambda: _lib.check(lib.scasml_cholesky_inverse(_lib.ptr(L), Mp, _lib.ptr(A), s), "cholesky_inverse"))
         bdy_g = torch.as_tensor(np.asarray(self.bdy_g(self.x_t_boundary), dtype=np.float64), device="cuda").contiguous()
         sol = torch.zeros(3 * N, dtype=torch.float64, device="cuda")
         b = torch.empty(M, dtype=torch.float64, device="cuda")

@@ -1,0 +1,98 @@
+"""The generic Equation path (equations/equations.py:15-230 is the reference's plug-in base): a second
+registered equation, Cubic_Reaction_Diffusion (eq_id 1), through every kernel family against the oracle -- Picard tree
+(f and g functors), GP training (collocation operator F with its first and second derivatives), fused GP evaluation (PDE
+residual) and ScaSML -- with the tolerances of the Grad_Dependent_Nonlinear tests."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _points(d, nd, nb, seed):
+    from oracle.equation import sample_points
+    return sample_points(np.random.default_rng(seed), d, nd, nb)
+
+
+@pytest.mark.parametrize("variant,d,n,par,B", [("quad", 20, 2, 2, 64), ("quad", 20, 3, 3, 24), ("quad", 100, 3, 3, 6), ("fh", 20, 3, 3, 40), ("fh", 100, 4, 3, 5)])
+def test_plain_mlp_on_the_second_equation_matches_oracle(variant, d, n, par, B):
+    from oracle.equation import CubicReactionDiffusion
+    from oracle.mlp import PicardOracle
+    from scasml_gp_amd.equations.equations import Cubic_Reaction_Diffusion
+    from scasml_gp_amd.solvers.MLP import MLP
+    from scasml_gp_amd.solvers.MLP_full_history import MLP_full_history
+    xt = np.concatenate(_points(d, B - B // 4, B // 4, 1))
+    eq = Cubic_Reaction_Diffusion(d + 1)
+    ora = PicardOracle(CubicReactionDiffusion(d + 1), variant, seed=3, stream=0)
+    if variant == "quad":
+        got, want = MLP(eq, seed=3).uz_solve(n, par, xt), ora.uz_solve(n, par, xt)
+    else:
+        got, want = MLP_full_history(eq, seed=3).uz_solve(n, None, xt, par), ora.uz_solve(n, par, xt)
+    assert np.all(np.abs(got - want) <= 2e-5 + 1e-4 * np.abs(want)), np.abs(got - want).max()
+
+
+@pytest.mark.parametrize("d,nd,nb", [(20, 120, 40), (6, 40, 12)])
+def test_gp_training_and_residual_on_the_second_equation_match_oracle(d, nd, nb):
+    from oracle.equation import CubicReactionDiffusion
+    from oracle.gp import OracleGP
+    from scasml_gp_amd.equations.equations import Cubic_Reaction_Diffusion
+    from scasml_gp_amd.models.GP import GP_Cubic_Reaction_Diffusion
+    dom, bdy = _points(d, nd, nb, 2)
+    gp = GP_Cubic_Reaction_Diffusion(Cubic_Reaction_Diffusion(d + 1))
+    ogp = OracleGP(CubicReactionDiffusion(d + 1))
+    gp.GPsolver(dom, bdy, GN_steps=20)
+    ogp.GPsolver(dom, bdy, GN_steps=20)
+    assert len(gp.loss_history) == len(ogp.loss_history) and np.allclose(gp.loss_history, ogp.loss_history, rtol=1e-8)
+    assert np.abs(gp.right_vector - ogp.right_vector).max() <= 1e-7 * np.abs(ogp.right_vector).max()
+    X = np.random.default_rng(4).uniform(-0.5, 0.5, (200, d + 1)).astype(np.float32)
+    X[:, -1] = np.abs(X[:, -1])
+    mag = (np.abs(ogp._features("I", X)) @ np.abs(ogp.right_vector))[:, 0] + 1e-3
+    magp = mag * (1 + ogp.a * (1 + d))
+    assert np.all(np.abs(gp.predict(X)[:, 0] - ogp.predict(X)[:, 0]) <= 2e-5 * mag)
+    assert np.all(np.abs(gp.compute_PDE_loss(X)[:, 0] - ogp.compute_PDE_loss(X)[:, 0]) <= 2e-5 * magp)
+    # host view of the collocation operator agrees with the oracle's
+    sol = np.random.default_rng(5).standard_normal(3 * nd) * 0.1
+    assert np.allclose(gp.time_der_rep(sol, 0.0), ogp.time_der_rep(sol))
+
+
+def test_scasml_on_the_second_equation_matches_oracle_and_improves_on_the_surrogate():
+    from oracle.equation import CubicReactionDiffusion, rel_l2
+    from oracle.gp import OracleGP
+    from oracle.mlp import PicardOracle
+    from scasml_gp_amd.equations.equations import Cubic_Reaction_Diffusion
+    from scasml_gp_amd.models.GP import GP_Cubic_Reaction_Diffusion
+    from scasml_gp_amd.solvers.ScaSML import ScaSML
+    from scasml_gp_amd.solvers.ScaSML_full_history import ScaSML_full_history
+    d = 20
+    dom, bdy = _points(d, 300, 60, 6)
+    eq, oeq = Cubic_Reaction_Diffusion(d + 1), CubicReactionDiffusion(d + 1)
+    ogp = OracleGP(oeq)
+    ogp.GPsolver(dom, bdy)
+    gp = GP_Cubic_Reaction_Diffusion(eq)
+    gp.load_right_vector(dom, bdy, ogp.right_vector)
+    xt = np.concatenate(_points(d, 96, 32, 7))
+    got, want = ScaSML(eq, gp, seed=2).uz_solve(2, 2, xt), PicardOracle(oeq, "quad", gp=ogp, seed=2).uz_solve(2, 2, xt)
+    assert np.all(np.abs(got - want) <= 5e-5 + 2e-4 * np.abs(want)), np.abs(got - want).max()
+    got, want = ScaSML_full_history(eq, gp, seed=2).uz_solve(3, None, xt, 3), PicardOracle(oeq, "fh", gp=ogp, seed=2).uz_solve(3, 3, xt)
+    assert np.all(np.abs(got - want) <= 5e-5 + 2e-4 * np.abs(want)), np.abs(got - want).max()
+    big = np.concatenate(_points(d, 900, 300, 8))
+    exact = eq.exact_solution(big)
+    assert rel_l2(ScaSML(eq, gp, seed=3).u_solve(2, 2, big), exact) < rel_l2(gp.predict(big), exact)
+
+
+def test_equations_without_kernels_are_refused():
+    from scasml_gp_amd import _lib
+    from scasml_gp_amd.equations.equations import Equation, Grad_Dependent_Nonlinear
+    from scasml_gp_amd.solvers.MLP import MLP
+
+    class Mine(Grad_Dependent_Nonlinear):
+        eq_id = None
+    with pytest.raises(NotImplementedError):
+        MLP(Mine(11))
+    lib = _lib.load()
+    prob = _lib.Problem(10, 7, 0.5, 0.0, 0.25, 1.0)
+    from scasml_gp_amd import tables
+    import ctypes as C
+    plan = tables.build_plan("quad", 1, 1, 0.5, True)
+    rc = lib.scasml_picard_tree(C.byref(prob), C.byref(plan), 0, C.c_void_p(8), 4, _lib.Rng(0, 0, 0, 0, 1, 0, 0), None, None, C.c_void_p(8), None, None)
+    assert rc == -2 and b"unknown equation id 7" in lib.scasml_last_error()
+    assert issubclass(Grad_Dependent_Nonlinear, Equation)
