@@ -28,10 +28,11 @@ accumulator over its whole block row (one transposed gemv), one all-reduce of 25
 Newton (models/GP.py:501-588) without K_p^-1 and without the (3 N_dom)^2 Hessian (500 GB at this size): the damped Newton
 system (H + 1e-4 I) delta = -g is solved INEXACTLY by conjugate gradients with H v = 2 J^T K_p^-1 J v + second-derivative
 term (scasml_gp_newton_jv / _jtv), one distributed solve per product; where CG meets negative curvature the step falls back
-to the Gauss-Newton operator, as the single-GPU path does.  H inherits the conditioning of K_p (1e6 at the reference's
-sizes) and CG is not preconditioned, so a step is cut off after `cg_max` products and the outer iteration absorbs the
-inexactness (more Newton steps than the dense solve needs, same stationary point: tests/test_gpu_dist_gp.py).  A
-preconditioner built from K_p = L L^T products (two collectives each instead of two per block) is the known next step.
+to the Gauss-Newton operator, as the single-GPU path does.  H inherits the conditioning of K_p (1e5-1e6 at the
+reference's sizes); CG is preconditioned with P = 1/2 S K_p S^T, S the selector of the (z1, z3, z5) rows of b -- exact
+for the rows on which b is the identity in sol, i.e. everything but the F rows: cond 1.5e5 -> 73 and 1900 -> 35 iterations at
+300 + 60 points (measured on the oracle).  P v is one product with K_p = L L^T: two local gemv sweeps over the rank's block
+rows and TWO collectives of an M-vector (DistCholesky.matvec), against two collectives PER BLOCK for a solve.
 """
 import ctypes as C
 
@@ -226,6 +227,25 @@ class DistCholesky:
                 _lib.check(lib.scasml_gemv_sub(self._ptr(R, slot * BLK, 0, Mp), Mp, BLK, k * BLK, _lib.ptr(xk), _lib.ptr(acc), 1, s), "gemv_sub^T")
         return x[:self.M].clone()
 
+    def matvec(self, v):
+        """K_p v = L (L^T v) for a replicated v (length M): each rank sweeps its block rows twice, two collectives of Mp doubles."""
+        torch = _lib.require_gpu()
+        lib, s, cm = self.lib, _lib.stream_ptr(), self.comm
+        R, Mp = self.R, self.Mp
+        vp = torch.zeros(Mp, dtype=torch.float64, device="cuda")
+        vp[:self.M] = v
+        acc = torch.zeros(Mp, dtype=torch.float64, device="cuda")          # -(L^T v), summed over ranks
+        for slot, i in enumerate(self.mine):
+            _lib.check(lib.scasml_gemv_sub(self._ptr(R, slot * BLK, 0, Mp), Mp, BLK, (i + 1) * BLK, C.c_void_p(vp.data_ptr() + 8 * i * BLK),
+                                           _lib.ptr(acc), 1, s), "gemv_sub^T")
+        cm.all_reduce(acc)
+        out = torch.zeros(Mp, dtype=torch.float64, device="cuda")
+        for slot, i in enumerate(self.mine):                                # u_i = -L_i acc = L_i (L^T v)
+            _lib.check(lib.scasml_gemv_sub(self._ptr(R, slot * BLK, 0, Mp), Mp, BLK, (i + 1) * BLK, _lib.ptr(acc),
+                                           C.c_void_p(out.data_ptr() + 8 * i * BLK), 0, s), "gemv_sub")
+        cm.all_reduce(out)
+        return out[:self.M].clone()
+
     def gather_factor(self):
         """The full lower factor on every rank (tests at small M only)."""
         torch = _lib.require_gpu()
@@ -246,7 +266,7 @@ class DistributedGP:
         self.cg_iterations = []
         self.gauss_newton_steps = 0
 
-    def fit(self, x_t_domain, x_t_boundary, GN_steps=20, cg_tol=1e-8, cg_max=300):
+    def fit(self, x_t_domain, x_t_boundary, GN_steps=20, cg_tol=1e-10, cg_max=400):
         torch = _lib.require_gpu()
         lib, s = _lib.load(), _lib.stream_ptr()
         gp = self.gp
@@ -275,25 +295,35 @@ class DistributedGP:
             _lib.check(lib.scasml_gp_newton_jv(eq_id, d, sig, mu, _lib.ptr(sol), _lib.ptr(v), N, Nb, _lib.ptr(jv), s), "gp_newton_jv")
             return jtv(ch.solve(jv), Ab, v if Ab is not None else None) + damping * v
 
+        rows = torch.cat([torch.arange(0, N), torch.arange(N + Nb, 2 * N + Nb), torch.arange(3 * N + Nb, M)]).cuda()   # z1, z3, z5 rows of b
+
+        def precond(r):
+            """P r = 1/2 S K_p S^T r."""
+            v = torch.zeros(M, dtype=torch.float64, device="cuda")
+            v[rows] = r
+            return 0.5 * ch.matvec(v)[rows]
+
         def cg(rhs, Ab):
-            """(H + damping I) x = rhs by conjugate gradients; None on negative curvature."""
+            """(H + damping I) x = rhs by preconditioned conjugate gradients; None on negative curvature."""
             x = torch.zeros_like(rhs)
             r = rhs.clone()
-            p = r.clone()
-            rr = float(torch.dot(r, r))
-            stop = cg_tol ** 2 * rr
+            z = precond(r)
+            p = z.clone()
+            rz = float(torch.dot(r, z))
+            stop = cg_tol * float(torch.linalg.vector_norm(rhs))
             it = 0
-            while rr > stop and it < cg_max:
+            while float(torch.linalg.vector_norm(r)) > stop and it < cg_max:
                 hp = hess(p, Ab)
                 php = float(torch.dot(p, hp))
                 if not php > 0.0:
                     return None, it
-                alpha = rr / php
+                alpha = rz / php
                 x.add_(p, alpha=alpha)
                 r.add_(hp, alpha=-alpha)
-                rr_new = float(torch.dot(r, r))
-                p.mul_(rr_new / rr).add_(r)
-                rr = rr_new
+                z = precond(r)
+                rz_new = float(torch.dot(r, z))
+                p.mul_(rz_new / rz).add_(z)
+                rz = rz_new
                 it += 1
             return x, it
 
