@@ -16,10 +16,12 @@ JAX's threefry stream is an un-vendored dependency and cannot be reproduced here
   ``root`` is the global index of the evaluation point; ``stream`` separates solver
   calls.  quad = 0x80000000 is reserved for the full-history uniform time draw.
 * Normals: Box-Muller on 24-bit uniforms, with ln / sin / cos evaluated by fixed
-  polynomials (Cephes single-precision coefficients) using ONLY IEEE-754 binary32
-  multiply, add and correctly-rounded sqrt, each rounded separately (no fma).  Any
-  conforming implementation -- NumPy float32 here, ``__fmul_rn/__fadd_rn`` on the GPU
-  -- therefore produces the same bits.
+  polynomials (Cephes single-precision coefficients) in Horner form, every step ONE
+  IEEE-754 binary32 operation: a multiply, an add, a correctly-rounded sqrt, or -- where
+  the code below says ``fma32`` -- a fused multiply-add (one rounding; ``fmaf`` on the GPU,
+  an exact emulation through float64 here).  Any conforming implementation therefore
+  produces the same bits.  (Round 1 specified separately rounded multiply and add
+  throughout; the fused form is 16 % fewer instructions in a kernel that is bound by them.)
 """
 import numpy as np
 
@@ -63,6 +65,23 @@ _ONE = _f32(1.0)
 _TWO_M24 = _f32(2.0 ** -24)
 
 
+def fma32(a, b, c):
+    """Correctly rounded binary32 fused multiply-add a*b + c, vectorised.  The product of two binary32 numbers is exact
+    in binary64; the binary64 sum is rounded once more, which can differ from the single binary32 rounding only when it
+    lands EXACTLY on a binary32 midpoint while the true sum does not -- detected from the sum's exact error (TwoSum) and
+    resolved by stepping off the midpoint in the error's direction before the final rounding."""
+    a64, b64, c64 = (np.asarray(v, dtype=np.float32).astype(np.float64) for v in (a, b, c))
+    a64, b64, c64 = np.broadcast_arrays(a64, b64, c64)
+    prod = a64 * b64
+    s = prod + c64
+    bb = s - prod
+    err = (prod - (s - bb)) + (c64 - bb)
+    mid = (np.ascontiguousarray(s).view(np.uint64) & np.uint64(0x1FFFFFFF)) == np.uint64(0x10000000)
+    fix = mid & (err != 0)
+    s = np.where(fix, np.nextafter(s, np.where(err > 0, np.inf, -np.inf)), s)
+    return s.astype(np.float32)
+
+
 def ln_u24(k):
     """ln(k * 2^-24) for integer k in [1, 2^24], binary32, mul/add only (Cephes logf scheme)."""
     f = k.astype(np.float32)                       # exact: k <= 2^24
@@ -74,17 +93,16 @@ def ln_u24(k):
     e = np.where(big, e + np.int32(1), e)
     x = m - _ONE                                   # exact (Sterbenz)
     z = x * x
-    p = _LOG_P[0]
+    p = np.broadcast_to(_LOG_P[0], x.shape)
     for c in _LOG_P[1:]:
-        p = p * x
-        p = p + c
+        p = fma32(p, x, c)
     y = x * z
     y = y * p
     fe = (e - np.int32(24)).astype(np.float32)
-    y = y + fe * _LN2_LO
-    y = y - _HALF * z
+    y = fma32(fe, _LN2_LO, y)
+    y = fma32(-_HALF, z, y)
     r = x + y
-    r = r + fe * _LN2_HI
+    r = fma32(fe, _LN2_HI, r)
     return r.astype(np.float32)
 
 
@@ -100,21 +118,13 @@ def sincos_u24(k):
     w = (frac - np.int32(1 << 21)).astype(np.float32) + _HALF    # exact half-integers
     x = w * _ANGLE_SCALE
     z = x * x
-    s = _SIN_P[0] * z
-    s = s + _SIN_P[1]
+    s = fma32(_SIN_P[0], z, _SIN_P[1])
+    s = fma32(s, z, _SIN_P[2])
     s = s * z
-    s = s + _SIN_P[2]
-    s = s * z
-    s = s * x
-    s = s + x
-    c = _COS_P[0] * z
-    c = c + _COS_P[1]
-    c = c * z
-    c = c + _COS_P[2]
-    c = c * z
-    c = c * z
-    c = c - _HALF * z
-    c = c + _ONE
+    s = fma32(s, x, x)
+    c = fma32(_COS_P[0], z, _COS_P[1])
+    c = fma32(c, z, _COS_P[2])
+    c = fma32(c, z * z, fma32(-_HALF, z, _ONE))
     cc = np.where(quad == 0, c, np.where(quad == 1, -s, np.where(quad == 2, -c, s)))
     ss = np.where(quad == 0, s, np.where(quad == 1, c, np.where(quad == 2, -s, -c)))
     return cc.astype(np.float32), ss.astype(np.float32)

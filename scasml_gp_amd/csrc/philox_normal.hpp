@@ -1,11 +1,11 @@
 // Device RNG: Philox4x32-10 + Box-Muller normals, bit-reproducible.
 //
 // Replaces jax.random.normal / random.uniform of solvers/MLP.py:178,221 and
-// solvers/MLP_full_history.py:99,133,138.  The normal transform is specified in IEEE-754
-// binary32 multiply / add / correctly-rounded sqrt only, each rounded on its own (this TU is
-// built with -ffp-contract=off, so `a * b + c` is never fused), with the Cephes single
-// precision logf / sinf / cosf polynomials -- any conforming implementation yields the same
-// bits, which is what tests/test_gpu_rng.py checks against the independent NumPy statement.
+// solvers/MLP_full_history.py:99,133,138.  The normal transform is specified operation by operation in IEEE-754
+// binary32: multiply, add, correctly-rounded sqrt, and fused multiply-add exactly where `fmaf` is written (this TU is
+// built with -ffp-contract=off, so `a * b + c` is never fused behind the specification's back), with the Cephes
+// single precision logf / sinf / cosf polynomials in Horner form -- any conforming implementation yields the same
+// bits, which is what tests/test_gpu_rng.py checks against the independent NumPy statement (oracle/philox.py).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -44,21 +44,21 @@ __device__ __forceinline__ float ln_u24(uint32_t k) {
     const float x = m - 1.0f;
     const float z = x * x;
     float p = 7.0376836292e-2f;
-    p = p * x; p = p + -1.1514610310e-1f;
-    p = p * x; p = p + 1.1676998740e-1f;
-    p = p * x; p = p + -1.2420140846e-1f;
-    p = p * x; p = p + 1.4249322787e-1f;
-    p = p * x; p = p + -1.6668057665e-1f;
-    p = p * x; p = p + 2.0000714765e-1f;
-    p = p * x; p = p + -2.4999993993e-1f;
-    p = p * x; p = p + 3.3333331174e-1f;
+    p = __builtin_fmaf(p, x, -1.1514610310e-1f);
+    p = __builtin_fmaf(p, x, 1.1676998740e-1f);
+    p = __builtin_fmaf(p, x, -1.2420140846e-1f);
+    p = __builtin_fmaf(p, x, 1.4249322787e-1f);
+    p = __builtin_fmaf(p, x, -1.6668057665e-1f);
+    p = __builtin_fmaf(p, x, 2.0000714765e-1f);
+    p = __builtin_fmaf(p, x, -2.4999993993e-1f);
+    p = __builtin_fmaf(p, x, 3.3333331174e-1f);
     float y = x * z;
     y = y * p;
     const float fe = (float)(e - 24);
-    y = y + fe * -2.12194440e-4f;
-    y = y - 0.5f * z;
+    y = __builtin_fmaf(fe, -2.12194440e-4f, y);
+    y = __builtin_fmaf(-0.5f, z, y);
     float r = x + y;
-    r = r + fe * 0.693359375f;
+    r = __builtin_fmaf(fe, 0.693359375f, r);
     return r;
 }
 
@@ -69,21 +69,13 @@ __device__ __forceinline__ void sincos_u24(uint32_t k, float &cc, float &ss) {
     const float w = (float)(frac - (1 << 21)) + 0.5f;
     const float x = w * 0x1.921fb6p-22f;  // (pi/2) * 2^-22 rounded to binary32
     const float z = x * x;
-    float s = -1.9515295891e-4f * z;
-    s = s + 8.3321608736e-3f;
+    float s = __builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    s = __builtin_fmaf(s, z, -1.6666654611e-1f);
     s = s * z;
-    s = s + -1.6666654611e-1f;
-    s = s * z;
-    s = s * x;
-    s = s + x;
-    float c = 2.443315711809948e-5f * z;
-    c = c + -1.388731625493765e-3f;
-    c = c * z;
-    c = c + 4.166664568298827e-2f;
-    c = c * z;
-    c = c * z;
-    c = c - 0.5f * z;
-    c = c + 1.0f;
+    s = __builtin_fmaf(s, x, x);
+    float c = __builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    c = __builtin_fmaf(c, z, 4.166664568298827e-2f);
+    c = __builtin_fmaf(c, z * z, __builtin_fmaf(-0.5f, z, 1.0f));
     // quadrant: (cos, sin) = (c, s), (-s, c), (-c, -s), (s, -c) for quad = 0..3.  Bit-select and sign-bit XOR instead of six
     // compare-selects (a v_cndmask reads its mask from SGPRs and issues at half rate): odd quadrants swap the two,
     // cos is negated in quadrants 1 and 2 (bit 1 of quad + 1), sin in quadrants 2 and 3 (bit 1 of quad).

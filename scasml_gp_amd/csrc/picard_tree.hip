@@ -60,6 +60,13 @@ __device__ __forceinline__ float exp_fast(float v) { return __builtin_amdgcn_exp
 // ~g 1.2e-7 / (sqrt(T-t) (T-t) sqrt(mg)): 1e-4 g at T - t = 1.6e-3 but 0.03 g one fp16 ulp below T.  Below this
 // volatility (sigma sqrt(T-t) < 1e-2, i.e. T - t < 1.6e-3 at sigma = 0.25) the normals are replayed instead.
 constexpr float kReadbackMinVol = 1e-2f;
+// Terminal samples whose rows ACCUMULATE requests ahead of the one it consumes.  Measured at the headline shape (same box,
+// profiles/r02_accumulate_prefetch.txt): 1 -> 1.29 ms, 2 -> 1.30, 3 -> 1.65, 5 -> 1.66: beyond one the extra registers and
+// moves cost more than the bytes in flight buy.
+#ifndef SCASML_ACC_AHEAD
+#define SCASML_ACC_AHEAD 1
+#endif
+constexpr int kAhead = SCASML_ACC_AHEAD;
 
 template <int VAR, int MODE, int EQ>
 struct Walker {
@@ -223,24 +230,34 @@ struct Walker {
             const float drift = a.mu * tau, vol = a.sigma * sqrt_fast(tau);
             float su = 0.0f;
             float4 sz = f4(0.0f);
-            // ACCUMULATE reads the stored X_T back: the rows of the next sample are requested before this one is
-            // consumed (one dependent HBM round trip per sample otherwise: the pass is latency-bound)
+            // ACCUMULATE reads the stored X_T back: the rows of the next kAhead samples are requested before this one is
+            // consumed (one dependent HBM round trip per sample otherwise; the pass is bound by the bytes it keeps in flight)
             const bool readback = MODE == SCASML_MODE_ACCUMULATE && vol >= kReadbackMinVol;
-            float4 XT_next = f4(0.0f), gp_next = f4(0.0f);
-            if (MODE == SCASML_MODE_ACCUMULATE && !(TOP && a.world > 1)) {
-                if (readback) XT_next = load_point(base);
-                gp_next = gp_at(base);
+            float4 XTq[kAhead], gpq[kAhead];
+#pragma unroll
+            for (int p = 0; p < kAhead; ++p) {
+                XTq[p] = f4(0.0f);
+                gpq[p] = f4(0.0f);
+                if (MODE == SCASML_MODE_ACCUMULATE && !(TOP && a.world > 1) && p < mg) {
+                    if (readback) XTq[p] = load_point(base + (uint32_t)p);
+                    gpq[p] = gp_at(base + (uint32_t)p);
+                }
             }
             for (int m = 0; m < mg; ++m) {                       // MLP.py:175-202
                 const uint32_t site = base + (uint32_t)m;
                 float4 nrm, XT, gpv = f4(0.0f);
                 if constexpr (MODE == SCASML_MODE_ACCUMULATE) {
                     if (!(TOP && a.world > 1)) {                 // un-sharded: software-pipelined reads
-                        XT = XT_next;
-                        gpv = gp_next;
-                        if (m + 1 < mg) {
-                            if (readback) XT_next = load_point(site + 1);
-                            gp_next = gp_at(site + 1);
+                        XT = XTq[0];
+                        gpv = gpq[0];
+#pragma unroll
+                        for (int p = 0; p + 1 < kAhead; ++p) {
+                            XTq[p] = XTq[p + 1];
+                            gpq[p] = gpq[p + 1];
+                        }
+                        if (m + kAhead < mg) {
+                            if (readback) XTq[kAhead - 1] = load_point(site + kAhead);
+                            gpq[kAhead - 1] = gp_at(site + kAhead);
                         }
                     } else {
                         if (!owned(TOP)) continue;

@@ -1,0 +1,98 @@
+#!/usr/bin/env python
+"""Rehearsal of the block-row distributed GP fit (scasml_gp_amd/dist_gp.py) with `--ranks` processes sharing ONE GPU over gloo
+(the RCCL run needs the multi-GPU node): Gram rows, distributed Cholesky, preconditioned Newton-CG, against the single-GPU
+GPsolver on the same data.  Prints one JSON line per rank 0.
+
+    python tools/dist_gp_demo.py --ranks 2 --d 250 --n-dom 8333 --n-bdy 1667      # M = 34 999: BASELINE configs[4], staged
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def worker(rank, world, port, args, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from scasml_gp_amd.dist_gp import Comm, DistCholesky, DistributedGP
+    from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
+    from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
+    eq = Grad_Dependent_Nonlinear(args.d + 1)
+    np.random.seed(1234)
+    dom, bdy = eq.generate_data(args.n_dom, args.n_bdy)
+    xt = np.concatenate(eq.generate_test_data(500, 100))
+    out = {"ranks": world, "d": args.d, "collocation": "%d+%d" % (args.n_dom, args.n_bdy)}
+    cm = Comm()
+    # stage timings of the distributed factorisation alone
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    ch = DistCholesky(args.d, 1.0 / (0.25 ** 2 * args.d), dom, bdy, 1e-2, cm).build()
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    ch.factor()
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+    b = torch.from_numpy(np.random.default_rng(0).standard_normal(ch.M)).cuda()
+    ch.solve(b)
+    torch.cuda.synchronize(); t3 = time.perf_counter()
+    ch.matvec(b)
+    torch.cuda.synchronize(); t4 = time.perf_counter()
+    out.update(M=ch.M, block_rows=ch.nblk, panel_gb_per_rank=round(ch.memory_bytes() / 1e9, 2), gram_s=round(t1 - t0, 3),
+               factor_s=round(t2 - t1, 3), factor_tflops_all_ranks=round(ch.M ** 3 / 3 / (t2 - t1) / 1e12, 2),
+               solve_s=round(t3 - t2, 3), matvec_s=round(t4 - t3, 3), collective_gb_per_rank=round(cm.bytes_moved / 1e9, 2))
+    del ch
+    torch.cuda.empty_cache()
+    gp = GP_Grad_Dependent_Nonlinear(eq)
+    fit = DistributedGP(gp, Comm())
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    fit.fit(dom, bdy, GN_steps=20)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    out.update(fit_s=round(t1 - t0, 2), newton_steps=len(gp.loss_history) - 1, cg_products=fit.cg_iterations,
+               loss=[float("%.6g" % v) for v in gp.loss_history], grad_norm_last=gp.grad_norms[-1])
+    pred = gp.predict(xt)
+    exact = eq.exact_solution(xt)
+    out["gp_rel_l2"] = round(float(np.linalg.norm(pred - exact) / np.linalg.norm(exact)), 4)
+    if rank == 0 and not args.no_single:
+        one = GP_Grad_Dependent_Nonlinear(eq)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        one.GPsolver(dom, bdy, GN_steps=20)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        out.update(single_gpu_fit_s=round(t1 - t0, 2), single_gpu_newton_steps=len(one.loss_history) - 1,
+                   right_vector_rel_diff=float(np.abs(gp.right_vector - one.right_vector).max() / np.abs(one.right_vector).max()),
+                   predict_max_diff=float(np.abs(pred - one.predict(xt)).max()))
+    if rank == 0:
+        q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ranks", type=int, default=2)
+    ap.add_argument("--d", type=int, default=250)
+    ap.add_argument("--n-dom", type=int, default=8333)
+    ap.add_argument("--n-bdy", type=int, default=1667)
+    ap.add_argument("--no-single", action="store_true")
+    args = ap.parse_args()
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, args.ranks, port, args, q)) for r in range(args.ranks)]
+    for p in procs:
+        p.start()
+    print(json.dumps(q.get(timeout=3000)), flush=True)
+    for p in procs:
+        p.join()
+
+
+if __name__ == "__main__":
+    main()
