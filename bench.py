@@ -17,6 +17,7 @@ over `sample_ranks` ranks by cost (scasml_plan_deal_units), ONE RCCL all-reduce 
 step -- timed on the same workload right after the root-sharded leg (strong scaling: the B roots of one GPU are shared).
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -333,7 +334,6 @@ def main():
     traffic, traffic_source, issue = None, None, None
     # HBM bytes and issue-slot counters per launch come from separate rocprofv3 --pmc passes of this same command, condensed
     # by profiles/summarize.py (they cannot be collected inside this process): NOT measured in this run, and labelled so
-    import glob
     for prof in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gp_eval_pmc.json")), reverse=True):
         try:
             pj = json.load(open(prof))
@@ -381,11 +381,25 @@ def main():
     # the path kernels, priced with the materialised-state model of SURVEY.md 8(d): 16*d bytes per path-step
     path_ms = (kernel_ms.get("picard_generate") or 0.0) + (kernel_ms.get("picard_accumulate") or 0.0)
     path_roof = None
+    from scasml_gp_amd import _lib as _l
+    kp_path = _l.load().scasml_point_stride(d)
     if path_ms:
         gbs = B * steps_exec * 16.0 * d / (path_ms * 1e-3) / 1e9
         path_roof = {"kernels": "picard_tree generate+accumulate", "bound": "hbm", "achieved": round(gbs, 2),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                     "avg_launch_ms": round(path_ms, 4)}
+                     "avg_launch_ms": round(path_ms, 4), "model": "16*d algorithmic bytes per path-step (SURVEY.md 8(d))"}
+        # what the two kernels really move (rocprofv3 --pmc passes condensed by profiles/summarize.py; not measured in this run)
+        for prof in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_picard_pmc.json")), reverse=True):
+            try:
+                pj = json.load(open(prof))
+                real = sum(v["hbm_bytes_per_launch"] for v in pj.values() if v.get("grid_threads") in ((B * (int(kp_path) // 4) + 255) // 256 * 256, B * 32))
+            except Exception:
+                continue
+            if real:
+                path_roof.update({"traffic": real, "traffic_gb_per_s": round(real / (path_ms * 1e-3) / 1e9, 1),
+                                  "traffic_frac_of_hbm_peak": round(real / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                  "traffic_source": os.path.relpath(prof, ROOT)})
+                break
 
     # ---- GP training on record: the bench's own 1000 + 200 fit and the staged size of BASELINE configs[4] ----
     gp_train = None

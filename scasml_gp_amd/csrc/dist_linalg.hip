@@ -72,43 +72,48 @@ __global__ void gp_gram_rows_kernel(int d, double a, const float *x_dom, int n_d
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int kLDP = kNB + 2;   // padded LDS leading dimension (gp_train.hip)
 
-// 64 x 64 tile per 256-thread workgroup, wave w owns quadrant (w >> 1, w & 1) as 2 x 2 MFMA tiles; the K dimension is
-// streamed through LDS 32 at a time, double-buffered (global loads of chunk k+1 in flight while chunk k feeds the matrix cores).
-// A: rows x K (lda), B: cols x K (ldb), C: rows x cols (ldc).  K must be a multiple of 32.
+// (32 WS)^2 tile per workgroup of WS x WS waves, each wave 2 x 2 MFMA tiles of 16 x 16 (WS = 2: 64 x 64, 4 waves; WS = 4:
+// 128 x 128, 16 waves -- half the operand traffic per flop, used when both extents are large; gp_train.hip has the same pair);
+// the K dimension is streamed through LDS 32 at a time, double-buffered (global loads of chunk k+1 in flight while chunk k
+// feeds the matrix cores).  A: rows x K (lda), B: cols x K (ldb), C: rows x cols (ldc).  K must be a multiple of 32.
 // Triangular skipping for block-cyclic row panels: local row block lb (of SCASML_DIST_BLOCK rows) is global block row
 // tri_row0 + lb * tri_stride, tile column block cb is global block column tri_col0 + cb; tiles strictly above the block
 // diagonal are not touched (tri_stride = 0: no skipping).
 struct TriMap {
     int64_t row0, stride, col0;
 };
+constexpr size_t gemm_lds_bytes(int ws) { return (size_t)2 * 2 * (32 * ws) * kLDP * sizeof(double); }   // 2 operands x 2 buffers
 
-__global__ __launch_bounds__(256) void gemm_nt_sub_kernel(double *C, int64_t ldc, int64_t rows, int64_t cols, const double *A,
-                                                          int64_t lda, const double *B, int64_t ldb, int64_t K, TriMap tri) {
-    __shared__ double Pa[2][64][kLDP];
-    __shared__ double Pb[2][64][kLDP];
-    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+template <int WS>
+__global__ __launch_bounds__(64 * WS * WS) void gemm_nt_sub_kernel(double *C, int64_t ldc, int64_t rows, int64_t cols, const double *A,
+                                                                   int64_t lda, const double *B, int64_t ldb, int64_t K, TriMap tri) {
+    constexpr int TBX = 32 * WS, THREADS = 64 * WS * WS, PER = TBX * kNB / THREADS;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double (*Pa)[TBX][kLDP] = reinterpret_cast<double (*)[TBX][kLDP]>(smem);
+    double (*Pb)[TBX][kLDP] = reinterpret_cast<double (*)[TBX][kLDP]>(smem + 2 * TBX * kLDP);
+    const int64_t r0 = (int64_t)blockIdx.y * TBX, c0 = (int64_t)blockIdx.x * TBX;
     if (tri.stride > 0 && tri.col0 + c0 / SCASML_DIST_BLOCK > tri.row0 + (r0 / SCASML_DIST_BLOCK) * tri.stride) return;   // block-uniform
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int wr = (wv >> 1) * 32, wc = (wv & 1) * 32;
+    const int wr = (wv / WS) * 32, wc = (wv % WS) * 32;
     const int l15 = lane & 15, l4 = lane >> 4;
     f64x4 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
-    double ra[8], rb[8];
+    double ra[PER], rb[PER];
     auto fetch = [&](int64_t kk) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int idx = threadIdx.x + e * 256, rr = idx / kNB, cc = idx % kNB;
+        for (int e = 0; e < PER; ++e) {
+            const int idx = threadIdx.x + e * THREADS, rr = idx / kNB, cc = idx % kNB;
             ra[e] = r0 + rr < rows ? A[(r0 + rr) * lda + kk + cc] : 0.0;
             rb[e] = c0 + rr < cols ? B[(c0 + rr) * ldb + kk + cc] : 0.0;
         }
     };
     auto park = [&](int buf) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int idx = threadIdx.x + e * 256, rr = idx / kNB, cc = idx % kNB;
+        for (int e = 0; e < PER; ++e) {
+            const int idx = threadIdx.x + e * THREADS, rr = idx / kNB, cc = idx % kNB;
             Pa[buf][rr][cc] = ra[e];
             Pb[buf][rr][cc] = rb[e];
         }
@@ -217,10 +222,22 @@ extern "C" int scasml_gemm_nt_sub(double *C, int64_t ldc, int64_t rows, int64_t 
     if (!C || !A || !B || rows < 0 || cols < 0 || K < 0 || ldc < cols || lda < K || ldb < K) return fail(SCASML_ERR_ARG, "gemm_nt_sub: bad argument");
     if (K % kNB) return fail(SCASML_ERR_UNSUPPORTED, "gemm_nt_sub: K=%lld is not a multiple of %d", (long long)K, kNB);
     if (rows == 0 || cols == 0 || K == 0) return 0;
-    const int64_t gx = (cols + 63) / 64, gy = (rows + 63) / 64;
+    const TriMap tri{tri_row0, tri_stride, tri_col0};
+    const bool big = rows >= 4096 && cols >= 4096 && K >= 256;
+    const int tb = big ? 128 : 64;
+    const int64_t gx = (cols + tb - 1) / tb, gy = (rows + tb - 1) / tb;
     if (gy > 65535) return fail(SCASML_ERR_UNSUPPORTED, "gemm_nt_sub: too many rows for one launch");
-    hipLaunchKernelGGL(gemm_nt_sub_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, C, ldc, rows, cols, A, lda, B, ldb, K,
-                       TriMap{tri_row0, tri_stride, tri_col0});
+    if (big) {
+        constexpr size_t lds = gemm_lds_bytes(4);
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_sub_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return fail(SCASML_ERR_HIP, "gemm_nt_sub: cannot reserve %zu bytes of LDS", lds);
+        hipLaunchKernelGGL(gemm_nt_sub_kernel<4>, dim3((unsigned)gx, (unsigned)gy), dim3(1024), lds, (hipStream_t)stream, C, ldc, rows, cols, A, lda, B, ldb, K, tri);
+    } else {
+        constexpr size_t lds = gemm_lds_bytes(2);
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_sub_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return fail(SCASML_ERR_HIP, "gemm_nt_sub: cannot reserve %zu bytes of LDS", lds);
+        hipLaunchKernelGGL(gemm_nt_sub_kernel<2>, dim3((unsigned)gx, (unsigned)gy), dim3(256), lds, (hipStream_t)stream, C, ldc, rows, cols, A, lda, B, ldb, K, tri);
+    }
     return check_launch("gemm_nt_sub launch");
 }
 
@@ -237,7 +254,10 @@ extern "C" int scasml_trsm_right_lt(const double *L, int64_t ldl, int64_t nb, do
         if (rest > 0) {
             const int64_t gy = (rows + 63) / 64;
             if (gy > 65535) return fail(SCASML_ERR_UNSUPPORTED, "trsm_right_lt: too many rows for one launch");
-            hipLaunchKernelGGL(gemm_nt_sub_kernel, dim3((unsigned)((rest + 63) / 64), (unsigned)gy), dim3(256), 0, s, X + j + kNB, ldx, rows, rest,
+            constexpr size_t lds = gemm_lds_bytes(2);
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_sub_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return fail(SCASML_ERR_HIP, "trsm_right_lt: cannot reserve LDS");
+            hipLaunchKernelGGL(gemm_nt_sub_kernel<2>, dim3((unsigned)((rest + 63) / 64), (unsigned)gy), dim3(256), lds, s, X + j + kNB, ldx, rows, rest,
                                X + j, ldx, L + (j + kNB) * ldl + j, ldl, (int64_t)kNB, TriMap{0, 0, 0});
         }
     }

@@ -78,8 +78,12 @@ template <int NT>
 struct TileAcc {
     f64x4 v[NT][NT];
 };
-template <int NT>
-constexpr size_t tile_lds_bytes() { return (size_t)2 * 2 * (32 * NT) * LDP * sizeof(double); }   // 2 operands x 2 buffers
+// WS = waves per tile side: a workgroup is WS x WS waves (64 WS^2 threads), each owning NT x NT MFMA tiles of 16 x 16, i.e. an
+// output tile of (16 NT WS)^2.  (NT, WS) = (2, 2): 64 x 64, 4 waves, 8 flop per operand byte; (2, 4): 128 x 128, 16 waves --
+// the same registers per wave, half the operand traffic per flop and four waves per SIMD to hide it (139 KB of LDS: one
+// workgroup per CU).  The large trailing updates use (2, 4), everything small (2, 2).
+template <int NT, int WS = 2>
+constexpr size_t tile_lds_bytes() { return (size_t)2 * 2 * (16 * NT * WS) * LDP * sizeof(double); }   // 2 operands x 2 buffers
 
 template <int NT>
 __device__ __forceinline__ void mfma_tile_zero(TileAcc<NT> &t) {
@@ -90,10 +94,10 @@ __device__ __forceinline__ void mfma_tile_zero(TileAcc<NT> &t) {
 }
 
 // t += As (TB x NB) * Bt (TB x NB)^T
-template <int NT>
+template <int NT, int WS = 2>
 __device__ __forceinline__ void mfma_tile_accumulate(const double (*As)[LDP], const double (*Bt)[LDP], TileAcc<NT> &t) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int wr = (wv >> 1) * (16 * NT), wc = (wv & 1) * (16 * NT);   // quadrant origin
+    const int wr = (wv / WS) * (16 * NT), wc = (wv % WS) * (16 * NT);   // this wave's origin inside the tile
     const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
     for (int k0 = 0; k0 < NB; k0 += 4) {
@@ -110,10 +114,10 @@ __device__ __forceinline__ void mfma_tile_accumulate(const double (*As)[LDP], co
 }
 
 // C -= t (rows x cols valid)
-template <int NT>
+template <int NT, int WS = 2>
 __device__ __forceinline__ void mfma_tile_subtract(const TileAcc<NT> &t, double *C, int64_t ldc, int64_t rows, int64_t cols) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int wr = (wv >> 1) * (16 * NT), wc = (wv & 1) * (16 * NT);
+    const int wr = (wv / WS) * (16 * NT), wc = (wv % WS) * (16 * NT);
     const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
     for (int i = 0; i < NT; ++i)
@@ -129,16 +133,16 @@ __device__ __forceinline__ void mfma_tile_subtract(const TileAcc<NT> &t, double 
 // The K loop shared by the Cholesky and triangular-solve updates: `fetch(kk, ra, rb)` loads this thread's elements
 // of the two operand chunks of columns [kk, kk + NB) into registers (element e of a thread is panel entry
 // idx = tid + 256 e, row idx / NB, column idx % NB).
-template <int NT, class Fetch>
+template <int NT, int WS = 2, class Fetch>
 __device__ __forceinline__ void mfma_tile_k_loop(double *smem, int64_t k_begin, int64_t k_end, Fetch fetch, TileAcc<NT> &t) {
-    constexpr int TBX = 32 * NT, PER = TBX * NB / 256;
+    constexpr int TBX = 16 * NT * WS, THREADS = 64 * WS * WS, PER = TBX * NB / THREADS;
     double (*Pa)[TBX][LDP] = reinterpret_cast<double (*)[TBX][LDP]>(smem);
     double (*Pb)[TBX][LDP] = reinterpret_cast<double (*)[TBX][LDP]>(smem + 2 * TBX * LDP);
     double ra[PER], rb[PER];
     auto park = [&](int buf) {
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
-            const int idx = threadIdx.x + e * 256, rr = idx / NB, cc = idx % NB;
+            const int idx = threadIdx.x + e * THREADS, rr = idx / NB, cc = idx % NB;
             Pa[buf][rr][cc] = ra[e];
             Pb[buf][rr][cc] = rb[e];
         }
@@ -150,7 +154,7 @@ __device__ __forceinline__ void mfma_tile_k_loop(double *smem, int64_t k_begin, 
     for (int64_t kk = k_begin; kk < k_end; kk += NB) {
         const bool more = kk + NB < k_end;
         if (more) fetch(kk + NB, ra, rb);
-        mfma_tile_accumulate<NT>(Pa[cur], Pb[cur], t);
+        mfma_tile_accumulate<NT, WS>(Pa[cur], Pb[cur], t);
         if (more) park(cur ^ 1);
         __syncthreads();
         cur ^= 1;
@@ -255,9 +259,9 @@ __global__ __launch_bounds__(256) void gp_gram_mfma_kernel(int d, double a, cons
 // accumulators: C is read and written ONCE per K columns.  The factorisation below uses it twice: inside an outer
 // panel (K = NB, columns of that panel only) and for the rest of the matrix once per outer panel (K = kOuter) --
 // with K = NB everywhere the factorisation moves M^3 / (3 NB) * 16 bytes through HBM (7 TB at M = 35 000).
-template <int NT>
-__global__ __launch_bounds__(256) void chol_update_k_kernel(double *A, int64_t M, int64_t J, int64_t K, int64_t R0, int64_t col_end) {
-    constexpr int TBX = 32 * NT, PER = TBX * NB / 256;
+template <int NT, int WS>
+__global__ __launch_bounds__(64 * WS * WS) void chol_update_k_kernel(double *A, int64_t M, int64_t J, int64_t K, int64_t R0, int64_t col_end) {
+    constexpr int TBX = 16 * NT * WS, THREADS = 64 * WS * WS, PER = TBX * NB / THREADS;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int64_t ti = blockIdx.y, tj = blockIdx.x;
     if (tj > ti) return;
@@ -265,15 +269,15 @@ __global__ __launch_bounds__(256) void chol_update_k_kernel(double *A, int64_t M
     if (r0 >= M || c0 >= col_end) return;
     TileAcc<NT> t;
     mfma_tile_zero(t);
-    mfma_tile_k_loop<NT>(smem, J, J + K, [&](int64_t kk, double (&ra)[PER], double (&rb)[PER]) {
+    mfma_tile_k_loop<NT, WS>(smem, J, J + K, [&](int64_t kk, double (&ra)[PER], double (&rb)[PER]) {
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
-            const int idx = threadIdx.x + e * 256, rr = idx / NB, cc = idx % NB;
+            const int idx = threadIdx.x + e * THREADS, rr = idx / NB, cc = idx % NB;
             ra[e] = r0 + rr < M ? A[(r0 + rr) * M + kk + cc] : 0.0;
             rb[e] = c0 + rr < M ? A[(c0 + rr) * M + kk + cc] : 0.0;
         }
     }, t);
-    mfma_tile_subtract<NT>(t, A + r0 * M + c0, M, M - r0, col_end - c0);
+    mfma_tile_subtract<NT, WS>(t, A + r0 * M + c0, M, M - r0, col_end - c0);
 }
 
 // ---------------------------------------------------------------------------------- TRSM
@@ -315,24 +319,24 @@ __global__ __launch_bounds__(256) void trsm_diag_kernel(const double *L, int64_t
 //   TRANS == 0:  B[r, :] -= L[r, J:J+K] * X[J:J+K, :]          for rows rbase <= r < rend  (rows below the solved ones)
 //   TRANS == 1:  B[r, :] -= L[J:J+K, r]^T * X[J:J+K, :]        for rows rbase <= r < rend  (rows above them)
 // tri != 0: only tiles on or below the block diagonal (c0 < r0 + TB) are updated -- the lower triangle of a symmetric result
-template <int TRANS, int NT>
-__global__ __launch_bounds__(256) void trsm_update_kernel(const double *L, int64_t M, double *B, int64_t nrhs, int64_t J, int64_t K,
+template <int TRANS, int NT, int WS>
+__global__ __launch_bounds__(64 * WS * WS) void trsm_update_kernel(const double *L, int64_t M, double *B, int64_t nrhs, int64_t J, int64_t K,
                                                           int64_t rbase, int64_t rend, int tri) {
-    constexpr int TBX = 32 * NT, PER = TBX * NB / 256;
+    constexpr int TBX = 16 * NT * WS, THREADS = 64 * WS * WS, PER = TBX * NB / THREADS;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int64_t r0 = rbase + (int64_t)blockIdx.y * TBX, c0 = (int64_t)blockIdx.x * TBX;
     if (r0 >= rend || (tri && c0 >= r0 + TBX)) return;   // block-uniform
     TileAcc<NT> t;
     mfma_tile_zero(t);
-    mfma_tile_k_loop<NT>(smem, J, J + K, [&](int64_t kk, double (&rl)[PER], double (&rx)[PER]) {
+    mfma_tile_k_loop<NT, WS>(smem, J, J + K, [&](int64_t kk, double (&rl)[PER], double (&rx)[PER]) {
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
-            const int idx = threadIdx.x + e * 256, rr = idx / NB, cc = idx % NB;
+            const int idx = threadIdx.x + e * THREADS, rr = idx / NB, cc = idx % NB;
             rl[e] = r0 + rr < rend ? (TRANS == 0 ? L[(r0 + rr) * M + kk + cc] : L[(kk + cc) * M + r0 + rr]) : 0.0;
             rx[e] = c0 + rr < nrhs ? B[(kk + cc) * nrhs + c0 + rr] : 0.0;   // Xt[col][k]
         }
     }, t);
-    mfma_tile_subtract<NT>(t, B + r0 * nrhs + c0, nrhs, rend - r0, nrhs - c0);
+    mfma_tile_subtract<NT, WS>(t, B + r0 * nrhs + c0, nrhs, rend - r0, nrhs - c0);
 }
 
 // ---------------------------------------------------------------------------------- Newton system
@@ -469,26 +473,44 @@ static bool reserve_lds(Kern kern, size_t bytes) {
            hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
 }
 
-template <int NT>
-static void launch_chol_update(double *A, int64_t M, int64_t J, int64_t K, int64_t R0, int64_t col_end, hipStream_t s) {
-    constexpr int TBX = 32 * NT;
+// tiles at least this many on both sides: the 128 x 128 tile (one workgroup per CU) still fills the chip
+constexpr int64_t kBigTileRows = 4096;
+
+template <int NT, int WS>
+static void launch_chol_update_ws(double *A, int64_t M, int64_t J, int64_t K, int64_t R0, int64_t col_end, hipStream_t s) {
+    constexpr int TBX = 16 * NT * WS;
     const int64_t nti = (M - R0 + TBX - 1) / TBX, ntj = (col_end - R0 + TBX - 1) / TBX;
     if (nti <= 0 || ntj <= 0) return;
-    auto kern = chol_update_k_kernel<NT>;
-    if (!reserve_lds(kern, tile_lds_bytes<NT>())) return;   // reported by check_launch through hipGetLastError
-    hipLaunchKernelGGL(kern, dim3((unsigned)ntj, (unsigned)nti), dim3(256), tile_lds_bytes<NT>(), s, A, M, J, K, R0, col_end);
+    auto kern = chol_update_k_kernel<NT, WS>;
+    constexpr size_t lds = tile_lds_bytes<NT, WS>();
+    if (!reserve_lds(kern, lds)) return;   // reported by check_launch through hipGetLastError
+    hipLaunchKernelGGL(kern, dim3((unsigned)ntj, (unsigned)nti), dim3(64 * WS * WS), lds, s, A, M, J, K, R0, col_end);
+}
+
+template <int NT>
+static void launch_chol_update(double *A, int64_t M, int64_t J, int64_t K, int64_t R0, int64_t col_end, hipStream_t s) {
+    if (K >= 8 * NB && M - R0 >= kBigTileRows && col_end - R0 >= kBigTileRows) launch_chol_update_ws<NT, 4>(A, M, J, K, R0, col_end, s);
+    else launch_chol_update_ws<NT, 2>(A, M, J, K, R0, col_end, s);
 }
 
 // rows [rbase, rend) x columns [0, ncols) of B
+template <int TRANS, int NT, int WS>
+static void launch_trsm_update_ws(const double *L, int64_t M, double *B, int64_t nrhs, int64_t J, int64_t K, int64_t rbase, int64_t rend,
+                                  int64_t ncols, int tri, hipStream_t s) {
+    constexpr int TBX = 16 * NT * WS;
+    const int64_t ntr = (rend - rbase + TBX - 1) / TBX, ntc = (ncols + TBX - 1) / TBX;
+    if (ntr <= 0 || ntc <= 0) return;
+    auto kern = trsm_update_kernel<TRANS, NT, WS>;
+    constexpr size_t lds = tile_lds_bytes<NT, WS>();
+    if (!reserve_lds(kern, lds)) return;
+    hipLaunchKernelGGL(kern, dim3((unsigned)ntc, (unsigned)ntr), dim3(64 * WS * WS), lds, s, L, M, B, nrhs, J, K, rbase, rend, tri);
+}
+
 template <int TRANS, int NT>
 static void launch_trsm_update(const double *L, int64_t M, double *B, int64_t nrhs, int64_t J, int64_t K, int64_t rbase, int64_t rend,
                                int64_t ncols, int tri, hipStream_t s) {
-    constexpr int TBX = 32 * NT;
-    const int64_t ntr = (rend - rbase + TBX - 1) / TBX, ntc = (ncols + TBX - 1) / TBX;
-    if (ntr <= 0 || ntc <= 0) return;
-    auto kern = trsm_update_kernel<TRANS, NT>;
-    if (!reserve_lds(kern, tile_lds_bytes<NT>())) return;
-    hipLaunchKernelGGL(kern, dim3((unsigned)ntc, (unsigned)ntr), dim3(256), tile_lds_bytes<NT>(), s, L, M, B, nrhs, J, K, rbase, rend, tri);
+    if (K >= 8 * NB && rend - rbase >= kBigTileRows && ncols >= kBigTileRows) launch_trsm_update_ws<TRANS, NT, 4>(L, M, B, nrhs, J, K, rbase, rend, ncols, tri, s);
+    else launch_trsm_update_ws<TRANS, NT, 2>(L, M, B, nrhs, J, K, rbase, rend, ncols, tri, s);
 }
 
 template <int TRANS>
