@@ -105,7 +105,7 @@ const char *scasml_last_error(void);
  * 0 scasml_problem, 1 scasml_rng, 2 scasml_term, 3 scasml_plan, 4 scasml_gp_model. */
 size_t scasml_sizeof(int which);
 
-/* Rows of the point buffer / GP-value buffer per root: sites[n] + 1 (the root itself last). */
+/* Sites of the point buffer / GP-value buffer per root: sites[n] + 1 (the root itself last). */
 int64_t scasml_points_per_root(const scasml_plan *plan_h);
 /* Padded row length (floats) of a point row: round_up(d + 4, 16): X, t, three spare columns the GP
  * evaluation uses for folded constants (d+1, d+2 and the last one), zero pad to a whole 16-bit MFMA K-step. */
@@ -118,17 +118,20 @@ int32_t scasml_point_stride(int32_t d);
  * Philox normals, Euler-Maruyama stepping, the recursive quadrature, f and g
  * (equations/equations.py:248-304), clipping.
  *   x_t      : B x (d+1) evaluation points.
- *   points   : MODE_GENERATE out: points_per_root x B x point_stride, SITE-major (row = site*B + root): the 32
- *              rows a wavefront of scasml_gp_eval takes are one tree site of 32 roots, so per-site work
- *              selection there is wave-uniform.  Row content (X, t, zero pad).
+ *   site_stride : rows between consecutive tree sites in `points` / `gp_vals` (>= B; 0 means B).  A multiple of 32
+ *              makes every 32-row wavefront tile of scasml_gp_eval_sites a single site, which is what lets it pick the
+ *              cheapest epilogue per site (and makes u_hat independent of how a batch is chunked); rows B .. site_stride-1
+ *              of a site are padding that is neither written nor read here.
+ *   points   : MODE_GENERATE out: points_per_root x site_stride x point_stride, SITE-major (row = site*site_stride + root).
+ *              Row content (X, t, zero pad).
  *              MODE_ACCUMULATE in: the same buffer (Euler-Maruyama states are read back, not recomputed).
- *   gp_vals  : MODE_ACCUMULATE in: points_per_root x B x 4 = (u_hat, div_x u_hat, eps_PDE, dt u_hat), same row
- *              order, from scasml_gp_eval on `points`.
+ *   gp_vals  : MODE_ACCUMULATE in: points_per_root x site_stride x 4 = (u_hat, div_x u_hat, eps_PDE, dt u_hat), same row
+ *              order, from scasml_gp_eval_sites on `points`.
  *   out_uz   : B x (1+d): (u, z) clipped [MLP, ACCUMULATE]; un-clipped partial sums if world > 1.
  *   out_uhat : B: u_hat at the root [ACCUMULATE] (ScaSML.py:303), may be NULL.
  */
 int scasml_picard_tree(const scasml_problem *prob_h, const scasml_plan *plan_h, int mode,
-                       const float *x_t, int64_t B, scasml_rng rng,
+                       const float *x_t, int64_t B, int64_t site_stride, scasml_rng rng,
                        float *points, const float *gp_vals,
                        float *out_uz, float *out_uhat, void *stream);
 
@@ -172,8 +175,11 @@ typedef struct {
 
 /* Build `coef` and the padded `colloc` from points and right_vector (models/GP.py:599-600):
  * c0 = rv[u(X)] (domain and boundary rows), cL = rv[Lap], ct = rv[dt], cS = rv[div] (zero on
- * boundary rows).  x_dom: n_dom x (d+1), x_bdy: n_bdy x (d+1), rv: 4*n_dom + n_bdy (float64). */
-int scasml_gp_pack(int32_t d, float a, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy,
+ * boundary rows).  x_dom: n_dom x (d+1), x_bdy: n_bdy x (d+1), rv: 4*n_dom + n_bdy (float64).
+ * T_terminal: the equation's terminal time.  A third of a ScaSML step's evaluation points are terminal samples at exactly
+ * t = T (ScaSML.py:61); for them the time difference to a collocation point is a per-row constant, which the pack folds into
+ * a 4-float form of the constants (site kind 3 of scasml_plan_site_kinds). */
+int scasml_gp_pack(int32_t d, float a, float T_terminal, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy,
                    const double *rv, float *colloc_out, float *colloc_frag_out,
                    uint16_t *colloc_bf16_out /* scasml_gp_plane_halfwords(d, n_pad) */,
                    float *coef_out /* scasml_gp_coef_floats(n_pad) */, void *stream);
@@ -197,14 +203,15 @@ int scasml_gp_eval(const scasml_gp_model *gp_h, const float *points, int64_t n_i
                    float *out4, float *lap, void *stream);
 
 /* Same, for the site-major point buffer of scasml_picard_tree: rows [s*rows_per_site, (s+1)*rows_per_site) are
- * tree site s; site_u_only[s] != 0 (device bytes, from scasml_plan_site_kinds) marks sites where only u_hat is
- * consumed (terminal-time points, ScaSML.py:61; the root, ScaSML.py:303) -- their rows get u_hat only
- * (div, eps, dt = 0), which halves the epilogue work there; site_u_only[s] == 2 marks sites to skip. */
+ * tree site s; site_u_only[s] (device bytes, from scasml_plan_site_kinds): 0 = every output needed; 1 = only u_hat is
+ * consumed (the root, ScaSML.py:303) -- its rows get u_hat only (div, eps, dt = 0), which halves the epilogue work;
+ * 3 = only u_hat AND every row of the site has t = T_terminal of scasml_gp_pack exactly (terminal samples, ScaSML.py:61):
+ * a quarter of the full epilogue, used when rows_per_site is a multiple of 32 (otherwise treated as 1); 2 = skip the site. */
 int scasml_gp_eval_sites(const scasml_gp_model *gp_h, const float *points, int64_t n_inf, int64_t rows_per_site,
                          const uint8_t *site_u_only, float *out4, void *stream);
 
-/* Host helper: fill kinds_h[0 .. points_per_root) with 1 for sites whose GP value is used as u_hat only
- * (terminal samples and the trailing root row), 0 for Euler-Maruyama sites (u_hat, div, eps_PDE needed) and
+/* Host helper: fill kinds_h[0 .. points_per_root) with 3 for terminal samples (u_hat only, at t = T), 1 for the trailing
+ * root row (u_hat only, at the root's own time), 0 for Euler-Maruyama sites (u_hat, div, eps_PDE needed) and
  * 2 for sites of root-call units this rank does not own under Monte-Carlo sample sharding (unit_owner_h[unit] !=
  * rank, or unit % world != rank when unit_owner_h is NULL -- the same rule as scasml_rng): scasml_picard_tree
  * neither writes nor reads those rows and scasml_gp_eval_sites skips workgroups that lie entirely inside them.

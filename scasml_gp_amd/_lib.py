@@ -58,14 +58,14 @@ SIGNATURES = {
     "scasml_sizeof": (C.c_size_t, [C.c_int]),
     "scasml_points_per_root": (C.c_int64, [C.POINTER(Plan)]),
     "scasml_point_stride": (C.c_int32, [C.c_int32]),
-    "scasml_picard_tree": (C.c_int, [C.POINTER(Problem), C.POINTER(Plan), C.c_int, C.c_void_p, C.c_int64, Rng,
+    "scasml_picard_tree": (C.c_int, [C.POINTER(Problem), C.POINTER(Plan), C.c_int, C.c_void_p, C.c_int64, C.c_int64, Rng,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "scasml_clip": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
     "scasml_debug_normals": (C.c_int, [Rng, C.c_uint32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "scasml_debug_transform": (C.c_int, [C.c_uint32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "scasml_gp_plane_halfwords": (C.c_int64, [C.c_int32, C.c_int32]),
     "scasml_gp_coef_floats": (C.c_int64, [C.c_int32]),
-    "scasml_gp_pack": (C.c_int, [C.c_int32, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+    "scasml_gp_pack": (C.c_int, [C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "scasml_gp_eval": (C.c_int, [C.POINTER(GpModel), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "scasml_gp_eval_sites": (C.c_int, [C.POINTER(GpModel), C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void gp_gradient_kernel(const float *points, c
 }
 
 // Build the device model from the training set and right_vector (models/GP.py:593-600).
-__global__ void gp_pack_kernel(int d, float a, const float *x_dom, int n_dom, const float *x_bdy, int n_bdy,
+__global__ void gp_pack_kernel(int d, float a, float T, const float *x_dom, int n_dom, const float *x_bdy, int n_bdy,
                                const double *rv, float *colloc, float *frag, uint16_t *bf, float *coef, int n_pad, int kp) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_pad) return;
@@ -321,7 +321,13 @@ __global__ void gp_pack_kernel(int d, float a, const float *x_dom, int n_dom, co
     c2[9] = -4.0f * a * cL;
     c2[10] = -2.0f * a * k1 * cS;
     c2[11] = 2.0f * a * a * fd * k1 * cL;
-    c2[12] = c2[13] = c2[14] = c2[15] = 0.0f;
+    // terminal-time form (site kind 3): with t_x = T the scaled time difference pT = sqrt(q) a (T - t_y) is a constant of the
+    // row, so E = e0 + eL (Lam + pT^2) + et pT + cS ss = e0T + eL Lam + cS ss and one ds_read_b128 carries the row
+    const float pT = rq * a * (T - ty);
+    c2[12] = a * sy;
+    c2[13] = c2[2] + c2[3] * pT * pT + c2[4] * pT;
+    c2[14] = c2[3];
+    c2[15] = cS;
 }
 
 template <int NK4>
@@ -361,7 +367,7 @@ extern "C" int64_t scasml_gp_plane_halfwords(int32_t d, int32_t n_pad) {
 
 extern "C" int64_t scasml_gp_coef_floats(int32_t n_pad) { return (int64_t)n_pad * 2 * kCoefRow; }
 
-extern "C" int scasml_gp_pack(int32_t d, float a, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy,
+extern "C" int scasml_gp_pack(int32_t d, float a, float T_terminal, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy,
                               const double *rv, float *colloc_out, float *colloc_frag_out, uint16_t *colloc_bf16_out,
                               float *coef_out, void *stream) {
     if (!x_dom || !rv || !colloc_out || !colloc_frag_out || !colloc_bf16_out || !coef_out || (n_bdy > 0 && !x_bdy))
@@ -369,7 +375,7 @@ extern "C" int scasml_gp_pack(int32_t d, float a, const float *x_dom, int32_t n_
     if (d < 1 || d > SCASML_MAX_DIM || n_dom < 1 || n_bdy < 0) return fail(SCASML_ERR_ARG, "gp_pack: bad sizes");
     const int n_pad = (n_dom + n_bdy + 31) / 32 * 32;
     const int kp = scasml_point_stride(d);
-    hipLaunchKernelGGL(gp_pack_kernel, dim3((n_pad + 63) / 64), dim3(64), 0, (hipStream_t)stream, d, a, x_dom, n_dom, x_bdy,
+    hipLaunchKernelGGL(gp_pack_kernel, dim3((n_pad + 63) / 64), dim3(64), 0, (hipStream_t)stream, d, a, T_terminal, x_dom, n_dom, x_bdy,
                        n_bdy, rv, colloc_out, colloc_frag_out, colloc_bf16_out, coef_out, n_pad, kp);
     return check_launch("gp_pack launch");
 }

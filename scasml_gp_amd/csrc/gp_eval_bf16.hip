@@ -268,22 +268,27 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
         const float *b = lds + slot * STAGE;
         return GpStageView{reinterpret_cast<const float4 *>(b), b + NPL * KS * 256};
     };
-    // site-major buffers: all 32 rows of this wave belong to one or two neighbouring tree sites; if only
-    // u_hat is consumed there (terminal-time points, the root) the epilogue drops the dt / div / Lap sums
-    bool uonly = false;
+    // site-major buffers: all 32 rows of this wave belong to one tree site (rows_per_site a multiple of 32: the layout the
+    // solvers use) or to two neighbouring ones.  form 1: only u_hat is consumed there (the root, terminal samples): the
+    // epilogue drops the dt / div / Lap sums; form 2: additionally every row has t = T exactly (terminal samples, site kind
+    // 3), which folds the time terms into the row constants.  Form 2 is taken only for single-site tiles, so that the
+    // arithmetic a point sees never depends on how its batch was cut.
+    int form = 0;
     if (g.site_u_only && g.rows_per_site >= 32) {
         const int64_t last = p0 + 31 < g.n_inf ? p0 + 31 : g.n_inf - 1;
         const int64_t s0 = p0 < g.n_inf ? p0 / g.rows_per_site : 0, s1 = last / g.rows_per_site;
-        uonly = g.site_u_only[s0] == 1 && g.site_u_only[s1] == 1;
+        const int k0 = g.site_u_only[s0], k1s = g.site_u_only[s1];
+        if ((k0 == 1 || k0 == 3) && (k1s == 1 || k1s == 3)) form = (k0 == 3 && s0 == s1 && g.rows_per_site % 32 == 0) ? 2 : 1;
     }
-    uonly = __builtin_amdgcn_readfirstlane((int)uonly) != 0;
+    form = __builtin_amdgcn_readfirstlane(form);
     f32x16 acc;
     uint32_t region;
     asm volatile("s_mov_b32 %0, -1" : "=s"(region));   // see tile(): basic-block boundaries, never false
-    // the whole sweep is instantiated twice (full / u-only epilogue) and the wave-uniform choice is made once,
-    // outside the tile loops: a branch inside them costs registers (the allocator then spills the point tile)
-    auto sweep = [&](auto uo) {
-        constexpr bool UO = decltype(uo)::value;
+    // the whole sweep is instantiated three times (full / u-only / u-only at t = T) and the wave-uniform choice is made
+    // once, outside the tile loops: a branch inside them costs registers (the allocator then spills the point tile)
+    auto sweep = [&](auto fm) {
+        constexpr int FORM = decltype(fm)::value;
+        constexpr bool UO = FORM != 0;
         constexpr int AHEAD = NSLOT == 4 ? 2 : 1;
         auto tile = [&](int jt, auto kind) {
             // (Measured and rejected here, profiles/r02_gp_eval_experiments.txt: s_setprio around either phase -- no effect;
@@ -305,12 +310,13 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
             rendezvous(jt + AHEAD < n_tiles);
         };
         const int nb0 = g.first_bdy_tile < n_tiles ? g.first_bdy_tile : n_tiles;
-        for (int jt = 0; jt < nb0; ++jt) tile(jt, std::integral_constant<int, UO ? 1 : 0>{});
+        for (int jt = 0; jt < nb0; ++jt) tile(jt, std::integral_constant<int, FORM == 2 ? 4 : (UO ? 1 : 0)>{});
         for (int jt = nb0; jt < n_tiles; ++jt) tile(jt, std::integral_constant<int, UO ? 3 : 2>{});   // boundary rows only
     };
     rendezvous(n_tiles > 1);  // tile 0 has landed (tile 1 may still be in flight)
-    if (uonly) sweep(std::true_type{});
-    else sweep(std::false_type{});
+    if (form == 2) sweep(std::integral_constant<int, 2>{});
+    else if (form == 1) sweep(std::integral_constant<int, 1>{});
+    else sweep(std::integral_constant<int, 0>{});
 
     // undo the exponent units (gp_common.hpp): dt = sum / sqrt(q), lap = sum / k1 - a d u
     const float s2 = g.sigma * g.sigma;

@@ -31,6 +31,7 @@ struct TreeArgs {
     float *out_uz;
     float *out_uhat;
     int64_t B;
+    int64_t Bs;   // site stride: row of (site, root) = site * Bs + root (>= B)
     int64_t ppr;  // points per root = plan.sites[n] + 1
     uint32_t k0, k1, stream, root0;
     int32_t rank, world;
@@ -95,12 +96,12 @@ struct Walker {
     // the lane contributes a fixed 32-bit element offset -- a 64-bit VGPR product per access costs three v_mad_u64_u32.
     __device__ __forceinline__ void emit_point(float4 X, float t, uint32_t site) const {
         if (!row_lane) return;                                    // lanes past the padded row
-        float4 *base = reinterpret_cast<float4 *>(a.points + (int64_t)site * a.B * a.kp);
+        float4 *base = reinterpret_cast<float4 *>(a.points + (int64_t)site * a.Bs * a.kp);
         base[row_off4] = fma4(t, tmask, mul4(X, mask));           // (X, t, zero pad)
     }
-    __device__ __forceinline__ float4 gp_at(uint32_t site) const { return (a.gpv + (int64_t)site * a.B)[gp_off]; }
+    __device__ __forceinline__ float4 gp_at(uint32_t site) const { return (a.gpv + (int64_t)site * a.Bs)[gp_off]; }
     __device__ __forceinline__ float4 load_point(uint32_t site) const {   // this lane's four dims of a stored tree point
-        const float4 *base = reinterpret_cast<const float4 *>(a.points + (int64_t)site * a.B * a.kp);
+        const float4 *base = reinterpret_cast<const float4 *>(a.points + (int64_t)site * a.Bs * a.kp);
         return base[row_off4];
     }
     __device__ __forceinline__ bool owned(bool top) {
@@ -424,10 +425,10 @@ extern "C" int64_t scasml_points_per_root(const scasml_plan *plan_h) {
 }
 
 // Site kinds in the kernels' enumeration order (terminal samples first, then per level / path / node the
-// Euler-Maruyama site followed by its child subtrees): 1 = only u_hat of the surrogate is consumed there.
+// Euler-Maruyama site followed by its child subtrees): 3 = terminal sample (only u_hat consumed, at t = T), 1 = only u_hat consumed (the root row).
 static void site_kinds_rec(const scasml_plan *p, int n, uint8_t *&out) {
     if (n == 0) return;
-    for (int m = 0; m < p->mg[n]; ++m) *out++ = 1;
+    for (int m = 0; m < p->mg[n]; ++m) *out++ = 3;   // terminal samples: u_hat only, at t = T
     for (int l = 0; l < n; ++l) {
         const scasml_term &t = p->term[n][l];
         for (int m = 0; m < t.mc; ++m)
@@ -515,10 +516,11 @@ extern "C" int scasml_plan_site_kinds(const scasml_plan *plan_h, int32_t rank, i
 extern "C" int32_t scasml_point_stride(int32_t d) { return (d + 4 + 15) / 16 * 16; }
 
 extern "C" int scasml_picard_tree(const scasml_problem *prob, const scasml_plan *plan, int mode, const float *x_t,
-                                  int64_t B, scasml_rng rng, float *points, const float *gp_vals, float *out_uz,
+                                  int64_t B, int64_t site_stride, scasml_rng rng, float *points, const float *gp_vals, float *out_uz,
                                   float *out_uhat, void *stream) {
     if (!prob || !plan) return fail(SCASML_ERR_ARG, "picard_tree: null argument");
     if (B < 0) return fail(SCASML_ERR_ARG, "picard_tree: negative batch");
+    if (site_stride != 0 && site_stride < B) return fail(SCASML_ERR_ARG, "picard_tree: site_stride %lld is smaller than the batch %lld", (long long)site_stride, (long long)B);
     if (B == 0) return 0;
     if (!x_t) return fail(SCASML_ERR_ARG, "picard_tree: x_t is null");
     if (prob->d < 1 || prob->d > SCASML_MAX_DIM)
@@ -553,6 +555,7 @@ extern "C" int scasml_picard_tree(const scasml_problem *prob, const scasml_plan 
     a.out_uz = out_uz;
     a.out_uhat = out_uhat;
     a.B = B;
+    a.Bs = site_stride ? site_stride : B;
     a.ppr = (int64_t)plan->sites[plan->n] + 1;
     a.k0 = (uint32_t)(rng.seed & 0xFFFFFFFFu);
     a.k1 = (uint32_t)(rng.seed >> 32);

@@ -303,7 +303,7 @@ class GP(object):
         rv = rv.contiguous()
         # collocation points that are exactly fp16 (the reference's deepxde float16 arrays are) need one plane
         self._colloc_is_f16 = bool((self._xd.half().float() == self._xd).all()) and bool((self._xb.half().float() == self._xb).all())
-        _lib.check(lib.scasml_gp_pack(self.d, 1.0 / float(self.sigma) ** 2, _lib.ptr(self._xd), self.N_domain,
+        _lib.check(lib.scasml_gp_pack(self.d, 1.0 / float(self.sigma) ** 2, float(self.T), _lib.ptr(self._xd), self.N_domain,
                                       _lib.ptr(self._xb), self.N_boundary, _lib.ptr(rv), _lib.ptr(self._colloc),
                                       _lib.ptr(self._frag), _lib.ptr(self._bf16), _lib.ptr(self._coef), _lib.stream_ptr()), "gp_pack")
         torch.cuda.current_stream().synchronize()                  # rv may be freed by the caller

@@ -129,13 +129,16 @@ class PicardEngine:
         s = _lib.stream_ptr()
         if self.gp is None:
             _lib.check(self._timed("picard_mlp", lambda: lib.scasml_picard_tree(
-                C.byref(prob), C.byref(plan), _lib.MODE_MLP, _lib.ptr(x), B, rng, None, None, _lib.ptr(out), None, s)), "picard_tree")
+                C.byref(prob), C.byref(plan), _lib.MODE_MLP, _lib.ptr(x), B, 0, rng, None, None, _lib.ptr(out), None, s)), "picard_tree")
             return out, None, was_numpy
         uhat = torch.empty((B,), dtype=torch.float32, device="cuda")
         ppr = int(lib.scasml_points_per_root(C.byref(plan)))
         kp = int(lib.scasml_point_stride(d))
         chunk = max(1, min(B, POINT_BUFFER_BYTES // (ppr * kp * 4)))
-        pts, vals = self._buffers(chunk * ppr, kp)
+        # rows between consecutive tree sites: the chunk rounded up to the 32 rows a wavefront of the GP evaluation takes, so that
+        # every such tile is ONE site (per-site choice of the cheapest epilogue, independent of how the batch is cut)
+        stride = (chunk + 31) // 32 * 32
+        pts, vals = self._buffers(stride * ppr, kp)
         if world > 1:
             pts.zero_()                    # rows of un-owned units are never written
         kinds = self.site_kinds(n, par, rank, world) if n > 0 else None
@@ -146,11 +149,11 @@ class PicardEngine:
             if n > 0:
                 ob, ub = out[b0:b0 + nb], uhat[b0:b0 + nb]
                 _lib.check(self._timed("picard_generate", lambda: lib.scasml_picard_tree(
-                    C.byref(prob), C.byref(plan), _lib.MODE_GENERATE, _lib.ptr(xc), nb, rng_c,
+                    C.byref(prob), C.byref(plan), _lib.MODE_GENERATE, _lib.ptr(xc), nb, stride, rng_c,
                     _lib.ptr(pts), None, None, None, s)), "picard_tree(generate)")
-                self._timed("gp_eval", lambda: self.gp._eval_rows(pts, nb * ppr, nb, kinds, vals, x_bound=self.path_bound()))
+                self._timed("gp_eval", lambda: self.gp._eval_rows(pts, stride * ppr, stride, kinds, vals, x_bound=self.path_bound()))
                 _lib.check(self._timed("picard_accumulate", lambda: lib.scasml_picard_tree(
-                    C.byref(prob), C.byref(plan), _lib.MODE_ACCUMULATE, _lib.ptr(xc), nb, rng_c,
+                    C.byref(prob), C.byref(plan), _lib.MODE_ACCUMULATE, _lib.ptr(xc), nb, stride, rng_c,
                     _lib.ptr(pts), _lib.ptr(vals), _lib.ptr(ob), _lib.ptr(ub), s)), "picard_tree(accumulate)")
             else:                          # n == 0: zeros (ScaSML.py:217-219); u_hat still needed by u_solve
                 out[b0:b0 + nb].zero_()

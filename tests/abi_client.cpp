@@ -56,7 +56,7 @@ int main(int argc, char **argv) {
     float *dx = nullptr, *dout = nullptr;
     if (hipMalloc(&dx, x.size() * sizeof(float)) != hipSuccess || hipMalloc(&dout, x.size() * sizeof(float)) != hipSuccess) return 3;
     hipMemcpy(dx, x.data(), x.size() * sizeof(float), hipMemcpyHostToDevice);
-    const int rc = scasml_picard_tree(&prob, &plan, SCASML_MODE_MLP, dx, B, rng, nullptr, nullptr, dout, nullptr, nullptr);
+    const int rc = scasml_picard_tree(&prob, &plan, SCASML_MODE_MLP, dx, B, 0, rng, nullptr, nullptr, dout, nullptr, nullptr);
     if (rc != 0) {
         fprintf(stderr, "scasml_picard_tree: %d %s\n", rc, scasml_last_error());
         return 4;

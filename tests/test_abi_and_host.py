@@ -40,14 +40,14 @@ def test_struct_layouts_and_version(lib):
 def test_argument_errors_are_codes_not_crashes(lib):
     plan = tables.build_plan("quad", 2, 2, 0.5, True)
     prob = _lib.Problem(300, 0, 0.5, -0.1, 0.25, 1.0)            # d too large
-    rc = lib.scasml_picard_tree(C.byref(prob), C.byref(plan), 0, C.c_void_p(8), 4, _lib.Rng(0, 0, 0, 0, 1, 0, 0),
+    rc = lib.scasml_picard_tree(C.byref(prob), C.byref(plan), 0, C.c_void_p(8), 4, 0, _lib.Rng(0, 0, 0, 0, 1, 0, 0),
                                 None, None, C.c_void_p(8), None, None)
     assert rc == -2 and b"d=300" in lib.scasml_last_error()
     prob.d = 20
-    rc = lib.scasml_picard_tree(C.byref(prob), C.byref(plan), 0, C.c_void_p(8), 4, _lib.Rng(0, 0, 0, 2, 2, 0, 0),
+    rc = lib.scasml_picard_tree(C.byref(prob), C.byref(plan), 0, C.c_void_p(8), 4, 0, _lib.Rng(0, 0, 0, 2, 2, 0, 0),
                                 None, None, C.c_void_p(8), None, None)
     assert rc == -1 and b"rank" in lib.scasml_last_error()
-    assert lib.scasml_picard_tree(C.byref(prob), C.byref(plan), 0, None, 0, _lib.Rng(0, 0, 0, 0, 1, 0, 0), None, None, None, None, None) == 0
+    assert lib.scasml_picard_tree(C.byref(prob), C.byref(plan), 0, None, 0, 0, _lib.Rng(0, 0, 0, 0, 1, 0, 0), None, None, None, None, None) == 0
     assert lib.scasml_points_per_root(C.byref(plan)) == 29
     assert lib.scasml_trsm_lower(C.c_void_p(8), 33, C.c_void_p(8), 1, 0, None) == -2
 
@@ -155,7 +155,8 @@ def test_site_kinds_partition_the_tree_under_sample_sharding(lib, variant, n, pa
     assert (owners[:-1] == 1).all() and owners[-1] == world
     if base is not None:
         tab = approx_parameters(par) if variant == "quad" else None
-        assert ppr == site_count(variant, n, par, tab) + 1 and base[-1] == 1 and set(base) <= {0, 1}
+        assert ppr == site_count(variant, n, par, tab) + 1 and base[-1] == 1 and set(base) <= {0, 1, 3}
+        assert (base == 3).sum() + 1 == (base != 0).sum()          # terminal samples are kind 3, the root row alone is kind 1
     assert lib.scasml_plan_site_kinds(C.byref(plan), world, world, None, np.zeros(ppr, dtype=np.uint8).ctypes.data_as(C.c_void_p)) == -1
 
 

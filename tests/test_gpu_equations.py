@@ -93,6 +93,6 @@ def test_equations_without_kernels_are_refused():
     from scasml_gp_amd import tables
     import ctypes as C
     plan = tables.build_plan("quad", 1, 1, 0.5, True)
-    rc = lib.scasml_picard_tree(C.byref(prob), C.byref(plan), 0, C.c_void_p(8), 4, _lib.Rng(0, 0, 0, 0, 1, 0, 0), None, None, C.c_void_p(8), None, None)
+    rc = lib.scasml_picard_tree(C.byref(prob), C.byref(plan), 0, C.c_void_p(8), 4, 0, _lib.Rng(0, 0, 0, 0, 1, 0, 0), None, None, C.c_void_p(8), None, None)
     assert rc == -2 and b"unknown equation id 7" in lib.scasml_last_error()
     assert issubclass(Grad_Dependent_Nonlinear, Equation)
