@@ -307,6 +307,8 @@ struct Walker {
     }
 };
 
+// (An occupancy hint for ACCUMULATE was measured, profiles/r02_accumulate_prefetch.txt: 5 waves/SIMD 1.22 ms against 1.26, but the
+// deeper levels then spill inside their loops; 6 and 8 are slower.  No hint.)
 template <int VAR, int MODE, int N, int EQ>
 __global__ __launch_bounds__(256) void picard_tree_kernel(const TreeArgs a) {
     const int lane = threadIdx.x & 63;

@@ -214,3 +214,29 @@ def test_header_is_plain_c(tmp_path):
     src.write_text('#include "scasml_hip.h"\nint main(void) { return (int)sizeof(scasml_plan) > 0 ? 0 : 1; }\n')
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(root, "include"),
                     "-c", str(src), "-o", str(tmp_path / "t.o")], check=True)
+
+
+def test_round2_entry_points_validate_their_arguments_without_a_gpu(lib):
+    """Argument errors of the reference-compat, distributed and dealing entry points come back as codes + messages before
+    anything is launched (so this runs on the CPU box)."""
+    p8 = C.c_void_p(8)
+    idx = (C.c_int32 * 5)(1, 1, 2, 3, 4)
+    assert lib.scasml_gp_gram_compat(20, 0.8, p8, 10, p8, 2, idx, 1, p8, None) == -1 and b"repeated" in lib.scasml_last_error()
+    idx = (C.c_int32 * 5)(0, 1, 2, 3, 20)
+    assert lib.scasml_gp_gram_compat(20, 0.8, p8, 10, p8, 2, idx, 1, p8, None) == -1 and b"outside [0, d)" in lib.scasml_last_error()
+    idx = (C.c_int32 * 5)(0, 1, 2, 3, 4)
+    assert lib.scasml_gp_gram_compat(4, 0.8, p8, 10, p8, 2, idx, 1, p8, None) == -1          # d < 5
+    assert lib.scasml_gp_eval_compat(20, 0.8, 0.25, 0.0, 9, p8, 10, 2, 12, p8, idx, 1, p8, 4, 32, p8, None, None) == -2
+    assert b"unknown equation id 9" in lib.scasml_last_error()
+    assert lib.scasml_gp_eval_compat(20, 0.8, 0.25, 0.0, 0, p8, 10, 2, 11, p8, idx, 1, p8, 4, 32, p8, None, None) == -1   # ldc < N
+    assert lib.scasml_gp_eval_compat(20, 0.8, 0.25, 0.0, 0, p8, 10, 2, 12, p8, idx, 1, p8, 0, 32, p8, None, None) == 0    # empty batch
+    assert lib.scasml_gemm_nt_sub(p8, 64, 64, 64, p8, 33, p8, 33, 33, 0, 0, 0, None) == -2 and b"multiple of 32" in lib.scasml_last_error()
+    assert lib.scasml_gemm_nt_sub(p8, 10, 64, 64, p8, 64, p8, 64, 64, 0, 0, 0, None) == -1                                # ldc < cols
+    assert lib.scasml_trsm_right_lt(p8, 256, 250, p8, 256, 10, None) == -2
+    assert lib.scasml_gp_gram_rows(20, 0.8, p8, 10, p8, 2, 40, 8, 42, p8, 42, None) == -1                                  # rows beyond M = 42
+    assert lib.scasml_gemv_sub(p8, 4, 8, 8, p8, p8, 0, None) == -1                                                         # lda < cols
+    assert lib.scasml_gp_newton_b(5, 20, 0.25, 0.0, p8, p8, 10, 2, p8, None) == -2
+    prob = _lib.Problem(10, 0, 0.5, 0.0, 0.25, 1.0)
+    plan = tables.build_plan("quad", 1, 1, 0.5, True)
+    assert lib.scasml_picard_tree(C.byref(prob), C.byref(plan), 0, p8, 4, 3, _lib.Rng(0, 0, 0, 0, 1, 0, 0), None, None, p8, None, None) == -1
+    assert b"site_stride" in lib.scasml_last_error()
