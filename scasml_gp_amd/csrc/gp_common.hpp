@@ -90,13 +90,13 @@ __device__ __forceinline__ void gp_epilogue_tile(const GpStageView &st, const f3
 //   E = c0 + cL L + ct a r_t + cS ss = e0 + eL Lh + et pp + cS ss.
 // Per collocation row `coef2` holds (gp_pack_kernel):
 //   0 a*sum y   1 sqrt(q) a t_y   2 e0 = c0 - a d cL   3 eL = cL / k1  |  4 et = ct / sqrt(q)   5 cS   6 sqrt(q) a ct
-//   7 2 a cL  |  8 a d cS   9 -4 a cL   10 -2 a k1 cS   11 2 a^2 d k1 cL  |  12 a*sum y   13 e0T   14 eL   15 cS
-// (12..15: the terminal-time form, E = e0T + eL Lam + cS ss for points with t = T exactly, e0T = e0 + eL pT^2 + et pT with
-// pT = sqrt(q) a (T - t_y): KIND 4)
+//   7 2 a cL  |  8 a d cS   9 -4 a cL   10 -2 a k1 cS   11 2 a^2 d k1 cL  |  12 unused   13 e0T   14 eL   15 cS
+// (12..15: the terminal-time form, E = e0T + eL Lam + cS (a S_x) for points with t = T exactly,
+// e0T = e0 + eL pT^2 + et pT - cS a S_y with pT = sqrt(q) a (T - t_y): KIND 4)
 // and the sums are  u = sum kappa E,  dt = (1/sqrt(q)) sum kappa (q6 - pp E),  div = sum kappa (-ss E + q7 ss + q8),
 // lap = (1/k1) sum kappa (Lh (E + q9) + q10 ss + q11) - a d u   (the rescalings happen once per point, after the
 // sweep).  17 VALU + 1 exp per (collocation, point) pair.  KIND selects what a wave needs:
-//   0 all four sums;  1 u only (the root: 7 VALU + exp);  4 u only at t = T (terminal samples: 4 VALU + exp, one LDS read);
+//   0 all four sums;  1 u only (the root: 7 VALU + exp);  4 u only at t = T (terminal samples: 3 VALU + exp, one LDS read);
 //   2 / 3 the same on tiles of boundary rows (cL = ct = cS = 0, E = c0): 8 VALU + exp / 1 VALU + exp.
 template <int KIND, bool PF>
 __device__ __forceinline__ void gp_epilogue_scaled(const GpStageView &st, const f32x16 &acc, int half, float sx, float tx,
@@ -132,10 +132,9 @@ __device__ __forceinline__ void gp_epilogue_scaled(const GpStageView &st, const 
         const float vsy = q[cur][0].x, vty = q[cur][0].y, ve0 = q[cur][0].z, veL = q[cur][0].w;
         if constexpr (KIND == 3) {
             au = fmaf(kap, ve0, au);
-        } else if constexpr (KIND == 4) {       // this form's float4 is (a*sum y, e0T, eL, cS)
+        } else if constexpr (KIND == 4) {       // this form's float4 is (-, e0T, eL, cS): E = e0T + eL Lam + cS (a S_x)
             const float e0T = q[cur][0].y, eLT = q[cur][0].z, cST = q[cur][0].w;
-            const float ss = sx - vsy;
-            au = fmaf(kap, fmaf(cST, ss, fmaf(eLT, lam, e0T)), au);
+            au = fmaf(kap, fmaf(cST, sx, fmaf(eLT, lam, e0T)), au);
         } else {
             const float pp = tx - vty;
             const float ss = sx - vsy;

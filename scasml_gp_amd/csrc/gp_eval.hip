@@ -322,10 +322,11 @@ __global__ void gp_pack_kernel(int d, float a, float T, const float *x_dom, int 
     c2[10] = -2.0f * a * k1 * cS;
     c2[11] = 2.0f * a * a * fd * k1 * cL;
     // terminal-time form (site kind 3): with t_x = T the scaled time difference pT = sqrt(q) a (T - t_y) is a constant of the
-    // row, so E = e0 + eL (Lam + pT^2) + et pT + cS ss = e0T + eL Lam + cS ss and one ds_read_b128 carries the row
+    // row, so E = e0 + eL (Lam + pT^2) + et pT + cS (a S_x - a S_y) = e0T + eL Lam + cS (a S_x) with the row's own terms folded
+    // into e0T, and one ds_read_b128 carries the row
     const float pT = rq * a * (T - ty);
-    c2[12] = a * sy;
-    c2[13] = c2[2] + c2[3] * pT * pT + c2[4] * pT;
+    c2[12] = 0.0f;
+    c2[13] = c2[2] + c2[3] * pT * pT + c2[4] * pT - cS * (a * sy);
     c2[14] = c2[3];
     c2[15] = cS;
 }
