@@ -206,12 +206,14 @@ int scasml_gp_eval(const scasml_gp_model *gp_h, const float *points, int64_t n_i
  * tree site s; site_u_only[s] (device bytes, from scasml_plan_site_kinds): 0 = every output needed; 1 = only u_hat is
  * consumed (the root, ScaSML.py:303) -- its rows get u_hat only (div, eps, dt = 0), which halves the epilogue work;
  * 3 = only u_hat AND every row of the site has t = T_terminal of scasml_gp_pack exactly (terminal samples, ScaSML.py:61):
- * a quarter of the full epilogue, used when rows_per_site is a multiple of 32 (otherwise treated as 1); 2 = skip the site. */
+ * a quarter of the full epilogue, used when rows_per_site is a multiple of 32 (otherwise treated as 1); 4 = u_hat and
+ * div_x u_hat are consumed (eps, dt = 0); 2 = skip the site. */
 int scasml_gp_eval_sites(const scasml_gp_model *gp_h, const float *points, int64_t n_inf, int64_t rows_per_site,
                          const uint8_t *site_u_only, float *out4, void *stream);
 
 /* Host helper: fill kinds_h[0 .. points_per_root) with 3 for terminal samples (u_hat only, at t = T), 1 for the trailing
- * root row (u_hat only, at the root's own time), 0 for Euler-Maruyama sites (u_hat, div, eps_PDE needed) and
+ * root row (u_hat only, at the root's own time), 0 for the Euler-Maruyama sites of level-0 terms (u_hat, div, eps_PDE needed),
+ * 4 for those of level l > 0 terms (u_hat and div only: eps_PDE enters the sum in the level-0 term alone, ScaSML.py:274-280) and
  * 2 for sites of root-call units this rank does not own under Monte-Carlo sample sharding (unit_owner_h[unit] !=
  * rank, or unit % world != rank when unit_owner_h is NULL -- the same rule as scasml_rng): scasml_picard_tree
  * neither writes nor reads those rows and scasml_gp_eval_sites skips workgroups that lie entirely inside them.

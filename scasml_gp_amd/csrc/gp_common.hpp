@@ -97,13 +97,14 @@ __device__ __forceinline__ void gp_epilogue_tile(const GpStageView &st, const f3
 // lap = (1/k1) sum kappa (Lh (E + q9) + q10 ss + q11) - a d u   (the rescalings happen once per point, after the
 // sweep).  17 VALU + 1 exp per (collocation, point) pair.  KIND selects what a wave needs:
 //   0 all four sums;  1 u only (the root: 7 VALU + exp);  4 u only at t = T (terminal samples: 3 VALU + exp, one LDS read);
+//   5 u and div only (Euler-Maruyama sites whose eps_PDE is not consumed: 10 VALU + exp);
 //   2 / 3 the same on tiles of boundary rows (cL = ct = cS = 0, E = c0): 8 VALU + exp / 1 VALU + exp.
 template <int KIND, bool PF>
 __device__ __forceinline__ void gp_epilogue_scaled(const GpStageView &st, const f32x16 &acc, int half, float sx, float tx,
                                                    float &au, float &at, float &ad, float &al) {
     // C row = (r&3) + 8*(r>>2) + 4*half: one per-lane base (depends on the half-wave), compile-time row offsets
     const float4 *cb = reinterpret_cast<const float4 *>(__builtin_assume_aligned(st.coef + 4 * kCoefRow * half, 16));
-    constexpr int NQ = KIND == 0 ? 3 : (KIND == 1 ? 2 : 1);       // float4 reads per row
+    constexpr int NQ = (KIND == 0 || KIND == 5) ? 3 : (KIND == 1 ? 2 : 1);       // float4 reads per row
     constexpr int Q0 = KIND == 4 ? 3 : 0;                         // first float4 of the row this form reads
     // PF: rows ping-pong between two register sets (the reads of row r+1 are issued before row r is consumed);
     // one row per scheduling region keeps the VGPR budget flat
@@ -155,6 +156,9 @@ __device__ __forceinline__ void gp_epilogue_scaled(const GpStageView &st, const 
                     at = fmaf(kap, fmaf(-pp, E, act), at);
                     ad = fmaf(kap, fmaf(-ss, E, fmaf(c2, ss, c3)), ad);
                     al = fmaf(kap, fmaf(Lh, E + c4, fmaf(c5, ss, c6)), al);
+                } else if constexpr (KIND == 5) {
+                    const float c2 = q[cur][1].w, c3 = q[cur][2].x;
+                    ad = fmaf(kap, fmaf(-ss, E, fmaf(c2, ss, c3)), ad);   // the same operations as KIND 0: div does not depend on the form
                 }
             }
         }

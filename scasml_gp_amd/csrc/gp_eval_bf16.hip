@@ -133,12 +133,15 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
     extern __shared__ __attribute__((aligned(16))) float lds[];   // NSLOT slots
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int col = lane & 31, half = lane >> 5;
-    const int64_t p0 = ((int64_t)blockIdx.x * WPB + wv) * 32;
+    // (Walking the workgroups ACROSS the sites, so that matrix-bound terminal tiles and vector-bound Euler-Maruyama tiles share a
+    // SIMD at all times, was measured: 7.94 / 7.96 ms against 7.94 / 7.85 in buffer order -- nothing.)
+    const int64_t blk = blockIdx.x;
+    const int64_t p0 = (blk * WPB + wv) * 32;
     const int n_tiles = g.n_pad / 32;
 
     // Monte-Carlo sample sharding: a workgroup whose rows all belong to sites this rank does not own has
     // nothing to do (block-uniform, so the barriers below stay consistent)
-    if (g.site_u_only && g.rows_per_site >= 32 && gp_block_unowned(g, (int64_t)blockIdx.x * WPB * 32, WPB * 32)) return;
+    if (g.site_u_only && g.rows_per_site >= 32 && gp_block_unowned(g, blk * WPB * 32, WPB * 32)) return;
     // stage one collocation tile: NCHUNK 1-KiB chunks (A fragments (plane, step), then the two coefficient KiB).
     // Wave w issues chunks w, w + WPB, ...: CLO of them, one more on the first NCHUNK % WPB waves (an LDS-DMA costs
     // its wave 60-185 issue cycles, MI355X_MICROARCH.md, so no padding copies).  The count is a wave-uniform
@@ -279,6 +282,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
         const int64_t s0 = p0 < g.n_inf ? p0 / g.rows_per_site : 0, s1 = last / g.rows_per_site;
         const int k0 = g.site_u_only[s0], k1s = g.site_u_only[s1];
         if ((k0 == 1 || k0 == 3) && (k1s == 1 || k1s == 3)) form = (k0 == 3 && s0 == s1 && g.rows_per_site % 32 == 0) ? 2 : 1;
+        else if (k0 == 4 && s0 == s1 && g.rows_per_site % 32 == 0) form = 3;   // u_hat and div only
     }
     form = __builtin_amdgcn_readfirstlane(form);
     f32x16 acc;
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
     // once, outside the tile loops: a branch inside them costs registers (the allocator then spills the point tile)
     auto sweep = [&](auto fm) {
         constexpr int FORM = decltype(fm)::value;
-        constexpr bool UO = FORM != 0;
+        constexpr bool UO = FORM == 1 || FORM == 2;
         constexpr int AHEAD = NSLOT == 4 ? 2 : 1;
         auto tile = [&](int jt, auto kind) {
             // (Measured and rejected here, profiles/r02_gp_eval_experiments.txt: s_setprio around either phase -- no effect;
@@ -310,11 +314,12 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
             rendezvous(jt + AHEAD < n_tiles);
         };
         const int nb0 = g.first_bdy_tile < n_tiles ? g.first_bdy_tile : n_tiles;
-        for (int jt = 0; jt < nb0; ++jt) tile(jt, std::integral_constant<int, FORM == 2 ? 4 : (UO ? 1 : 0)>{});
+        for (int jt = 0; jt < nb0; ++jt) tile(jt, std::integral_constant<int, FORM == 3 ? 5 : (FORM == 2 ? 4 : (UO ? 1 : 0))>{});
         for (int jt = nb0; jt < n_tiles; ++jt) tile(jt, std::integral_constant<int, UO ? 3 : 2>{});   // boundary rows only
     };
     rendezvous(n_tiles > 1);  // tile 0 has landed (tile 1 may still be in flight)
-    if (form == 2) sweep(std::integral_constant<int, 2>{});
+    if (form == 3) sweep(std::integral_constant<int, 3>{});
+    else if (form == 2) sweep(std::integral_constant<int, 2>{});
     else if (form == 1) sweep(std::integral_constant<int, 1>{});
     else sweep(std::integral_constant<int, 0>{});
 

@@ -176,10 +176,12 @@ struct Walker {
                     dplus = rcp_fast(fmaf(tau, tm.dplus[k], 1e-6f));   // MLP.py:249 (stale) / ScaSML.py:253
                     dminus = rcp_fast(fmaf(tau, tm.cfrac[k], 1e-6f));  // MLP.py:270
                 } else {                                         // MLP_full_history.py:133-145
-                    // compat_crn: the level-0 draws ARE the terminal draws (MLP_full_history.py:92-93,99,138: one subkey)
-                    const float4 xi = normals(a.crn && L == 0 ? base + (uint32_t)m : site);
                     const float D = uniform_tau(site, root, a.stream, a.k0, a.k1) * tau;
                     const float sD = sqrt_fast(D);
+                    // compat_crn: the level-0 draws ARE the terminal draws (MLP_full_history.py:92-93,99,138: one subkey).
+                    // (ACCUMULATE replays these normals: reading the stored X back instead, as the terminal samples do, was
+                    // measured slower -- 5.9 against 5.4 ms at n = 4, M = 3 -- the pass is bound by its reads, not its RNG.)
+                    const float4 xi = normals(a.crn && L == 0 ? base + (uint32_t)m : site);
                     X = fma4(a.sigma * sD, xi, add4(x, a.mu * D));
                     tk = t + D;
                     wk = tau;
@@ -427,7 +429,8 @@ extern "C" int64_t scasml_points_per_root(const scasml_plan *plan_h) {
 }
 
 // Site kinds in the kernels' enumeration order (terminal samples first, then per level / path / node the
-// Euler-Maruyama site followed by its child subtrees): 3 = terminal sample (only u_hat consumed, at t = T), 1 = only u_hat consumed (the root row).
+// Euler-Maruyama site followed by its child subtrees): 3 = terminal sample (only u_hat consumed, at t = T), 1 = only u_hat consumed (the root row),
+// 4 = Euler-Maruyama site of a level l > 0 term (u_hat and div u_hat consumed, eps_PDE not), 0 = everything consumed.
 static void site_kinds_rec(const scasml_plan *p, int n, uint8_t *&out) {
     if (n == 0) return;
     for (int m = 0; m < p->mg[n]; ++m) *out++ = 3;   // terminal samples: u_hat only, at t = T
@@ -435,7 +438,7 @@ static void site_kinds_rec(const scasml_plan *p, int n, uint8_t *&out) {
         const scasml_term &t = p->term[n][l];
         for (int m = 0; m < t.mc; ++m)
             for (int k = 0; k < t.q; ++k) {
-                *out++ = 0;
+                *out++ = l > 0 ? 4 : 0;   // eps_PDE enters the sum only in the level-0 term (ScaSML.py:274-280)
                 site_kinds_rec(p, l, out);
                 if (l > 0) site_kinds_rec(p, l - 1, out);
             }

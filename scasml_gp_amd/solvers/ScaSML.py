@@ -46,10 +46,12 @@ class ScaSML:
 
     def uz_solve(self, n, rho, x_t):
         '''solvers/ScaSML.py:149-284.'''
+        self.Mf, self.Mg, self.Q, self.c, self.w = self.approx_parameters(rho)       # :161
         uz, _, was_numpy = self._solve(n, rho, x_t)
         return deliver(uz, was_numpy)
 
     def u_solve(self, n, rho, x_t):
         '''u_hat + u_breve, solvers/ScaSML.py:286-304.'''
+        self.Mf, self.Mg, self.Q, self.c, self.w = self.approx_parameters(rho)
         uz, uhat, was_numpy = self._solve(n, rho, x_t)
         return deliver(uz[:, 0:1] + uhat[:, None], was_numpy)

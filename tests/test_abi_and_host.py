@@ -155,8 +155,10 @@ def test_site_kinds_partition_the_tree_under_sample_sharding(lib, variant, n, pa
     assert (owners[:-1] == 1).all() and owners[-1] == world
     if base is not None:
         tab = approx_parameters(par) if variant == "quad" else None
-        assert ppr == site_count(variant, n, par, tab) + 1 and base[-1] == 1 and set(base) <= {0, 1, 3}
-        assert (base == 3).sum() + 1 == (base != 0).sum()          # terminal samples are kind 3, the root row alone is kind 1
+        assert ppr == site_count(variant, n, par, tab) + 1 and base[-1] == 1 and set(base) <= {0, 1, 3, 4}
+        assert (base == 1).sum() == 1                              # the root row alone is kind 1; terminal samples are kind 3
+        if variant == "quad" and n == 3 and par == 3:              # 234 terminal jumps executed, 431 Euler-Maruyama steps
+            assert (base == 3).sum() == 234 and (base == 0).sum() == 380 and (base == 4).sum() == 51
     assert lib.scasml_plan_site_kinds(C.byref(plan), world, world, None, np.zeros(ppr, dtype=np.uint8).ctypes.data_as(C.c_void_p)) == -1
 
 
