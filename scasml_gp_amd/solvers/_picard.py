@@ -138,9 +138,8 @@ class PicardEngine:
         # rows between consecutive tree sites: the chunk rounded up to the 32 rows a wavefront of the GP evaluation takes, so that
         # every such tile is ONE site (per-site choice of the cheapest epilogue, independent of how the batch is cut)
         stride = (chunk + 31) // 32 * 32
-        pts, vals = self._buffers(stride * ppr, kp)
-        if world > 1:
-            pts.zero_()                    # rows of un-owned units are never written
+        pts, vals = self._buffers(stride * ppr, kp)   # rows of un-owned units and padding rows are never written: their (finite,
+        # stale) content is evaluated or skipped by the GP kernel and never read back by ACCUMULATE
         kinds = self.site_kinds(n, par, rank, world) if n > 0 else None
         for b0 in range(0, B, chunk):
             nb = min(chunk, B - b0)
@@ -167,8 +166,8 @@ class PicardEngine:
         have = self._work.get("pts")
         if have is None or have.shape[0] < rows or have.shape[1] != kp:
             self._work.clear()
-            self._work["pts"] = torch.empty((rows, kp), dtype=torch.float32, device="cuda")
-            self._work["vals"] = torch.empty((rows, 4), dtype=torch.float32, device="cuda")
+            self._work["pts"] = torch.zeros((rows, kp), dtype=torch.float32, device="cuda")    # zeroed once: rows nobody writes stay finite
+            self._work["vals"] = torch.zeros((rows, 4), dtype=torch.float32, device="cuda")
         return self._work["pts"][:rows], self._work["vals"][:rows]
 
     def finalize_partials(self, summed):
