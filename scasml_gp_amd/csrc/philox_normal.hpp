@@ -118,10 +118,19 @@ __device__ __forceinline__ void box_muller(uint32_t ra, uint32_t rb, float &n0, 
 // four N(0,1) values: dims 4*quad .. 4*quad+3 of path-step `site` of root `root`
 __device__ __forceinline__ float4 normal4(uint32_t quad, uint32_t site, uint32_t root, uint32_t stream,
                                           uint32_t k0, uint32_t k1) {
+#if defined(SCASML_ABLATION) && SCASML_ABL_RNG == 1   // development: cost of Philox (a two-multiply mixer instead)
+    const uint32_t h = (quad * 0x9E3779B9u) ^ (site * 0x85EBCA6Bu) ^ root ^ stream ^ k0 ^ k1;
+    const u32x4 r = {h, h * 0xC2B2AE35u, h ^ 0x27D4EB2Fu, h + 0x165667B1u};
+#else
     const u32x4 r = philox4x32_10(quad, site, root, stream, k0, k1);
+#endif
     float4 n;
+#if defined(SCASML_ABLATION) && SCASML_ABL_RNG == 2   // development: cost of the normal transform (a scale instead)
+    n.x = (float)(int)r.x * 0x1p-31f; n.y = (float)(int)r.y * 0x1p-31f; n.z = (float)(int)r.z * 0x1p-31f; n.w = (float)(int)r.w * 0x1p-31f;
+#else
     box_muller(r.x, r.y, n.x, n.y);
     box_muller(r.z, r.w, n.z, n.w);
+#endif
     return n;
 }
 
