@@ -101,13 +101,23 @@ __global__ __launch_bounds__(64 * WS * WS) void gemm_nt_sub_kernel(double *C, in
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    const bool interior = r0 + TBX <= rows && c0 + TBX <= cols;   // block-uniform: no bounds tests, loads issued back to back
     double ra[PER], rb[PER];
     auto fetch = [&](int64_t kk) {
+        if (interior) {
 #pragma unroll
-        for (int e = 0; e < PER; ++e) {
-            const int idx = threadIdx.x + e * THREADS, rr = idx / kNB, cc = idx % kNB;
-            ra[e] = r0 + rr < rows ? A[(r0 + rr) * lda + kk + cc] : 0.0;
-            rb[e] = c0 + rr < cols ? B[(c0 + rr) * ldb + kk + cc] : 0.0;
+            for (int e = 0; e < PER; ++e) {
+                const int idx = threadIdx.x + e * THREADS, rr = idx / kNB, cc = idx % kNB;
+                ra[e] = A[(r0 + rr) * lda + kk + cc];
+                rb[e] = B[(c0 + rr) * ldb + kk + cc];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < PER; ++e) {
+                const int idx = threadIdx.x + e * THREADS, rr = idx / kNB, cc = idx % kNB;
+                ra[e] = r0 + rr < rows ? A[(r0 + rr) * lda + kk + cc] : 0.0;
+                rb[e] = c0 + rr < cols ? B[(c0 + rr) * ldb + kk + cc] : 0.0;
+            }
         }
     };
     auto park = [&](int buf) {
@@ -118,13 +128,7 @@ __global__ __launch_bounds__(64 * WS * WS) void gemm_nt_sub_kernel(double *C, in
             Pb[buf][rr][cc] = rb[e];
         }
     };
-    fetch(0);
-    park(0);
-    __syncthreads();
-    int cur = 0;
-    for (int64_t kk = 0; kk < K; kk += kNB) {
-        const bool more = kk + kNB < K;
-        if (more) fetch(kk + kNB);
+    auto accumulate = [&](int cur) {
 #pragma unroll
         for (int k0 = 0; k0 < kNB; k0 += 4) {
             double av[2], bv[2];
@@ -137,9 +141,39 @@ __global__ __launch_bounds__(64 * WS * WS) void gemm_nt_sub_kernel(double *C, in
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
-        if (more) park(cur ^ 1);
+    };
+    fetch(0);
+    park(0);
+    __syncthreads();
+    int cur = 0;
+    for (int64_t kk = 0; kk + kNB < K; kk += kNB) {
+        fetch(kk + kNB);
+        accumulate(cur);
+        park(cur ^ 1);
         __syncthreads();
         cur ^= 1;
+    }
+    // the output tile's loads fly under the last chunk's matrix work (gp_train.hip, mfma_tile_load_full: the guarded
+    // read-modify-write tail cost a quarter of the factorisation)
+    double *Ct = C + (r0 + wr + l4) * ldc + c0 + wc + l15;
+    f64x4 cin[2][2];
+    if (interior) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cin[i][j][e] = Ct[(int64_t)(16 * i + 4 * e) * ldc + 16 * j];
+    }
+    accumulate(cur);
+    if (interior) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Ct[(int64_t)(16 * i + 4 * e) * ldc + 16 * j] = cin[i][j][e] - acc[i][j][e];
+        return;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
