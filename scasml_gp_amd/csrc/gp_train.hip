@@ -529,6 +529,8 @@ static bool reserve_lds(Kern kern, size_t bytes) {
 
 // tiles at least this many on both sides: the 128 x 128 tile (one workgroup per CU) still fills the chip
 constexpr int64_t kBigTileRows = 4096;
+// matrices at least this large factor with a one-panel lookahead on a second stream (scasml_cholesky)
+constexpr int64_t kLookaheadRows = 8192;
 
 template <int NT, int WS>
 static void launch_chol_update_ws(double *A, int64_t M, int64_t J, int64_t K, int64_t R0, int64_t col_end, hipStream_t s) {
@@ -583,19 +585,62 @@ extern "C" int scasml_cholesky(double *A, int64_t M, double nugget, int32_t *inf
     // two-level right-looking factorisation: columns are eliminated NB at a time inside an outer panel of kOuter
     // columns (updates confined to that panel's columns), then the whole trailing matrix is updated once with K = kOuter
     constexpr int64_t kOuter = kOuterRows;
-    auto update = [&](int64_t J, int64_t K, int64_t R0, int64_t col_end) {
-        launch_chol_update<2>(A, M, J, K, R0, col_end, s);
-    };
-    for (int64_t J = 0; J < M; J += kOuter) {
-        const int64_t jend = J + kOuter < M ? J + kOuter : M;
+    auto factor_panel = [&](int64_t J, int64_t jend, hipStream_t q) {   // columns [J, jend) final, all rows
         for (int64_t k0 = J; k0 < jend; k0 += NB) {
-            hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(NB, NB), 0, s, A, M, k0, info_dev);
+            hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(NB, NB), 0, q, A, M, k0, info_dev);
             const int64_t rest = M - k0 - NB;
             if (rest <= 0) break;
-            hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)((rest + 255) / 256)), dim3(256), 0, s, A, M, k0);
-            if (k0 + NB < jend) update(k0, NB, k0 + NB, jend);
+            hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)((rest + 255) / 256)), dim3(256), 0, q, A, M, k0);
+            if (k0 + NB < jend) launch_chol_update<2>(A, M, k0, NB, k0 + NB, jend, q);
         }
-        if (jend < M) update(J, jend - J, jend, M);
+    };
+    if (M < kLookaheadRows) {
+        for (int64_t J = 0; J < M; J += kOuter) {
+            const int64_t jend = J + kOuter < M ? J + kOuter : M;
+            factor_panel(J, jend, s);
+            if (jend < M) launch_chol_update<2>(A, M, J, jend - J, jend, M, s);
+        }
+    } else {
+        // Lookahead: a panel is a chain of 3 x 8 small dependent kernels (0.37 ms at M = 35 000, 50 ms over the factorisation, during
+        // which the chip idles).  The chain of panel p+1 needs only that panel's columns updated, so it runs on a second stream of
+        // this call's own while `s` applies panel p to the rest of the trailing matrix:
+        //   h:  factor(p) . [wait: s done with panel p-1] . update columns of panel p+1 with panel p . factor(p+1) ...
+        //   s:  [wait: factor(p)] . update everything right of panel p+1 with panel p . [wait: factor(p+1)] ...
+        // The two updates of a panel touch disjoint columns; the update on h waits for s because both subtract from panel p+1's
+        // columns.  The stream and the two events live for this call only (no state survives it; re-entrant as before).
+        hipStream_t h = nullptr;
+        hipEvent_t factored = nullptr, applied = nullptr;
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);   // (least, greatest): the short kernels of the chain go first
+        if (hipStreamCreateWithPriority(&h, hipStreamNonBlocking, hi) != hipSuccess ||
+            hipEventCreateWithFlags(&factored, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&applied, hipEventDisableTiming) != hipSuccess) {
+            if (factored) hipEventDestroy(factored);
+            if (h) hipStreamDestroy(h);
+            return fail(SCASML_ERR_HIP, "cholesky: cannot create the lookahead stream");
+        }
+        hipEventRecord(applied, s);   // everything the caller queued before this call
+        hipStreamWaitEvent(h, applied, 0);
+        for (int64_t J = 0; J < M; J += kOuter) {
+            const int64_t jend = J + kOuter < M ? J + kOuter : M;
+            const int64_t next_end = jend + kOuter < M ? jend + kOuter : M;
+            factor_panel(J, jend, h);
+            hipEventRecord(factored, h);
+            if (jend < M) {
+                hipStreamWaitEvent(h, applied, 0);                                  // panel J-1 applied to panel J+1's columns
+                launch_chol_update<2>(A, M, J, jend - J, jend, next_end, h);        // panel J -> columns of panel J+1 (rows >= jend)
+                if (next_end < M) {
+                    hipStreamWaitEvent(s, factored, 0);
+                    launch_chol_update<2>(A, M, J, jend - J, next_end, M, s);       // panel J -> everything right of panel J+1
+                    hipEventRecord(applied, s);
+                }
+            }
+        }
+        hipEventRecord(factored, h);
+        hipStreamWaitEvent(s, factored, 0);
+        hipEventDestroy(factored);   // released when the recorded work completes
+        hipEventDestroy(applied);
+        hipStreamDestroy(h);
     }
     hipLaunchKernelGGL(zero_upper_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)M), dim3(256), 0, s, A, M);
     return check_launch("cholesky launch");

@@ -60,6 +60,31 @@ def test_cholesky_and_trsm_against_numpy():
     assert rc == -2 and b"multiple of 32" in lib.scasml_last_error()
 
 
+
+def test_cholesky_lookahead_path_on_a_side_stream():
+    """M >= 8192 factors with the one-panel lookahead on the call's own second stream (csrc/gp_train.hip, scasml_cholesky):
+    same factor as LAPACK-on-GPU to rounding, for a size that is ragged against the 64/128/256 tilings, launched on a
+    non-default stream with work queued before and after it."""
+    import torch
+    from scasml_gp_amd import _lib
+    lib = _lib.load()
+    M = 8192 + 9 * 32
+    g = torch.Generator(device="cuda").manual_seed(5)
+    R = torch.randn((M, 640), dtype=torch.float64, device="cuda", generator=g)
+    A = R @ R.T + 40.0 * torch.eye(M, dtype=torch.float64, device="cuda")
+    want = torch.linalg.cholesky(A)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        L = A.clone()                                     # queued before the call on the same stream
+        _lib.check(lib.scasml_cholesky(_lib.ptr(L), M, 0.0, _lib.ptr(info), side.cuda_stream), "chol")
+        err = (L - want).abs().max()                      # queued after it: must see the finished factor
+    side.synchronize()
+    assert int(info.item()) == 0
+    assert float(err) < 1e-10 * float(want.abs().max()) * 40
+    assert float(torch.triu(L, 1).abs().max()) == 0.0
+
 @pytest.mark.parametrize("d,nd,nb", [(4, 30, 10), (20, 120, 40)])
 def test_training_matches_oracle(d, nd, nb):
     gp, ora, dom, bdy = _setup(d, nd, nb, seed=2)
