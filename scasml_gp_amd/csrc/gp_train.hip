@@ -575,6 +575,55 @@ static void trsm_update(const double *L, int64_t M, double *B, int64_t nrhs, int
     launch_trsm_update<TRANS, 2>(L, M, B, nrhs, J, K, rbase, rend, ncols, tri, s);
 }
 
+// One-panel lookahead for the blocked factorisation and substitutions below.  A panel (kOuterRows columns or rows) is a chain of
+// 2-3 x 8 short dependent kernels (0.37 ms in scasml_cholesky at M = 35 000: 50 ms over the factorisation with the chip idle).
+// The chain of panel p+1 needs only that panel's own block updated, so it runs on a second stream while the caller's stream applies
+// panel p to everything beyond panel p+1:
+//   side:  chain(p) . [factored] . wait(applied p-1) . apply p to the block of panel p+1 . chain(p+1) ...
+//   main:  wait(factored p) . apply p to everything beyond panel p+1 . [applied p] ...
+// The two applications of a panel write disjoint blocks; the one on the side stream waits for the main stream because both
+// subtract from panel p+1's block.  The stream and the two events live for one call (nothing survives it; re-entrant as before).
+struct Lookahead {
+    hipStream_t main = nullptr, side = nullptr;
+    hipEvent_t factored = nullptr, applied = nullptr;
+    bool open(hipStream_t s) {
+        main = s;
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);   // (least, greatest): the short kernels of the chain go first
+        if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, hi) != hipSuccess ||
+            hipEventCreateWithFlags(&factored, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&applied, hipEventDisableTiming) != hipSuccess) {
+            close_handles();
+            return false;
+        }
+        hipEventRecord(applied, main);   // everything queued on the caller's stream so far
+        hipStreamWaitEvent(side, applied, 0);
+        return true;
+    }
+    void chain_done() { hipEventRecord(factored, side); }
+    void side_waits_for_main() { hipStreamWaitEvent(side, applied, 0); }
+    void main_waits_for_chain() { hipStreamWaitEvent(main, factored, 0); }
+    void main_applied() { hipEventRecord(applied, main); }
+    void join() {   // both streams' work before anything later on the caller's stream; also lets the side stream see it
+        hipEventRecord(factored, side);
+        hipStreamWaitEvent(main, factored, 0);
+        hipEventRecord(applied, main);
+        hipStreamWaitEvent(side, applied, 0);
+    }
+    void close() {
+        hipEventRecord(factored, side);
+        hipStreamWaitEvent(main, factored, 0);
+        close_handles();   // released when the recorded work completes
+    }
+    void close_handles() {
+        if (factored) hipEventDestroy(factored);
+        if (applied) hipEventDestroy(applied);
+        if (side) hipStreamDestroy(side);
+        factored = applied = nullptr;
+        side = nullptr;
+    }
+};
+
 extern "C" int scasml_cholesky(double *A, int64_t M, double nugget, int32_t *info_dev, void *stream) {
     if (!A || !info_dev || M < 1) return fail(SCASML_ERR_ARG, "cholesky: bad argument");
     if (M % NB) return fail(SCASML_ERR_UNSUPPORTED, "cholesky: M=%lld is not a multiple of %d (pad with an identity block)", (long long)M, NB);
@@ -601,46 +650,24 @@ extern "C" int scasml_cholesky(double *A, int64_t M, double nugget, int32_t *inf
             if (jend < M) launch_chol_update<2>(A, M, J, jend - J, jend, M, s);
         }
     } else {
-        // Lookahead: a panel is a chain of 3 x 8 small dependent kernels (0.37 ms at M = 35 000, 50 ms over the factorisation, during
-        // which the chip idles).  The chain of panel p+1 needs only that panel's columns updated, so it runs on a second stream of
-        // this call's own while `s` applies panel p to the rest of the trailing matrix:
-        //   h:  factor(p) . [wait: s done with panel p-1] . update columns of panel p+1 with panel p . factor(p+1) ...
-        //   s:  [wait: factor(p)] . update everything right of panel p+1 with panel p . [wait: factor(p+1)] ...
-        // The two updates of a panel touch disjoint columns; the update on h waits for s because both subtract from panel p+1's
-        // columns.  The stream and the two events live for this call only (no state survives it; re-entrant as before).
-        hipStream_t h = nullptr;
-        hipEvent_t factored = nullptr, applied = nullptr;
-        int lo = 0, hi = 0;
-        hipDeviceGetStreamPriorityRange(&lo, &hi);   // (least, greatest): the short kernels of the chain go first
-        if (hipStreamCreateWithPriority(&h, hipStreamNonBlocking, hi) != hipSuccess ||
-            hipEventCreateWithFlags(&factored, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&applied, hipEventDisableTiming) != hipSuccess) {
-            if (factored) hipEventDestroy(factored);
-            if (h) hipStreamDestroy(h);
-            return fail(SCASML_ERR_HIP, "cholesky: cannot create the lookahead stream");
-        }
-        hipEventRecord(applied, s);   // everything the caller queued before this call
-        hipStreamWaitEvent(h, applied, 0);
+        Lookahead la;
+        if (!la.open(s)) return fail(SCASML_ERR_HIP, "cholesky: cannot create the lookahead stream");
         for (int64_t J = 0; J < M; J += kOuter) {
             const int64_t jend = J + kOuter < M ? J + kOuter : M;
             const int64_t next_end = jend + kOuter < M ? jend + kOuter : M;
-            factor_panel(J, jend, h);
-            hipEventRecord(factored, h);
+            factor_panel(J, jend, la.side);
+            la.chain_done();
             if (jend < M) {
-                hipStreamWaitEvent(h, applied, 0);                                  // panel J-1 applied to panel J+1's columns
-                launch_chol_update<2>(A, M, J, jend - J, jend, next_end, h);        // panel J -> columns of panel J+1 (rows >= jend)
+                la.side_waits_for_main();                                            // panel J-1 applied to panel J+1's columns
+                launch_chol_update<2>(A, M, J, jend - J, jend, next_end, la.side);   // panel J -> columns of panel J+1 (rows >= jend)
                 if (next_end < M) {
-                    hipStreamWaitEvent(s, factored, 0);
-                    launch_chol_update<2>(A, M, J, jend - J, next_end, M, s);       // panel J -> everything right of panel J+1
-                    hipEventRecord(applied, s);
+                    la.main_waits_for_chain();
+                    launch_chol_update<2>(A, M, J, jend - J, next_end, M, s);        // panel J -> everything right of panel J+1
+                    la.main_applied();
                 }
             }
         }
-        hipEventRecord(factored, h);
-        hipStreamWaitEvent(s, factored, 0);
-        hipEventDestroy(factored);   // released when the recorded work completes
-        hipEventDestroy(applied);
-        hipStreamDestroy(h);
+        la.close();
     }
     hipLaunchKernelGGL(zero_upper_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)M), dim3(256), 0, s, A, M);
     return check_launch("cholesky launch");
@@ -739,27 +766,70 @@ extern "C" int scasml_cholesky_inverse(const double *L, int64_t M, double *A, vo
     hipStream_t s = (hipStream_t)stream;
     auto tiles = [](int64_t n) { return (unsigned)((n + TB - 1) / TB); };
     hipLaunchKernelGGL(set_identity_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)M), dim3(256), 0, s, A, M);
-    for (int64_t J = 0; J < M; J += kOuterRows) {            // X = L^-1: row r is nonzero in columns <= r
-        const int64_t jend = J + kOuterRows < M ? J + kOuterRows : M;
+    auto forward_chain = [&](int64_t J, int64_t jend, hipStream_t q) {    // rows [J, jend) of X = L^-1 final
         for (int64_t k0 = J; k0 < jend; k0 += NB) {
             const int64_t lim = k0 + NB;
-            hipLaunchKernelGGL(trsm_diag_kernel<0>, dim3((unsigned)((lim + 255) / 256)), dim3(256), 0, s, L, M, A, M, k0, lim);
+            hipLaunchKernelGGL(trsm_diag_kernel<0>, dim3((unsigned)((lim + 255) / 256)), dim3(256), 0, q, L, M, A, M, k0, lim);
             if (k0 + NB < jend)
-                trsm_update<0>(L, M, A, M, k0, NB, k0 + NB, jend, lim, 0, s);
+                trsm_update<0>(L, M, A, M, k0, NB, k0 + NB, jend, lim, 0, q);
         }
-        if (jend < M)
-            trsm_update<0>(L, M, A, M, J, jend - J, jend, M, jend, 0, s);
-    }
-    for (int64_t jend = M; jend > 0; jend -= kOuterRows) {   // Z = L^-T X, lower triangle only
-        const int64_t J = jend > kOuterRows ? jend - kOuterRows : 0;
+    };
+    auto backward_chain = [&](int64_t J, int64_t jend, hipStream_t q) {   // rows [J, jend) of Z = L^-T X final
         for (int64_t k0 = jend - NB; k0 >= J; k0 -= NB) {
             const int64_t lim = k0 + NB;
-            hipLaunchKernelGGL(trsm_diag_kernel<1>, dim3((unsigned)((lim + 255) / 256)), dim3(256), 0, s, L, M, A, M, k0, lim);
+            hipLaunchKernelGGL(trsm_diag_kernel<1>, dim3((unsigned)((lim + 255) / 256)), dim3(256), 0, q, L, M, A, M, k0, lim);
             if (k0 > J)
-                trsm_update<1>(L, M, A, M, k0, NB, J, k0, k0, 1, s);
+                trsm_update<1>(L, M, A, M, k0, NB, J, k0, k0, 1, q);
         }
-        if (J > 0)
-            trsm_update<1>(L, M, A, M, J, jend - J, 0, J, J, 1, s);
+    };
+    if (M < kLookaheadRows) {
+        for (int64_t J = 0; J < M; J += kOuterRows) {            // X = L^-1: row r is nonzero in columns <= r
+            const int64_t jend = J + kOuterRows < M ? J + kOuterRows : M;
+            forward_chain(J, jend, s);
+            if (jend < M)
+                trsm_update<0>(L, M, A, M, J, jend - J, jend, M, jend, 0, s);
+        }
+        for (int64_t jend = M; jend > 0; jend -= kOuterRows) {   // Z = L^-T X, lower triangle only
+            const int64_t J = jend > kOuterRows ? jend - kOuterRows : 0;
+            backward_chain(J, jend, s);
+            if (J > 0)
+                trsm_update<1>(L, M, A, M, J, jend - J, 0, J, J, 1, s);
+        }
+    } else {   // the same with the chains on the lookahead stream (struct Lookahead): groups of rows instead of panels of columns
+        Lookahead la;
+        if (!la.open(s)) return fail(SCASML_ERR_HIP, "cholesky_inverse: cannot create the lookahead stream");
+        for (int64_t J = 0; J < M; J += kOuterRows) {
+            const int64_t jend = J + kOuterRows < M ? J + kOuterRows : M;
+            const int64_t next_end = jend + kOuterRows < M ? jend + kOuterRows : M;
+            forward_chain(J, jend, la.side);
+            la.chain_done();
+            if (jend < M) {
+                la.side_waits_for_main();
+                trsm_update<0>(L, M, A, M, J, jend - J, jend, next_end, jend, 0, la.side);   // group J -> rows of group J+1
+                if (next_end < M) {
+                    la.main_waits_for_chain();
+                    trsm_update<0>(L, M, A, M, J, jend - J, next_end, M, jend, 0, s);        // group J -> all rows below group J+1
+                    la.main_applied();
+                }
+            }
+        }
+        la.join();
+        for (int64_t jend = M; jend > 0; jend -= kOuterRows) {
+            const int64_t J = jend > kOuterRows ? jend - kOuterRows : 0;
+            const int64_t prev = J > kOuterRows ? J - kOuterRows : 0;
+            backward_chain(J, jend, la.side);
+            la.chain_done();
+            if (J > 0) {
+                la.side_waits_for_main();
+                trsm_update<1>(L, M, A, M, J, jend - J, prev, J, J, 1, la.side);             // group J -> rows of the group above
+                if (prev > 0) {
+                    la.main_waits_for_chain();
+                    trsm_update<1>(L, M, A, M, J, jend - J, 0, prev, J, 1, s);               // group J -> all rows above that
+                    la.main_applied();
+                }
+            }
+        }
+        la.close();
     }
     hipLaunchKernelGGL(mirror_lower_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)M), dim3(256), 0, s, A, M);
     return check_launch("cholesky_inverse launch");

@@ -80,10 +80,15 @@ def test_cholesky_lookahead_path_on_a_side_stream():
         L = A.clone()                                     # queued before the call on the same stream
         _lib.check(lib.scasml_cholesky(_lib.ptr(L), M, 0.0, _lib.ptr(info), side.cuda_stream), "chol")
         err = (L - want).abs().max()                      # queued after it: must see the finished factor
+        Ainv = torch.empty_like(L)
+        _lib.check(lib.scasml_cholesky_inverse(_lib.ptr(L), M, _lib.ptr(Ainv), side.cuda_stream), "cholesky_inverse")
+        want_inv = torch.cholesky_inverse(want)
+        err_inv = (Ainv - want_inv).abs().max() / want_inv.abs().max()
     side.synchronize()
     assert int(info.item()) == 0
     assert float(err) < 1e-10 * float(want.abs().max()) * 40
     assert float(torch.triu(L, 1).abs().max()) == 0.0
+    assert float(err_inv) < 1e-9          # condition number ~ 1e3 here
 
 @pytest.mark.parametrize("d,nd,nb", [(4, 30, 10), (20, 120, 40)])
 def test_training_matches_oracle(d, nd, nb):
