@@ -140,9 +140,12 @@ int scasml_clip(float *uz, int64_t count, float clip, void *stream);
 
 /* Raw RNG access for parity tests: normals of `site` for roots root0..root0+B-1 -> B x d. */
 int scasml_debug_normals(scasml_rng rng, uint32_t site, int32_t d, int64_t B, float *out, void *stream);
-/* The two halves of the Box-Muller transform on their 24-bit input domains, for exhaustive parity tests: for
- * k = k0 .. k0+n-1 (k0 + n <= 2^24)  rad[i] = sqrt(-2 ln((k+1) 2^-24)),  cos_sin[2i], cos_sin[2i+1] = angle word k. */
-int scasml_debug_transform(uint32_t k0, int64_t n, float *rad, float *cos_sin, void *stream);
+/* The normal transform on its whole input domain, for exhaustive parity tests: a normal is a function of the top 24 bits of
+ * its Philox word;  out[i] = N(word = (k0 + i) << 8)  for i < n, k0 + n <= 2^24 (device pointer). */
+int scasml_debug_transform(uint32_t k0, int64_t n, float *out, void *stream);
+/* The 768 x 4 binary32 coefficients of the table-driven inverse normal CDF (csrc/normal_table.inc) -> HOST memory:
+ * the specification of the normal transform as data, so that a second implementation can be checked against it. */
+int scasml_normal_table(float *table_h);
 
 /* ------------------------------------------------------------------ Gaussian process */
 

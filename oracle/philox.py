@@ -1,4 +1,4 @@
-"""Oracle RNG: Philox4x32-10 + a bit-reproducible Box-Muller normal generator.
+"""Oracle RNG: Philox4x32-10 + a bit-reproducible inverse-CDF normal generator.
 
 TEST INFRASTRUCTURE (see oracle/__init__.py).  Replaces the reference's
 ``jax.random.normal(key, (B, MC, d), float16)`` / ``random.uniform`` draws
@@ -15,13 +15,12 @@ JAX's threefry stream is an un-vendored dependency and cannot be reproduced here
   index of the path-step inside one root's Picard tree (oracle/mlp.py ``site_count``);
   ``root`` is the global index of the evaluation point; ``stream`` separates solver
   calls.  quad = 0x80000000 is reserved for the full-history uniform time draw.
-* Normals: Box-Muller on 24-bit uniforms, with ln / sin / cos evaluated by fixed
-  polynomials (Cephes single-precision coefficients) in Horner form, every step ONE
-  IEEE-754 binary32 operation: a multiply, an add, a correctly-rounded sqrt, or -- where
-  the code below says ``fma32`` -- a fused multiply-add (one rounding; ``fmaf`` on the GPU,
-  an exact emulation through float64 here).  Any conforming implementation therefore
-  produces the same bits.  (Round 1 specified separately rounded multiply and add
-  throughout; the fused form is 16 % fewer instructions in a kernel that is bound by them.)
+* Normals: one per Philox word, the inverse normal CDF of the 24-bit uniform in the word's top bits, evaluated as a
+  per-segment cubic from a 768-row table (``normal_table``) with three fused multiply-adds in IEEE-754 binary32
+  (``fma32``: one rounding; ``fmaf`` on the GPU, an exact emulation through float64 here).  Integer bit manipulation,
+  a table row and three correctly rounded operations: any conforming implementation produces the same bits.
+  (Round 1 and most of round 2 used Box-Muller with Cephes polynomials; the table form is half the vector instructions
+  in kernels that are bound by them.)
 """
 import numpy as np
 
@@ -51,18 +50,7 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 
 _f32 = np.float32
-_LOG_P = [_f32(v) for v in (7.0376836292e-2, -1.1514610310e-1, 1.1676998740e-1, -1.2420140846e-1,
-                            1.4249322787e-1, -1.6668057665e-1, 2.0000714765e-1, -2.4999993993e-1,
-                            3.3333331174e-1)]
-_LN2_HI = _f32(0.693359375)
-_LN2_LO = _f32(-2.12194440e-4)
-_SQRT2 = _f32(1.41421354)
-_SIN_P = [_f32(v) for v in (-1.9515295891e-4, 8.3321608736e-3, -1.6666654611e-1)]
-_COS_P = [_f32(v) for v in (2.443315711809948e-5, -1.388731625493765e-3, 4.166664568298827e-2)]
-_ANGLE_SCALE = _f32(np.pi / 2 * 2.0 ** -22)  # (pi/2) * 2^-22 rounded to binary32
 _HALF = _f32(0.5)
-_ONE = _f32(1.0)
-_TWO_M24 = _f32(2.0 ** -24)
 
 
 def fma32(a, b, c):
@@ -82,63 +70,42 @@ def fma32(a, b, c):
     return s.astype(np.float32)
 
 
-def ln_u24(k):
-    """ln(k * 2^-24) for integer k in [1, 2^24], binary32, mul/add only (Cephes logf scheme)."""
-    f = k.astype(np.float32)                       # exact: k <= 2^24
-    bits = f.view(np.uint32)
-    e = (bits >> np.uint32(23)).astype(np.int32) - np.int32(127)
-    m = ((bits & np.uint32(0x007FFFFF)) | np.uint32(0x3F800000)).view(np.float32)  # [1, 2)
-    big = m > _SQRT2
-    m = np.where(big, m * _HALF, m)                # exact
-    e = np.where(big, e + np.int32(1), e)
-    x = m - _ONE                                   # exact (Sterbenz)
-    z = x * x
-    p = np.broadcast_to(_LOG_P[0], x.shape)
-    for c in _LOG_P[1:]:
-        p = fma32(p, x, c)
-    y = x * z
-    y = y * p
-    fe = (e - np.int32(24)).astype(np.float32)
-    y = fma32(fe, _LN2_LO, y)
-    y = fma32(-_HALF, z, y)
-    r = x + y
-    r = fma32(fe, _LN2_HI, r)
-    return r.astype(np.float32)
+_TABLE = None
 
 
-def sincos_u24(k):
-    """(cos, sin) of a uniformly distributed angle built from the 24-bit integer k.
-
-    The top two bits choose the quadrant; the low 22 bits give an angle in
-    (-pi/4, pi/4) evaluated by the Cephes sinf/cosf kernels.  (The angle carries a
-    constant pi/4 phase relative to 2*pi*k/2^24, irrelevant for a uniform angle.)
-    """
-    quad = (k >> np.uint32(22)).astype(np.int32)
-    frac = (k & np.uint32(0x3FFFFF)).astype(np.int32)
-    w = (frac - np.int32(1 << 21)).astype(np.float32) + _HALF    # exact half-integers
-    x = w * _ANGLE_SCALE
-    z = x * x
-    s = fma32(_SIN_P[0], z, _SIN_P[1])
-    s = fma32(s, z, _SIN_P[2])
-    s = s * z
-    s = fma32(s, x, x)
-    c = fma32(_COS_P[0], z, _COS_P[1])
-    c = fma32(c, z, _COS_P[2])
-    c = fma32(c, z * z, fma32(-_HALF, z, _ONE))
-    cc = np.where(quad == 0, c, np.where(quad == 1, -s, np.where(quad == 2, -c, s)))
-    ss = np.where(quad == 0, s, np.where(quad == 1, c, np.where(quad == 2, -s, -c)))
-    return cc.astype(np.float32), ss.astype(np.float32)
+def normal_table():
+    """The 768 x 4 binary32 coefficients of the inverse normal CDF, restated from the definition (the product carries them
+    as a committed constant, scasml_gp_amd/csrc/normal_table.inc; tests/test_oracle_philox.py and tests/test_gpu_rng.py check
+    that the two agree bit for bit).  Row 32 e + g covers the odd integers v = 2 j + 1 in [2^e (1 + g/32), 2^e (1 + (g+1)/32)),
+    i.e. p = v 2^-25; its cubic is the Hermite interpolant of Phi^-1 between the segment's ends (values from scipy's ndtri,
+    slopes 1 / phi), in the integer coordinate s = low 18 mantissa bits of binary32(v)."""
+    global _TABLE
+    if _TABLE is None:
+        from scipy.special import ndtri
+        e = np.repeat(np.arange(24, dtype=np.float64), 32)
+        g = np.tile(np.arange(32, dtype=np.float64), 24)
+        pa = 2.0 ** e * (1.0 + g / 32.0) * 2.0 ** -25
+        pb = 2.0 ** e * (1.0 + (g + 1.0) / 32.0) * 2.0 ** -25
+        xa, xb = ndtri(pa), ndtri(pb)
+        ha = (pb - pa) * np.sqrt(2.0 * np.pi) * np.exp(0.5 * xa * xa)
+        hb = (pb - pa) * np.sqrt(2.0 * np.pi) * np.exp(0.5 * xb * xb)
+        dx = xb - xa
+        _TABLE = np.stack([xa, ha * 2.0 ** -18, (3.0 * dx - 2.0 * ha - hb) * 2.0 ** -36,
+                           (ha + hb - 2.0 * dx) * 2.0 ** -54], axis=1).astype(np.float32)
+    return _TABLE
 
 
-def box_muller(ra, rb):
-    """Two N(0,1) binary32 values from two uint32 words."""
-    k1 = (ra >> np.uint32(8)) + np.uint32(1)
-    k2 = rb >> np.uint32(8)
-    t = _f32(-2.0) * ln_u24(k1)
-    t = np.where(t < 0, _f32(0.0), t)
-    rad = np.sqrt(t).astype(np.float32)
-    c, s = sincos_u24(k2)
-    return (rad * c).astype(np.float32), (rad * s).astype(np.float32)
+def icdf_normal(r):
+    """One N(0,1) binary32 value per uint32 word: inverse CDF of u = ((r >> 8) + 1/2) 2^-24 by table (see normal_table)."""
+    r = np.asarray(r, dtype=np.uint32)
+    upper = (r >> np.uint32(31)).astype(bool)                       # u > 1/2
+    k = r >> np.uint32(8)
+    j = np.where(upper, k ^ np.uint32(0xFFFFFF), k) & np.uint32(0x7FFFFF)
+    b = (np.uint32(2) * j + np.uint32(1)).astype(np.float32).view(np.uint32)   # exact: < 2^24
+    c = normal_table()[(b >> np.uint32(18)) - np.uint32(127 << 5)]
+    s = (b & np.uint32(0x3FFFF)).astype(np.float32)                 # exact
+    x = fma32(fma32(fma32(c[..., 3], s, c[..., 2]), s, c[..., 1]), s, c[..., 0])
+    return np.where(upper, -x, x).astype(np.float32)
 
 
 def normals(seed, stream, root, site, d):
@@ -152,9 +119,7 @@ def normals(seed, stream, root, site, d):
     q = np.arange(nq, dtype=np.uint64)[None, :]
     r0, r1, r2, r3 = philox4x32_10(q, np.uint64(site), root[:, None], np.uint64(stream),
                                    np.uint64(seed) & _MASK, np.uint64(seed) >> _S32)
-    n0, n1 = box_muller(r0, r1)
-    n2, n3 = box_muller(r2, r3)
-    out = np.stack([n0, n1, n2, n3], axis=-1).reshape(root.shape[0], 4 * nq)
+    out = np.stack([icdf_normal(r) for r in (r0, r1, r2, r3)], axis=-1).reshape(root.shape[0], 4 * nq)
     return out[:, :d]
 
 

@@ -62,7 +62,8 @@ SIGNATURES = {
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "scasml_clip": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
     "scasml_debug_normals": (C.c_int, [Rng, C.c_uint32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
-    "scasml_debug_transform": (C.c_int, [C.c_uint32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "scasml_debug_transform": (C.c_int, [C.c_uint32, C.c_int64, C.c_void_p, C.c_void_p]),
+    "scasml_normal_table": (C.c_int, [C.c_void_p]),
     "scasml_gp_plane_halfwords": (C.c_int64, [C.c_int32, C.c_int32]),
     "scasml_gp_coef_floats": (C.c_int64, [C.c_int32]),
     "scasml_gp_pack": (C.c_int, [C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,

@@ -17,6 +17,7 @@
 // MODE_GENERATE emits every tree point (coalesced float4 rows), MODE_ACCUMULATE reads those states
 // back (recovering the normals from them; it replays Philox only where that would be inaccurate, see
 // kReadbackMinVol, and for the full-history draws) and consumes (u_hat, div u_hat, eps_PDE) per point.
+#include <string.h>
 #include "common.hpp"
 #include "equations.hpp"
 #include "philox_normal.hpp"
@@ -154,7 +155,7 @@ struct Walker {
                 float dplus, dminus;
                 if constexpr (VAR == 0 && MODE == SCASML_MODE_ACCUMULATE) {
                     // The pass that emitted the points already produced X_k, bit for bit; read it back instead
-                    // of replaying Philox + Box-Muller, and recover W_k = (X_k - x - mu (t_k - t)) / sigma (one
+                    // of replaying Philox and the normal transform, and recover W_k = (X_k - x - mu (t_k - t)) / sigma (one
                     // rounding of a difference of O(1) numbers divided by sigma: ~1e-6 relative).
                     const float ck = tau * tm.cfrac[k];
                     X = load_point(site);
@@ -268,7 +269,7 @@ struct Walker {
                         gpv = gp_at(site);
                     }
                     // The emitting pass stored X_T bit for bit: recover the normals (one rounding of a difference
-                    // of O(1) numbers: ~1e-6 relative) instead of replaying Philox + Box-Muller, which would be most
+                    // of O(1) numbers: ~1e-6 relative) instead of replaying Philox and the normal transform, which would be most
                     // of this pass's VALU work.  Close to T they cannot be recovered accurately (kReadbackMinVol): replay.
                     if (__builtin_expect(readback, 1)) {
                         const float rv = rcp_fast(vol);
@@ -313,13 +314,14 @@ struct Walker {
 // deeper levels then spill inside their loops; 6 and 8 are slower.  No hint.)
 template <int VAR, int MODE, int N, int EQ>
 __global__ __launch_bounds__(256) void picard_tree_kernel(const TreeArgs a) {
+    normal_table_to_lds();   // every thread, before any return below
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * (blockDim.x >> 6)) + (threadIdx.x >> 6);
     int64_t local;
     uint32_t gl;
     if constexpr (MODE == SCASML_MODE_GENERATE) {
         // GENERATE takes no sum over dims: lanes need not form power-of-two groups.  Flat (root, quad) mapping over the
-        // kp / 4 float4 of a row, so no lane idles through the Philox + Box-Muller work (at d = 100: 28 lanes per root
+        // kp / 4 float4 of a row, so no lane idles through the Philox and the normal transform work (at d = 100: 28 lanes per root
         // instead of 32, 25 of them drawing normals)
         const int64_t flat = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
         const int quads = a.kp >> 2;
@@ -408,6 +410,7 @@ __global__ void clip_kernel(float *v, int64_t n, float c) {
 
 __global__ void debug_normals_kernel(uint32_t k0, uint32_t k1, uint32_t stream, uint32_t root0, uint32_t site,
                                      int d, int64_t B, float *out) {
+    normal_table_to_lds();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int nq = (d + 3) / 4;
     if (i >= B * nq) return;
@@ -596,26 +599,31 @@ extern "C" int scasml_clip(float *uz, int64_t count, float clip, void *stream) {
     return check_launch("clip launch");
 }
 
-// radius sqrt(-2 ln((k+1) 2^-24)) and (cos, sin) of the angle word k, for k = k0 .. k0 + n - 1: the two halves of the normal
-// transform on their whole 24-bit domains (tests/test_gpu_rng.py checks all 2^24 inputs of each against NumPy)
-__global__ void debug_transform_kernel(uint32_t k0, int64_t n, float *rad, float *cs) {
+// the normal transform of the 24-bit word k (a normal depends on the top 24 bits of its Philox word only), for k = k0 .. k0 + n - 1:
+// tests/test_gpu_rng.py checks all 2^24 inputs against NumPy
+__global__ void debug_transform_kernel(uint32_t k0, int64_t n, float *out) {
+    normal_table_to_lds();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t k = k0 + (uint32_t)i;
-    float t = -2.0f * ln_u24(k + 1u);
-    t = t < 0.0f ? 0.0f : t;
-    rad[i] = sqrt_rn(t);
-    float c, s;
-    sincos_u24(k, c, s);
-    cs[2 * i] = c;
-    cs[2 * i + 1] = s;
+    out[i] = icdf_normal((k0 + (uint32_t)i) << 8, normal_table_lds());
 }
 
-extern "C" int scasml_debug_transform(uint32_t k0, int64_t n, float *rad, float *cos_sin, void *stream) {
-    if (!rad || !cos_sin || n < 0 || (uint64_t)k0 + (uint64_t)n > (1ull << 24)) return fail(SCASML_ERR_ARG, "debug_transform: bad argument");
+extern "C" int scasml_debug_transform(uint32_t k0, int64_t n, float *out, void *stream) {
+    if (!out || n < 0 || (uint64_t)k0 + (uint64_t)n > (1ull << 24)) return fail(SCASML_ERR_ARG, "debug_transform: bad argument");
     if (n == 0) return 0;
-    hipLaunchKernelGGL(debug_transform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, k0, n, rad, cos_sin);
+    hipLaunchKernelGGL(debug_transform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, k0, n, out);
     return check_launch("debug_transform launch");
+}
+
+// the host's copy of the same rows (the .inc file is included twice: the kernels read kNormalTable)
+static const float kNormalTableHost[kNormalTableRows][4] = {
+#include "normal_table.inc"
+};
+
+extern "C" int scasml_normal_table(float *table_h) {
+    if (!table_h) return fail(SCASML_ERR_ARG, "normal_table: null argument");
+    memcpy(table_h, kNormalTableHost, sizeof(kNormalTableHost));
+    return 0;
 }
 
 extern "C" int scasml_debug_normals(scasml_rng rng, uint32_t site, int32_t d, int64_t B, float *out, void *stream) {

@@ -95,8 +95,8 @@ class PicardEngine:
 
     def path_bound(self):
         """Bound on |coordinate| of every tree point, from the geometry (no device read): the cube's half-width plus the
-        largest drift and 5.8 standard deviations of the diffusion over [t0, T] -- the 24-bit Box-Muller radius cannot exceed
-        sqrt(-2 ln 2^-24) = 5.77.  Used as the stated precondition of the fp16 evaluation mode (scasml_gp_model.x_bound)."""
+        largest drift and 5.8 standard deviations of the diffusion over [t0, T] -- a normal of the 24-bit inverse-CDF transform
+        cannot exceed |Phi^-1(2^-25)| = 5.42.  Used as the stated precondition of the fp16 evaluation mode (scasml_gp_model.x_bound)."""
         eq = self.equation
         radius = float(getattr(eq, "radius", 0.5))
         T = float(eq.T) - float(getattr(eq, "t0", 0.0))

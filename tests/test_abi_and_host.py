@@ -72,6 +72,16 @@ def test_host_tables_equal_oracle_tables(rho):
         assert np.array_equal(np.nan_to_num(a, nan=-7.0), np.nan_to_num(b, nan=-7.0))
 
 
+def test_library_normal_table_equals_the_oracles_restatement(lib):
+    """The normal transform's table is a committed constant of the library (csrc/normal_table.inc); the oracle restates its
+    definition (oracle/philox.py normal_table).  Bit for bit, no GPU needed."""
+    from oracle import philox
+    got = np.empty((768, 4), dtype=np.float32)
+    assert lib.scasml_normal_table(got.ctypes.data_as(C.c_void_p)) == 0
+    assert np.array_equal(got.view(np.uint32), philox.normal_table().view(np.uint32))
+    assert lib.scasml_normal_table(None) == -1 and b"null" in lib.scasml_last_error()
+
+
 def test_stale_delta_t_schedule():
     """MLP.py:249 reuses the previous delta_t for the '+' term; ScaSML.py:253 recomputes it."""
     mlp = tables.build_plan("quad", 3, 3, 0.5, True)

@@ -23,23 +23,18 @@ def test_normals_bit_identical(d, site, seed, stream, root0):
 
 
 def test_normal_transform_is_bit_identical_on_every_input():
-    """Box-Muller here is separable: the radius depends on one 24-bit word, (cos, sin) on another, and a normal is
-    one IEEE product of the two.  Both halves are compared with the NumPy statement on their WHOLE domains
-    (2^24 inputs each), so every normal the device can produce has the oracle's bits."""
+    """A normal is a function of the top 24 bits of its Philox word: the device transform is compared with the NumPy statement
+    on ALL 2^24 inputs, so every normal the device can produce has the oracle's bits.  The library's table (the committed
+    constant) must be the oracle's restatement of its definition."""
     import torch
     from oracle import philox
     from scasml_gp_amd import _lib
     lib = _lib.load()
+    table = np.empty((768, 4), dtype=np.float32)
+    _lib.check(lib.scasml_normal_table(table.ctypes.data_as(C.c_void_p)), "normal_table")
+    assert np.array_equal(table.view(np.uint32), philox.normal_table().view(np.uint32))
     n = 1 << 24
-    rad = torch.empty(n, dtype=torch.float32, device="cuda")
-    cs = torch.empty((n, 2), dtype=torch.float32, device="cuda")
-    _lib.check(lib.scasml_debug_transform(0, n, _lib.ptr(rad), _lib.ptr(cs), _lib.stream_ptr()), "debug_transform")
-    k = np.arange(n, dtype=np.uint32)
-    t = np.float32(-2.0) * philox.ln_u24(k + np.uint32(1))
-    t = np.where(t < 0, np.float32(0.0), t)
-    want_rad = np.sqrt(t).astype(np.float32)
-    want_c, want_s = philox.sincos_u24(k)
-    got_rad, got_cs = rad.cpu().numpy(), cs.cpu().numpy()
-    assert np.array_equal(got_rad.view(np.uint32), want_rad.view(np.uint32))
-    assert np.array_equal(got_cs[:, 0].view(np.uint32), want_c.view(np.uint32))
-    assert np.array_equal(got_cs[:, 1].view(np.uint32), want_s.view(np.uint32))
+    out = torch.empty(n, dtype=torch.float32, device="cuda")
+    _lib.check(lib.scasml_debug_transform(0, n, _lib.ptr(out), _lib.stream_ptr()), "debug_transform")
+    want = philox.icdf_normal(np.arange(n, dtype=np.uint32) << np.uint32(8))
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))

@@ -25,7 +25,7 @@ def test_normals_are_float32_deterministic_and_standard():
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     assert abs(a.mean()) < 5e-3 and abs(a.std() - 1) < 5e-3
     assert abs((a.astype(np.float64) ** 4).mean() - 3) < 0.05
-    assert np.abs(a).max() < 5.8                         # 24-bit uniforms: radius <= sqrt(2*24*ln2)
+    assert np.abs(a).max() < 5.43                        # 24-bit uniforms: |Phi^-1(2^-25)| = 5.42
     # distinct sites / roots / streams / seeds decorrelate
     for other in (philox.normals(7, 3, np.arange(4096), 12, 100), philox.normals(7, 4, np.arange(4096), 11, 100),
                   philox.normals(8, 3, np.arange(4096), 11, 100), philox.normals(7, 3, np.arange(4096) + 4096, 11, 100)):
@@ -38,15 +38,31 @@ def test_ragged_dimension_is_prefix_of_padded_quads():
     assert np.array_equal(a, b[:, :7])
 
 
-def test_ln_and_sincos_accuracy():
-    k = np.arange(1, 2 ** 24 + 1, 997, dtype=np.uint32)
-    ref = np.log(k.astype(np.float64) * 2.0 ** -24)
-    got = philox.ln_u24(k).astype(np.float64)
-    assert np.abs(got - ref).max() < 5e-7 and (got <= 0).all()
-    assert philox.ln_u24(np.array([2 ** 24], dtype=np.uint32))[0] == 0.0
-    k = np.arange(0, 2 ** 24, 1013, dtype=np.uint32)
-    c, s = philox.sincos_u24(k)
-    assert np.abs(c.astype(np.float64) ** 2 + s.astype(np.float64) ** 2 - 1).max() < 3e-7
+def test_normal_transform_on_its_whole_domain():
+    """Every one of the 2^24 inputs: within 5e-7 (one binary32 ulp at |x| > 4) of scipy's inverse CDF of the input's uniform, odd about u = 1/2, and
+    monotone to rounding (a decrease between neighbouring inputs is at most one rounding of the cubic's value)."""
+    from scipy.special import ndtri
+    k = np.arange(1 << 24, dtype=np.uint32)
+    x = philox.icdf_normal(k << np.uint32(8))
+    assert x.dtype == np.float32
+    u = (k.astype(np.float64) + 0.5) * 2.0 ** -24
+    assert np.abs(x.astype(np.float64) - ndtri(u)).max() < 5e-7
+    assert np.array_equal(x[: 1 << 23], -x[1 << 23:][::-1])
+    assert np.diff(x.astype(np.float64)).min() > -5e-7 and x[0] < -5.41 and x[-1] > 5.41
+    # the low 8 bits of a Philox word do not matter
+    assert np.array_equal(philox.icdf_normal((k[::4099] << np.uint32(8)) | np.uint32(0xFF)), x[::4099])
+
+
+def test_committed_table_is_the_oracles_table():
+    """The product's constant (scasml_gp_amd/csrc/normal_table.inc, hex floats) against the oracle's restatement of the definition."""
+    import os
+    import re
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scasml_gp_amd", "csrc", "normal_table.inc")
+    rows = [[float.fromhex(v) for v in re.findall(r"-?0x[0-9a-f.]+p[+-]?\d+", line)] for line in open(path) if line.startswith("{")]
+    got = np.asarray(rows, dtype=np.float64)
+    want = philox.normal_table()
+    assert got.shape == (768, 4) == want.shape
+    assert np.array_equal(got.astype(np.float32).view(np.uint32), want.view(np.uint32)) and np.array_equal(got, want.astype(np.float64))
 
 
 def test_uniform_tau_open_interval():
