@@ -199,11 +199,14 @@ def test_units_are_dealt_by_cost(lib):
 
 
 def test_no_spills_inside_the_gp_tile_loops():
-    """The GP evaluation kernels count LDS-DMA completions with `s_waitcnt vmcnt(N)`; a register spill or reload
-    inside the tile loop would be counted too and silently break the hand-over.  tools/kernel_regs.py compiles the
-    file to ISA text and reports scratch instructions inside loops: only the kernels that drain fully (three LDS
-    slots, `vmcnt(0)`) may have any."""
+    """A register spill or reload inside the tile loop of the GP evaluation kernels is a performance cliff (round 1 measured
+    72 ms for a spilling build against 8), and it makes the counted `s_waitcnt vmcnt(N)` of the LDS-DMA hand-over more
+    conservative than written.  tools/kernel_regs.py compiles the file to ISA text and reports scratch instructions inside
+    loops: only the kernels that drain fully (three LDS slots, `vmcnt(0)`) may have any.  Needs hipcc ($HIPCC or /opt/rocm)."""
     import subprocess, sys, os, re
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc at %s" % hipcc)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_regs.py"), "gp_eval_bf16.hip"],
                          capture_output=True, text=True, check=True).stdout

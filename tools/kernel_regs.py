@@ -5,7 +5,7 @@ import os, re, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "scasml_gp_amd", "csrc", sys.argv[1])
 out = "/tmp/" + sys.argv[1].replace(".hip", ".s")
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-w", "-S",
+subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-w", "-S",
                 "--cuda-device-only", "-I" + os.path.join(root, "include"), "-o", out, src] + sys.argv[2:], check=True)
 t = open(out).read()
 # scratch (spill) instructions inside loops, per kernel: the GP kernels count LDS-DMA completions with s_waitcnt
