@@ -180,7 +180,22 @@ __device__ __forceinline__ void mfma_tile_store_diff_full(const TileAcc<NT> &c, 
 // The K loop shared by the Cholesky and triangular-solve updates: `fetch(kk, ra, rb)` loads this thread's elements
 // of the two operand chunks of columns [kk, kk + NB) into registers (element e of a thread is panel entry
 // idx = tid + 256 e, row idx / NB, column idx % NB).
-template <int NT, int WS = 2, class Fetch, class PreTail>
+// Which chunk entry (tile row rr, chunk column cc) is a thread's element e: consecutive lanes walk the direction that is contiguous
+// in memory -- chunk columns for a row-major panel, tile rows for an operand stored k-major (KMAJOR: entry (rr, cc) at P[cc * ld + rr];
+// with the row-major mapping there every lane of a load touched a cache line of its own).
+template <int TBX, int THREADS, bool KMAJOR>
+__device__ __forceinline__ void chunk_entry(int e, int &rr, int &cc) {
+    const int idx = threadIdx.x + e * THREADS;
+    if (KMAJOR) {
+        rr = idx % TBX;
+        cc = idx / TBX;
+    } else {
+        rr = idx / NB;
+        cc = idx % NB;
+    }
+}
+
+template <int NT, int WS = 2, bool KMAJOR_A = false, bool KMAJOR_B = false, class Fetch, class PreTail>
 __device__ __forceinline__ void mfma_tile_k_loop(double *smem, int64_t k_begin, int64_t k_end, Fetch fetch, PreTail pre_tail, TileAcc<NT> &t) {
     constexpr int TBX = 16 * NT * WS, THREADS = 64 * WS * WS, PER = TBX * NB / THREADS;
     double (*Pa)[TBX][LDP] = reinterpret_cast<double (*)[TBX][LDP]>(smem);
@@ -189,8 +204,10 @@ __device__ __forceinline__ void mfma_tile_k_loop(double *smem, int64_t k_begin, 
     auto park = [&](int buf) {
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
-            const int idx = threadIdx.x + e * THREADS, rr = idx / NB, cc = idx % NB;
+            int rr, cc;
+            chunk_entry<TBX, THREADS, KMAJOR_A>(e, rr, cc);
             Pa[buf][rr][cc] = ra[e];
+            chunk_entry<TBX, THREADS, KMAJOR_B>(e, rr, cc);
             Pb[buf][rr][cc] = rb[e];
         }
     };
@@ -390,19 +407,24 @@ __global__ __launch_bounds__(64 * WS * WS) void trsm_update_kernel(const double 
     double *Ct = B + r0 * nrhs + c0;
     TileAcc<NT> t, cin;
     mfma_tile_zero(t);
-    mfma_tile_k_loop<NT, WS>(smem, J, J + K, [&](int64_t kk, double (&rl)[PER], double (&rx)[PER]) {
+    // the right-hand side is always read k-major (Xt[col][k] = B[k][col]); L is k-major in the transposed solve
+    mfma_tile_k_loop<NT, WS, TRANS == 1, true>(smem, J, J + K, [&](int64_t kk, double (&rl)[PER], double (&rx)[PER]) {
         if (interior) {
 #pragma unroll
             for (int e = 0; e < PER; ++e) {
-                const int idx = threadIdx.x + e * THREADS, rr = idx / NB, cc = idx % NB;
+                int rr, cc;
+                chunk_entry<TBX, THREADS, TRANS == 1>(e, rr, cc);
                 rl[e] = TRANS == 0 ? L[(r0 + rr) * M + kk + cc] : L[(kk + cc) * M + r0 + rr];
-                rx[e] = B[(kk + cc) * nrhs + c0 + rr];   // Xt[col][k]
+                chunk_entry<TBX, THREADS, true>(e, rr, cc);
+                rx[e] = B[(kk + cc) * nrhs + c0 + rr];
             }
         } else {
 #pragma unroll
             for (int e = 0; e < PER; ++e) {
-                const int idx = threadIdx.x + e * THREADS, rr = idx / NB, cc = idx % NB;
+                int rr, cc;
+                chunk_entry<TBX, THREADS, TRANS == 1>(e, rr, cc);
                 rl[e] = r0 + rr < rend ? (TRANS == 0 ? L[(r0 + rr) * M + kk + cc] : L[(kk + cc) * M + r0 + rr]) : 0.0;
+                chunk_entry<TBX, THREADS, true>(e, rr, cc);
                 rx[e] = c0 + rr < nrhs ? B[(kk + cc) * nrhs + c0 + rr] : 0.0;
             }
         }
