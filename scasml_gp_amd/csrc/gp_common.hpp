@@ -15,6 +15,9 @@ struct GpArgs {
     const uint16_t *colloc_f16;   // [n_tiles][2 planes][kp/16][64][8] fp16 planes (h, l = fp16(v - h), unscaled)
     const float *coef;         // [n_pad][16]  FP32-kernel constants
     const float *coef2;        // [n_pad][16]  exponent-scaled constants of the 16-bit kernels (gp_epilogue_scaled)
+    const float *coef3;        // [n_pad][8]   constants of the E-from-MFMA epilogue (gp_epilogue_em), scaled by 2^s
+    const uint16_t *eplane;    // [n_tiles][1 KiB]: 64 x 4 fp16 A fragments of the linear part of E (K = 8), then 32 rows x 4 floats (gp_epilogue_em), scaled by 2^s
+    const float *escale;       // escale[0] = 2^-s
     int32_t first_bdy_tile;    // collocation tiles from here on hold boundary (and padding) rows only: cL = ct = cS = 0
     float4 *out4;              // n_inf x (u, div, eps, dt)
     float *lap;                // n_inf or null
@@ -159,6 +162,80 @@ __device__ __forceinline__ void gp_epilogue_scaled(const GpStageView &st, const 
                 } else if constexpr (KIND == 5) {
                     const float c2 = q[cur][1].w, c3 = q[cur][2].x;
                     ad = fmaf(kap, fmaf(-ss, E, fmaf(c2, ss, c3)), ad);   // the same operations as KIND 0: div does not depend on the form
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// E-from-MFMA epilogue (fp16x2 mode with fp16-exact collocation points, gp_eval_bf16.hip EM).  The part of E that is bilinear in
+// (point, collocation row),
+//     E_lin = e0 + et pp + cS ss = [e0 - et vty - cS vsy] + et tx + cS sx           (pp = tx - vty, ss = sx - vsy),
+// comes out of ONE extra MFMA per tile (32x32x8, fp16) instead of two vector instructions per pair: the collocation side carries
+// S (cE_h, cE_l, et_h, et_h | et_l, cS_h, cS_h, cS_l) as fp16 (h = fp16(v), l = fp16(v - h); S = 2^s brings the largest entry to
+// 2^12..2^13), the point side (1, 1, tx_h, tx_l | tx_h, sx_h, sx_l, sx_h): every product of two 11-bit significands is exact in the
+// fp32 accumulator, the dropped l*l terms are 2^-22 of their product.  Everything downstream is carried times S (constants
+// pre-scaled) and the four sums are multiplied by 2^-s once per point.  Tiles of terminal samples (KIND 4) and of boundary rows
+// (KIND 2 / 3) are bound by the matrix pipe or trivial and keep their all-vector forms, with their own row constants.
+// LDS slot behind the A planes: 512 B of E fragments (64 lanes x 4 halves) | 512 B `trow`: per row (S e0T, S eL, S cS, S e0) |
+// 1 KiB `coef3`: per row  0 vsy  1 vty  2 S eL  3 S q6  |  4 S q7  5 S q8  6 S q10  7 S q11  (q9 = -2 q7).  KIND as in
+// gp_epilogue_scaled:   0: 14 VALU + exp (16 before);  5 (u, div): 8 (10);  1 (u): 4 (7);  4, 2, 3: as before.
+template <int KIND, bool PF>
+__device__ __forceinline__ void gp_epilogue_em(const float *trow_lds, const f32x16 &acc, const f32x16 &accE, int half, float sx, float tx,
+                                               float &au, float &at, float &ad, float &al) {
+    const float4 *tb = reinterpret_cast<const float4 *>(__builtin_assume_aligned(trow_lds + 4 * 4 * half, 16));        // 1 float4 per row
+    const float4 *cb = reinterpret_cast<const float4 *>(__builtin_assume_aligned(trow_lds + 128 + 4 * 8 * half, 16));  // 2 float4 per row
+    constexpr bool USE_T = KIND == 2 || KIND == 3 || KIND == 4;                // reads the row's trow float4
+    constexpr int NQ = (KIND == 0 || KIND == 5) ? 2 : ((KIND == 3 || KIND == 4) ? 0 : 1);   // coef3 float4 per row
+    constexpr int NR = NQ + (USE_T ? 1 : 0);
+    float4 q[PF ? 2 : 1][NR];
+    auto fetch = [&](int r, float4 (&dst)[NR]) {
+        const int row = (r & 3) + 8 * (r >> 2);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) dst[i] = cb[row * 2 + i];
+        if constexpr (USE_T) dst[NQ] = tb[row];
+    };
+    if constexpr (PF) fetch(0, q[0]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int cur = PF ? (r & 1) : 0, nxt = cur ^ 1;
+        if constexpr (PF) {
+            if (r + 1 < 16) fetch(r + 1, q[nxt]);
+        } else {
+            fetch(r, q[0]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float lam = acc[r];
+        const float kap = __builtin_amdgcn_exp2f(lam);
+        if constexpr (KIND == 3) {
+            au = fmaf(kap, q[cur][0].w, au);
+        } else if constexpr (KIND == 4) {       // (S e0T, S eL, S cS, -): E = e0T + eL Lam + cS (a S_x)
+            au = fmaf(kap, fmaf(q[cur][0].z, sx, fmaf(q[cur][0].y, lam, q[cur][0].x)), au);
+        } else {
+            const float vsy = q[cur][0].x, vty = q[cur][0].y;
+            const float pp = tx - vty;
+            const float Lh = fmaf(pp, pp, lam);
+            if constexpr (KIND == 2) {
+                const float ss = sx - vsy;
+                const float ve0 = q[cur][1].w;
+                const float w = kap * ve0;
+                au = fmaf(kap, ve0, au);        // the same rounding as KIND 3
+                at = fmaf(-pp, w, at);
+                ad = fmaf(-ss, w, ad);
+                al = fmaf(Lh, w, al);
+            } else {
+                const float E = fmaf(q[cur][0].z, Lh, accE[r]);
+                au = fmaf(kap, E, au);
+                if constexpr (KIND == 0 || KIND == 5) {
+                    const float ss = sx - vsy;
+                    const float c2 = q[cur][1].x, c3 = q[cur][1].y;
+                    ad = fmaf(kap, fmaf(-ss, E, fmaf(c2, ss, c3)), ad);
+                    if constexpr (KIND == 0) {
+                        const float act = q[cur][0].w, c5 = q[cur][1].z, c6 = q[cur][1].w;
+                        at = fmaf(kap, fmaf(-pp, E, act), at);
+                        al = fmaf(kap, fmaf(Lh, fmaf(c2, -2.0f, E), fmaf(c5, ss, c6)), al);
+                    }
                 }
             }
         }

@@ -331,6 +331,73 @@ __global__ void gp_pack_kernel(int d, float a, float T, const float *x_dom, int 
     c2[15] = cS;
 }
 
+// ---- E-from-MFMA constants (gp_common.hpp, gp_epilogue_em): the four collocation-side entries of the linear part of E per row,
+// from the exponent-scaled constants `c2` of the row and the terminal time
+struct EmRow {
+    float cE, et, cS;
+};
+__device__ __forceinline__ EmRow em_row(const float *c2) {
+    EmRow r;
+    r.cE = c2[2] - c2[4] * c2[1] - c2[5] * c2[0];   // e0 - et vty - cS vsy
+    r.et = c2[4];
+    r.cS = c2[5];
+    return r;
+}
+// pass 1: largest magnitude over all rows -> bits of a non-negative float in *maxbits (zeroed by the caller)
+__global__ void gp_em_max_kernel(const float *coef2, int n_pad, unsigned int *maxbits) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    float m = 0.0f;
+    if (j < n_pad) {
+        const EmRow r = em_row(coef2 + (int64_t)j * kCoefRow);
+        m = fmaxf(fmaxf(fabsf(r.cE), fabsf(r.et)), fabsf(r.cS));
+        if (!(m < 3.0e38f)) m = 3.0e38f;            // NaN / inf rows (an untrained model) must not poison the scale
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(maxbits, __float_as_uint(m));
+}
+// pass 2: scale 2^s (largest entry -> [2^12, 2^13)), fp16 (h, l) fragments of the E plane, scaled row constants
+__global__ void gp_em_pack_kernel(const float *coef2, int n_pad, const unsigned int *maxbits, uint16_t *eplane, float *coef3, float *escale) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const float mx = __uint_as_float(*maxbits);
+    int ex = 0;
+    if (mx > 0.0f) frexpf(mx, &ex);                  // mx = f 2^ex, f in [0.5, 1)
+    const float S = mx > 0.0f ? ldexpf(1.0f, 13 - ex) : 1.0f;
+    if (j == 0) {
+        escale[0] = 1.0f / S;
+        escale[1] = S;
+    }
+    if (j >= n_pad) return;
+    const float *c2 = coef2 + (int64_t)j * kCoefRow;
+    const EmRow r = em_row(c2);
+    auto hl = [&](float v, _Float16 &h, _Float16 &l) {
+        const float sv = S * v;
+        h = (_Float16)sv;
+        l = (_Float16)(sv - (float)h);
+    };
+    _Float16 ch, cl, th, tl, sh, sl;
+    hl(r.cE, ch, cl);
+    hl(r.et, th, tl);
+    hl(r.cS, sh, sl);
+    const _Float16 k[8] = {ch, cl, th, th, tl, sh, sh, sl};
+    const int tile = j / 32, i = j % 32;
+    uint16_t *frag = eplane + (int64_t)tile * 512;                    // 1 KiB per tile: 512 B of fragments, 512 B of row constants
+    for (int e = 0; e < 8; ++e) frag[((e / 4) * 32 + i) * 4 + (e & 3)] = __builtin_bit_cast(unsigned short, k[e]);
+    float *trow = reinterpret_cast<float *>(frag + 256) + i * 4;
+    trow[0] = S * c2[13];                            // e0T
+    trow[1] = S * c2[3];                             // eL
+    trow[2] = S * c2[5];                             // cS
+    trow[3] = S * c2[2];                             // e0 (tiles of boundary rows)
+    float *c3 = coef3 + (int64_t)j * 8;
+    c3[0] = c2[0];
+    c3[1] = c2[1];
+    c3[2] = S * c2[3];
+    c3[3] = S * c2[6];
+    c3[4] = S * c2[7];
+    c3[5] = S * c2[8];
+    c3[6] = S * c2[10];
+    c3[7] = S * c2[11];
+}
+
 template <int NK4>
 static int launch_eval(const GpArgs &g, hipStream_t s) {
     constexpr int PT = NK4 <= 13 ? 2 : 1;
@@ -361,12 +428,14 @@ static int check_model(const scasml_gp_model *m, const char *who) {
 
 using namespace scasml;
 
+// planes: 3 bf16 + 2 fp16 planes of n_pad x kp, then the E plane (16 halfwords per row);  coef: coef, coef2 (16 floats per row each),
+// coef3 (8 per row), 16 floats of scale words
 extern "C" int64_t scasml_gp_plane_halfwords(int32_t d, int32_t n_pad) {
     const int64_t kp = scasml_point_stride(d);
-    return (int64_t)n_pad * 5 * kp;
+    return (int64_t)n_pad * 5 * kp + (int64_t)n_pad * 16;
 }
 
-extern "C" int64_t scasml_gp_coef_floats(int32_t n_pad) { return (int64_t)n_pad * 2 * kCoefRow; }
+extern "C" int64_t scasml_gp_coef_floats(int32_t n_pad) { return (int64_t)n_pad * (2 * kCoefRow + 8) + 16; }
 
 extern "C" int scasml_gp_pack(int32_t d, float a, float T_terminal, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy,
                               const double *rv, float *colloc_out, float *colloc_frag_out, uint16_t *colloc_bf16_out,
@@ -376,8 +445,17 @@ extern "C" int scasml_gp_pack(int32_t d, float a, float T_terminal, const float 
     if (d < 1 || d > SCASML_MAX_DIM || n_dom < 1 || n_bdy < 0) return fail(SCASML_ERR_ARG, "gp_pack: bad sizes");
     const int n_pad = (n_dom + n_bdy + 31) / 32 * 32;
     const int kp = scasml_point_stride(d);
-    hipLaunchKernelGGL(gp_pack_kernel, dim3((n_pad + 63) / 64), dim3(64), 0, (hipStream_t)stream, d, a, T_terminal, x_dom, n_dom, x_bdy,
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gp_pack_kernel, dim3((n_pad + 63) / 64), dim3(64), 0, s, d, a, T_terminal, x_dom, n_dom, x_bdy,
                        n_bdy, rv, colloc_out, colloc_frag_out, colloc_bf16_out, coef_out, n_pad, kp);
+    // E-from-MFMA constants: a global power-of-two scale needs the largest entry first
+    float *coef2 = coef_out + (int64_t)n_pad * kCoefRow, *coef3 = coef_out + (int64_t)n_pad * 2 * kCoefRow;
+    float *escale = coef3 + (int64_t)n_pad * 8;
+    unsigned int *maxbits = reinterpret_cast<unsigned int *>(escale + 4);
+    uint16_t *eplane = colloc_bf16_out + (int64_t)n_pad * 5 * kp;
+    if (hipMemsetAsync(maxbits, 0, sizeof(unsigned int), s) != hipSuccess) return fail(SCASML_ERR_HIP, "gp_pack: memset failed");
+    hipLaunchKernelGGL(gp_em_max_kernel, dim3((n_pad + 63) / 64), dim3(64), 0, s, coef2, n_pad, maxbits);
+    hipLaunchKernelGGL(gp_em_pack_kernel, dim3((n_pad + 63) / 64), dim3(64), 0, s, coef2, n_pad, maxbits, eplane, coef3, escale);
     return check_launch("gp_pack launch");
 }
 
@@ -396,6 +474,9 @@ static int gp_eval_impl(const scasml_gp_model *m, const float *points, int64_t n
     g.rows_per_site = rows_per_site;
     g.coef = m->coef;
     g.coef2 = m->coef + (int64_t)m->n_pad * kCoefRow;
+    g.coef3 = m->coef + (int64_t)m->n_pad * 2 * kCoefRow;
+    g.escale = g.coef3 + (int64_t)m->n_pad * 8;
+    g.eplane = m->colloc_bf16 ? m->colloc_bf16 + (int64_t)5 * m->n_pad * m->kp : nullptr;
     g.first_bdy_tile = (m->n_dom + SCASML_GP_TILE - 1) / SCASML_GP_TILE;
     g.out4 = reinterpret_cast<float4 *>(out4);
     g.lap = lap;

@@ -29,10 +29,15 @@
 
 #include "gp_common.hpp"
 
+#ifndef SCASML_GP_EM
+#define SCASML_GP_EM 1   // 0: development A/B against the all-vector epilogue
+#endif
+
 namespace scasml {
 
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void split3(float v, uint32_t &h, uint32_t &m, uint32_t &l) {
     h = __float_as_uint(v) & 0xFFFF0000u;
@@ -127,8 +132,11 @@ template <int KS, int SPLIT, int WPB, bool F16, int BPC, bool YEXACT>
 __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(const GpArgs g) {
     constexpr int NPL = YEXACT ? 1 : SPLIT;          // A planes staged per tile
     constexpr bool PF = WPB * BPC <= 8 || (F16 && YEXACT && KS <= 7);
+    // E-from-MFMA epilogue (gp_common.hpp, gp_epilogue_em): the slot's two coefficient KiB become one KiB of A fragments for the
+    // linear part of E and one KiB of row constants (8 floats per row)
+    constexpr bool EM = F16 && YEXACT && SCASML_GP_EM;
     static_assert(WPB == 4 || WPB == 8 || WPB == 12 || WPB == 16, "waves per workgroup");
-    constexpr int STAGE = NPL * KS * 256 + 512;         // floats per LDS slot (A fragments + 32 rows x 16 coefficients)
+    constexpr int STAGE = NPL * KS * 256 + 512;         // floats per LDS slot (A fragments + 32 rows x 16 coefficients, or E plane + 32 x 8)
     constexpr int NSLOT = (4 * STAGE * 4 * BPC <= 144 * 1024) ? 4 : 3;
     extern __shared__ __attribute__((aligned(16))) float lds[];   // NSLOT slots
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -156,8 +164,10 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
         const uint32_t dst = lds_base + (uint32_t)(slot * STAGE) * 4u;
         const float *srcA = reinterpret_cast<const float *>(F16 ? g.colloc_f16 : g.colloc_bf16) + (int64_t)tile * (F16 ? 2 : 3) * KS * 256;
         const float *srcC = g.coef2 + (int64_t)tile * 512 - (int64_t)NPL * KS * 256;   // chunk c >= NPL*KS -> coef + (c - NPL*KS) KiB
+        const float *srcE = reinterpret_cast<const float *>(g.eplane) + (int64_t)tile * 256 - (int64_t)NPL * KS * 256;        // EM: chunk NPL*KS
+        const float *src3 = g.coef3 + (int64_t)tile * 256 - (int64_t)(NPL * KS + 1) * 256;                                  // EM: chunk NPL*KS + 1
         auto chunk = [&](int c) {
-            const float *src = c < NPL * KS ? srcA : srcC;
+            const float *src = c < NPL * KS ? srcA : (EM ? (c == NPL * KS ? srcE : src3) : srcC);
             glds16_asm(src + c * 256, (uint32_t)lane * 16u, dst + (uint32_t)c * 1024u);
         };
 #pragma unroll
@@ -285,7 +295,19 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
         else if (k0 == 4 && s0 == s1 && g.rows_per_site % 32 == 0) form = 3;   // u_hat and div only
     }
     form = __builtin_amdgcn_readfirstlane(form);
-    f32x16 acc;
+    // EM: the point side of the E-plane product, (1, 1, tx_h, tx_l | tx_h, sx_h, sx_l, sx_h) as fp16 (gp_common.hpp, gp_epilogue_em)
+    h16x4 xe;
+    if constexpr (EM) {
+        const float txh = (float)(_Float16)tx, sxh = (float)(_Float16)sx;
+        union {
+            h16x4 h;
+            uint32_t u[2];
+        } b;
+        b.u[0] = half ? pack_h2(tx, sx) : pack_h2(1.0f, 1.0f);
+        b.u[1] = half ? pack_h2(sx - sxh, sx) : pack_h2(tx, tx - txh);
+        xe = b.h;
+    }
+    f32x16 acc, accE;
     uint32_t region;
     asm volatile("s_mov_b32 %0, -1" : "=s"(region));   // see tile(): basic-block boundaries, never false
     // the whole sweep is instantiated three times (full / u-only / u-only at t = T) and the wave-uniform choice is made
@@ -308,8 +330,24 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
             if (!(g.dbg & 2)) gp_epilogue_scaled<decltype(kind)::value, PF>(view(jt % NSLOT), acc, half, sx, tx, au, at, ad, al);
 #else
             if (jt + AHEAD < n_tiles) stage(jt + AHEAD, (jt + AHEAD) % NSLOT);
-            if (region & 1) gp_mfma_tile_bf16<KS, SPLIT, PF, F16, YEXACT>(a_of(jt % NSLOT), xb, acc, lane);
-            if (region & 2) gp_epilogue_scaled<decltype(kind)::value, PF>(view(jt % NSLOT), acc, half, sx, tx, au, at, ad, al);
+            constexpr int KIND = decltype(kind)::value;
+            if (region & 1) {
+                gp_mfma_tile_bf16<KS, SPLIT, PF, F16, YEXACT>(a_of(jt % NSLOT), xb, acc, lane);
+                if constexpr (EM && (KIND == 0 || KIND == 1 || KIND == 5)) {
+                    union {
+                        float2 f;
+                        h16x4 h;
+                    } ae;
+                    ae.f = reinterpret_cast<const float2 *>(lds + (jt % NSLOT) * STAGE + NPL * KS * 256)[lane];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) accE[r] = 0.0f;
+                    accE = __builtin_amdgcn_mfma_f32_32x32x8f16(ae.h, xe, accE, 0, 0, 0);
+                }
+            }
+            if (region & 2) {
+                if constexpr (EM) gp_epilogue_em<KIND, PF>(lds + (jt % NSLOT) * STAGE + NPL * KS * 256 + 128, acc, accE, half, sx, tx, au, at, ad, al);
+                else gp_epilogue_scaled<KIND, PF>(view(jt % NSLOT), acc, half, sx, tx, au, at, ad, al);
+            }
 #endif
             rendezvous(jt + AHEAD < n_tiles);
         };
@@ -325,6 +363,13 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 * BPC) void gp_eval_bf16_kernel(c
 
     // undo the exponent units (gp_common.hpp): dt = sum / sqrt(q), lap = sum / k1 - a d u
     const float s2 = g.sigma * g.sigma;
+    if constexpr (EM) {   // the EM epilogue carries E times 2^s
+        const float inv = g.escale[0];
+        au *= inv;
+        at *= inv;
+        ad *= inv;
+        al *= inv;
+    }
     const float u = au + __shfl_xor(au, 32);
     const float dt = (at + __shfl_xor(at, 32)) / sqrtf(qs);
     const float dv = ad + __shfl_xor(ad, 32);
