@@ -17,6 +17,10 @@
 // exactly fp16 -- the reference's deepxde float16 arrays are -- plane l_y is zero, so the l_y * h_x MFMA
 // and the staging of that plane are dropped (YEXACT): 2 MFMAs per K-step.
 //
+// In that case (fp16x2, YEXACT) the epilogue takes the bilinear part of E = e0 + eL Lh + et pp + cS ss from one extra
+// v_mfma_f32_32x32x8_f16 per tile (EM below; gp_common.hpp, gp_epilogue_em): 10 % fewer vector instructions in a kernel whose
+// vector ALUs are the busier pipe.
+//
 // Structure: workgroup of 8 waves, 32 points per wave held in VGPRs as 16-bit planes for the whole sweep; per
 // collocation tile one LDS slot [planes*KS KiB of A fragments | 2 KiB constants] filled two tiles ahead by
 // LDS-DMA; one barrier per tile.  The operands are scaled so that the product is the exponent of the kernel
