@@ -376,7 +376,9 @@ def main():
                     "flops_per_launch": flops, "achieved_vs_fp32_mfma_peak": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
                     "mfma_issued_tflops": round(issued, 1), "mfma_issued_frac": round(issued / peak, 4),
                     "note": "achieved = algorithmic fp32 flops (SURVEY 8(d)); the split-precision kernel issues %dx as many "
-                            "16-bit MFMA flops to keep products exact to 2^-22; the kernel is VALU-bound (valu_issue; DESIGN.md 4.2)" % products}
+                            "16-bit MFMA flops to keep products exact to 2^-22 (plus one K = 8 MFMA per tile for the bilinear part of the epilogue); "
+                            "the vector ALUs are the busier pipe and the chip holds ~1.55 GHz here against 2.1 in the path kernels "
+                            "(valu_issue; DESIGN.md 4.2)" % products}
     # the path kernels, priced with the materialised-state model of SURVEY.md 8(d): 16*d bytes per path-step
     path_ms = (kernel_ms.get("picard_generate") or 0.0) + (kernel_ms.get("picard_accumulate") or 0.0)
     path_roof = None
