@@ -24,11 +24,12 @@
 extern "C" {
 #endif
 
-#define SCASML_ABI_VERSION 2
+#define SCASML_ABI_VERSION 3
 #define SCASML_MAX_LEVEL 5   /* Picard level n <= 5 (kernels are instantiated per level)      */
 #define SCASML_MAX_Q 6       /* quadrature nodes per rule <= 6 (rho <= 5, solvers/MLP.py:132)  */
 #define SCASML_MAX_DIM 252   /* spatial dimension d <= 252 (one 4-dim quad per lane, +t, +3 spare columns) */
 #define SCASML_GP_TILE 32     /* collocation points per MFMA tile; n_pad is a multiple of it    */
+#define SCASML_NORMAL_TABLE_ROWS 768   /* rows (of 4 floats) of the inverse-normal-CDF table: 24 octaves x 32 segments */
 
 enum { SCASML_ERR_ARG = -1, SCASML_ERR_UNSUPPORTED = -2, SCASML_ERR_HIP = -3 };
 
@@ -143,9 +144,12 @@ int scasml_debug_normals(scasml_rng rng, uint32_t site, int32_t d, int64_t B, fl
 /* The normal transform on its whole input domain, for exhaustive parity tests: a normal is a function of the top 24 bits of
  * its Philox word;  out[i] = N(word = (k0 + i) << 8)  for i < n, k0 + n <= 2^24 (device pointer). */
 int scasml_debug_transform(uint32_t k0, int64_t n, float *out, void *stream);
-/* The 768 x 4 binary32 coefficients of the table-driven inverse normal CDF (csrc/normal_table.inc) -> HOST memory:
- * the specification of the normal transform as data, so that a second implementation can be checked against it. */
-int scasml_normal_table(float *table_h);
+/* The binary32 coefficients of the table-driven inverse normal CDF (csrc/normal_table.inc) -> HOST memory: the specification
+ * of the normal transform as data, so that a second implementation can be checked against it.  The table has
+ * scasml_normal_table_rows() (= SCASML_NORMAL_TABLE_ROWS) rows of 4 floats; the caller states how many rows table_h holds and a
+ * buffer that is too small is refused (ABI 2 copied the library's table into whatever it was given). */
+int32_t scasml_normal_table_rows(void);
+int scasml_normal_table(float *table_h, int32_t capacity_rows);
 
 /* ------------------------------------------------------------------ Gaussian process */
 
@@ -288,7 +292,9 @@ int scasml_gp_newton_jtv(int32_t eq_id, int32_t d, double sigma, double mu, cons
  *   idx_h   : the five Hutchinson indices, HOST int32[5], distinct, 0 <= i < d.  The reference draws them with
  *             random.choice(PRNGKey(0), d, (5,), replace=False) -- JAX threefry, not reproducible without JAX -- so they are
  *             an argument.  Index i differentiates along component i of the SHIFTED vector (original coordinate i+1).
- *   round16 : != 0 rounds every kernel entry to float16 (RNE) before it is stored / used.
+ *   round16 : bit 0 rounds every kernel entry to float16 (RNE) before it is stored / used; bit 1 (evaluation only) also returns
+ *             u_hat and eps_PDE as float16 values, as predict / compute_PDE_loss do (.astype(float16), models/GP.py:671, 769;
+ *             eps_PDE is then formed from the rounded u_hat).
  * scasml_gp_gram_compat   K(phi, phi), same block order as scasml_gp_gram              (models/GP.py:182-258)
  * scasml_round16_diag     A[i][i] = float16(A[i][i] + nugget): K_p as right_vector sees it   (:267-268, 599)
  * scasml_round16          v = float16(v) elementwise (time_der_rep(...).astype(float16), :719)
@@ -305,6 +311,30 @@ int scasml_gp_compat_pack(int32_t d, const float *x_dom, int32_t n_dom, const fl
 int scasml_gp_eval_compat(int32_t d, double a, double sigma_eq, double mu_eq, int32_t eq_id, const double *colloc_t, int32_t n_dom, int32_t n_bdy,
                           int64_t ldc, const double *rv, const int32_t *idx_h, int32_t round16, const float *points,
                           int64_t n_inf, int32_t kp, float *out4, float *lap, void *stream);
+/* Full gradient of the as-coded posterior mean, n_inf x (d+1), time last: GP.compute_gradient (:673-687) differentiates
+ * dot(kernel_x_t_phi_single(x), right_vector) by autodiff, i.e. THROUGH the float16 casts of the entries (a cast is the identity
+ * for the derivative), so the gradient is that of the unrounded shifted-Hutchinson features; round16 != 0 rounds the result
+ * (.astype(float16), :687). */
+int scasml_gp_gradient_compat(int32_t d, double a, const double *colloc_t, int32_t n_dom, int32_t n_bdy, int64_t ldc, const double *rv,
+                              const int32_t *idx_h, int32_t round16, const float *points, int64_t n_inf, int32_t kp, float *grad, void *stream);
+
+/* The same surrogate on the matrix cores -- the form the solvers use (csrc/gp_eval_compat_mfma.hip).  The three pair geometries
+ * (aligned, y shifted, x shifted) are one x.y product against three cyclic shifts of the collocation row, the 5-component
+ * Hutchinson sums one extra K = 16 product per geometry; entries are rounded with v_cvt_pk_f16_f32 from float32 values, so a
+ * rounding decision can differ from scasml_gp_eval_compat's float64 one where the value lies within ~2^-20 of a float16 midpoint.
+ * PRECONDITIONS: every collocation coordinate is exactly representable in float16 (the reference's deepxde float16 points are;
+ * the caller checks) and |x_k| <= x_bound (0 = 2.0) for every evaluation row, as for scasml_gp_model.split = 22.
+ *   scasml_gp_compat_model_floats  size of the packed model (floats) for n_pad = (n_dom + n_bdy) rounded up to SCASML_GP_TILE
+ *   scasml_gp_compat_pack_mfma     per (tile, geometry): fp16 A fragments of the shifted rows, the Hutchinson fragment, 8 row constants
+ *   scasml_gp_eval_compat_sites    out4 / lap as scasml_gp_eval_compat; rows_per_site / site_kinds as scasml_gp_eval_sites
+ *                                  (site_kinds may be NULL: every row gets everything).  A 128-row workgroup runs the geometries
+ *                                  its sites need: all three where eps_PDE is consumed, two where only u_hat (and div) are. */
+int64_t scasml_gp_compat_model_floats(int32_t d, int32_t n_pad);
+int scasml_gp_compat_pack_mfma(int32_t d, float a, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy,
+                               const double *rv, const int32_t *idx_h, float *model_out, void *stream);
+int scasml_gp_eval_compat_sites(int32_t d, float a, float sigma_eq, float mu_eq, int32_t eq_id, const float *model, int32_t n_dom,
+                                int32_t n_bdy, const int32_t *idx_h, int32_t round16, float x_bound, const float *points, int64_t n_inf,
+                                int64_t rows_per_site, const uint8_t *site_kinds, float *out4, float *lap, void *stream);
 
 /* ------------------------------------------------------------------ block-row distributed Gram / Cholesky / solves
  * For collocation sets whose K(phi, phi) does not fit one GPU (BASELINE configs[4]: 1e5 points, M = 350 000, 980 GB float64)

@@ -93,6 +93,41 @@ def sample_points(rng, d, n_dom, n_bdy, t0=0.0, T=0.5, radius=0.5):
     return dom.astype(np.float32), bdy.astype(np.float32)
 
 
+def deepxde_points(d, n_dom, n_bdy, t0=0.0, T=0.5, radius=0.5):
+    """deepxde's ``GeometryXTime.random_points`` / ``random_boundary_points`` for a Hypercube x TimeDomain geometry, call for call
+    on NumPy's GLOBAL generator, in float16 (``dde.config.set_default_float("float16")``, experiment_run.py:30) -- so that
+    ``np.random.seed(1234)`` (experiment_run.py:32) followed by this call is the reference's own training set, and the next call
+    (or ``np.random.seed(42 + i)`` first, RepeatedExperiment.py:63-64) its test set:
+      interior: the (d+1)-box in ONE draw, ``(xmax - xmin) * random((n, d+1)).astype(f16) + xmin``;
+      boundary: ``x = random((n, d)).astype(f16)``; ``rand_dim = randint(d, size=n)``; that coordinate rounded to 0 or 1;
+                ``(xmax - xmin) * x + xmin``; ``t = diam * random((n, 1)).astype(f16) + t0``, permuted.
+    Pinned by the reference's printed "Real Solution" (tests/test_reference_logs.py).  Returns float16 arrays."""
+    f16 = np.float16
+    lo = np.asarray([-radius] * d + [t0], dtype=f16)
+    hi = np.asarray([radius] * d + [T], dtype=f16)
+    dom = (hi - lo) * np.random.random(size=(n_dom, d + 1)).astype(f16) + lo
+    xb = np.random.random(size=(n_bdy, d)).astype(f16)
+    pick = np.random.randint(d, size=n_bdy)
+    xb[np.arange(n_bdy), pick] = np.round(xb[np.arange(n_bdy), pick])
+    xb = (hi[:d] - lo[:d]) * xb + lo[:d]
+    t = (f16(T - t0) * np.random.random(size=(n_bdy, 1)).astype(f16) + f16(t0)).astype(f16)
+    t = np.random.permutation(t)
+    return dom.astype(f16), np.hstack((xb, t)).astype(f16)
+
+
+def logistic_wave_f16(x_t):
+    """The reference's float16 evaluation of 1 - 1/(1 + exp(t + sum x)) (equations/equations.py:259-261, 317-323) on float16 rows:
+    the sum is accumulated in float32 and rounded once (jnp.sum), every other operation is rounded to float16."""
+    f16, f32 = np.float16, np.float32
+    x = np.asarray(x_t, dtype=f16)
+    s = x[:, :-1].astype(f32).sum(axis=1, dtype=f32).astype(f16)
+    arg = (x[:, -1].astype(f32) + s.astype(f32)).astype(f16)
+    with np.errstate(over="ignore"):                 # exp overflows float16 at t + sum x > 11.09 (inf, as in the reference): 1 - 1/(1 + inf) = 1
+        e = np.exp(arg.astype(f32)).astype(f16)
+    q = (f32(1) / (f32(1) + e.astype(f32)).astype(f16).astype(f32)).astype(f16)
+    return (f32(1) - q.astype(f32)).astype(f16)[:, None]
+
+
 def rel_l2(sol, exact):
     """tests/SimpleUniform.py:110-136: NaN-masked ||sol-exact||_2 / ||exact||_2."""
     sol = np.asarray(sol, dtype=np.float64).ravel()

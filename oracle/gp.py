@@ -111,10 +111,13 @@ class OracleGP:
         self.right_vector = np.linalg.solve(Kp, z)[:, None]  # :599-600
         return self.predict(self.x_t_domain)                # :602
 
+    def _g_boundary(self):
+        return self.eq.g(self.x_t_boundary)[:, 0]
+
     def _newton(self, A, GN_steps):
         """Newton iteration of models/GP.py:501-588 on J(sol) = b(sol)^T A b(sol); A = (L L^T)^-1."""
         M, N, Nb = self.phi_dim, self.N_domain, self.N_boundary
-        bdy_g = self._bdy_g = self.eq.g(self.x_t_boundary)[:, 0]          # :417-419
+        bdy_g = self._bdy_g = self._g_boundary()                           # :417-419
         d, s = self.d, self.sigma_eq
         r1, r3, r4, r5 = slice(0, N), slice(N + Nb, 2 * N + Nb), slice(2 * N + Nb, 3 * N + Nb), slice(3 * N + Nb, M)
         sol = np.zeros(3 * N)

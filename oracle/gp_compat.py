@@ -62,9 +62,11 @@ class OracleGPCompat(OracleGP):
 
     MC = 5                                            # models/GP.py:30
 
-    def __init__(self, eq, idx, round16=True, round_factor=True):
+    def __init__(self, eq, idx, round16=True, round_factor=True, round_out=None):
         super().__init__(eq)
         self.round_factor = bool(round_factor) and bool(round16)
+        # predict / compute_PDE_loss / compute_gradient return .astype(float16) (models/GP.py:671, 687, 769)
+        self.round_out = bool(round16) if round_out is None else bool(round_out)
         idx = np.asarray(idx, dtype=np.int64)
         if idx.shape != (self.MC,) or len(set(idx.tolist())) != self.MC or idx.min() < 0 or idx.max() >= self.d:
             raise ValueError("idx must be %d distinct indices in [0, d)" % self.MC)
@@ -123,6 +125,15 @@ class OracleGPCompat(OracleGP):
             P = -h * (2 * a * a * ri + (a * a * S)[:, :, None] - a ** 3 * S[:, :, None] * ri * ri).sum(2)
         return self._r(P * kap)
 
+    def _g_boundary(self):
+        """bdy_g = equation.g(x_bdy)[:, 0] (models/GP.py:417-419): on the reference's float16 boundary points the terminal condition
+        is its float16 graph (equations/equations.py:259-261), so the boundary data are float16 values."""
+        xb = self.x_t_boundary
+        if self.round16 and np.array_equal(xb, f16(xb)):
+            from .equation import logistic_wave_f16
+            return logistic_wave_f16(xb.astype(np.float16)).astype(np.float64)[:, 0]
+        return super()._g_boundary()
+
     # ---------------------------------------------------------------- factor (models/GP.py:258-268)
     def factor(self, K):
         """-> (A_loss, Kp_solve): the inverse the loss sees, (L16 L16^T)^-1, and the matrix
@@ -152,16 +163,54 @@ class OracleGPCompat(OracleGP):
         return self.predict(self.x_t_domain)
 
     # ---------------------------------------------------------------- inference
+    def _o(self, v):
+        return f16(v) if self.round_out else v
+
+    def predict(self, X):
+        """dot(kernel_x_t_phi_single(x), right_vector).astype(float16), models/GP.py:653-671."""
+        return self._o(super().predict(X))
+
+    def compute_PDE_loss(self, X):
+        """models/GP.py:746-769: the three operator rows are float64 products of float16 entries, ``sol`` is the float16 ``predict``,
+        and the combination is cast to float16."""
+        s = self.sigma_eq
+        dt, div, lap = self.pde_parts(X)
+        sol = self.predict(X)
+        return self._o(dt + self.eq.mu() * div + (s ** 2 / 2) * lap + self.eq.f_parts(sol, s * div)[0])
+
     def compute_gradient(self, X, sol=None):
-        """(n, d+1) array whose spatial columns SUM to div_x of the posterior mean (each holds div/d) and whose last
-        column is dt: all the solvers consume is sum_i z_i (f = sigma u sum z, equations.py:290-304), and the
-        per-coordinate gradient of the shifted Hutchinson features is not needed anywhere on the path."""
+        """(n, d+1) gradient of the posterior mean AS CODED, time derivative last (models/GP.py:673-687): autodiff of
+        dot(kernel_x_t_phi_single(x), right_vector) -- through the float16 casts of the entries (the identity for a derivative) and
+        through the shifted Hutchinson feature lap_y kappa(x, y') = h sg1 kappa1.  With r = x - y, r1 = x - y',
+        E0 = c0 + ct a r_t + cS a S, sg1 = sum_j (a^2 r1_{i_j}^2 - a):
+            d/dx_i = sum_j -a r_i kappa0 E0 + a kappa0 (ct [i = d] + cS [i < d]) + cL h kappa1 r1_i (2 a^2 [i in idx] - a sg1).
+        Its spatial columns sum to div_x_t_kernel_x_t_phi @ right_vector up to the entries' float16 rounding (tests check both)."""
         X = np.asarray(X, dtype=np.float64)
-        rv = self.right_vector
-        out = np.empty((X.shape[0], self.d + 1))
-        out[:, :self.d] = (self._features("div", X) @ rv) / self.d
-        out[:, self.d] = (self._features("dt", X) @ rv)[:, 0]
-        return out
+        a, d = self.a, self.d
+        h = d / float(self.MC)
+        dom, bdy = self.x_t_domain, self.x_t_boundary
+        N, Nb = self.N_domain, self.N_boundary
+        rv = self.right_vector[:, 0]
+        out = np.zeros((X.shape[0], d + 1))
+        inidx = np.zeros(d + 1)
+        inidx[self.idx] = 1.0
+        for Y, c0, cL, ct, cS in ((dom, rv[:N], rv[N + Nb:2 * N + Nb], rv[2 * N + Nb:3 * N + Nb], rv[3 * N + Nb:]),
+                                  (bdy, rv[N:N + Nb], None, None, None)):
+            kap0, _, S, rt = self._pairs(X, Y)
+            E0 = c0[None, :] + (0.0 if ct is None else ct[None, :] * a * rt + cS[None, :] * a * S)
+            al = -a * kap0 * E0                                              # multiplies r_i = x_i - y_i
+            out += X * al.sum(1)[:, None] - al @ Y
+            if ct is not None:
+                out[:, d] += (a * kap0 * ct[None, :]).sum(1)
+                out[:, :d] += (a * kap0 * cS[None, :]).sum(1)[:, None]
+                Ys = shift(Y)
+                kap1, _, _, ri = self._geom(X, Y, "ys")
+                sg1 = (a * a * ri * ri - a).sum(2)
+                dl = -a * h * cL[None, :] * kap1 * sg1                       # multiplies r1_i for every i
+                el = 2 * a * a * h * cL[None, :] * kap1                      # multiplies r1_i for i in idx
+                out += X * dl.sum(1)[:, None] - dl @ Ys
+                out += (X * el.sum(1)[:, None] - el @ Ys) * inidx[None, :]
+        return self._o(out)
 
     def div_x(self, X):
         """sum_{k<d} d/dx_k of the posterior mean = div_x_t_kernel_x_t_phi @ right_vector (:397-411)."""

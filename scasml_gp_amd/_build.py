@@ -8,7 +8,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libscasml_hip.so")
-SOURCES = ["abi.hip", "picard_tree.hip", "gp_eval.hip", "gp_eval_bf16.hip", "gp_train.hip", "gp_compat.hip", "dist_linalg.hip"]
+SOURCES = ["plan_host.cpp", "picard_tree.hip", "gp_eval.hip", "gp_eval_bf16.hip", "gp_train.hip", "gp_compat.hip", "gp_eval_compat_mfma.hip", "dist_linalg.hip"]
 # -ffp-contract=off: the RNG transform is specified in separately rounded IEEE mul/add
 # (philox_normal.hpp); every fused multiply-add elsewhere is written as fmaf() explicitly.
 # -fno-slp-vectorize: hipcc otherwise packs the scalar f32 epilogue into v_pk_fma_f32 / v_pk_mul_f32 plus
@@ -31,10 +31,12 @@ def build_library(force=False, verbose=False):
     objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        o = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+            # plan_host.cpp is plain C++ (host only): no offload flag, so nothing in it can depend on HIP
+            flags = FLAGS if src.endswith(".hip") else [f for f in FLAGS if not f.startswith("--offload-arch")]
+            jobs.append([hipcc] + flags + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

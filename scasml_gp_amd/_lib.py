@@ -8,7 +8,7 @@ MAX_Q = 6
 MAX_DIM = 252
 GP_TILE = 32
 DIST_BLOCK = 256
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 MODE_MLP, MODE_GENERATE, MODE_ACCUMULATE = 0, 1, 2
 RNG_COMPAT_CRN = 1
@@ -63,7 +63,8 @@ SIGNATURES = {
     "scasml_clip": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
     "scasml_debug_normals": (C.c_int, [Rng, C.c_uint32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "scasml_debug_transform": (C.c_int, [C.c_uint32, C.c_int64, C.c_void_p, C.c_void_p]),
-    "scasml_normal_table": (C.c_int, [C.c_void_p]),
+    "scasml_normal_table_rows": (C.c_int32, []),
+    "scasml_normal_table": (C.c_int, [C.c_void_p, C.c_int32]),
     "scasml_gp_plane_halfwords": (C.c_int64, [C.c_int32, C.c_int32]),
     "scasml_gp_coef_floats": (C.c_int64, [C.c_int32]),
     "scasml_gp_pack": (C.c_int, [C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
@@ -85,6 +86,13 @@ SIGNATURES = {
     "scasml_gp_compat_pack": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "scasml_gp_eval_compat": (C.c_int, [C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p,
                                         C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "scasml_gp_gradient_compat": (C.c_int, [C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
+                                            C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "scasml_gp_compat_model_floats": (C.c_int64, [C.c_int32, C.c_int32]),
+    "scasml_gp_compat_pack_mfma": (C.c_int, [C.c_int32, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]),
+    "scasml_gp_eval_compat_sites": (C.c_int, [C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                              C.c_int32, C.c_float, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "scasml_gp_gram_rows": (C.c_int, [C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int64,
                                       C.c_void_p, C.c_int64, C.c_void_p]),
     "scasml_gemm_nt_sub": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,

@@ -1,22 +1,10 @@
 // Shared host-side helpers of libscasml_hip.so: thread-local error string, HIP error mapping.
 #pragma once
 #include <hip/hip_runtime.h>
-#include <stdarg.h>
-#include <stdio.h>
 
-#include "scasml_hip.h"
+#include "host_common.hpp"
 
 namespace scasml {
-
-char *error_buffer();  // thread-local, 512 bytes (abi.hip)
-
-inline int fail(int code, const char *fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(error_buffer(), 512, fmt, ap);
-    va_end(ap);
-    return code;
-}
 
 inline int check_launch(const char *what) {
     const hipError_t e = hipGetLastError();

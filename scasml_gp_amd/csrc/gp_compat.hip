@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void gp_eval_compat_kernel(int d, double a, do
         PairGeom g;
         pair_geometry(d, a, ix, [&](int k) { return xs[k]; }, [&](int k) { return colloc_t[(int64_t)k * ldc + j]; }, g);
         double P[4][4];
-        compat_blocks(d, a, g, r16, P);
+        compat_blocks(d, a, g, r16 & 1, P);
         const double c0 = rv[j];
         double cL = 0.0, ct = 0.0, cS = 0.0;
         if (j < n_dom) {
@@ -204,10 +204,110 @@ __global__ __launch_bounds__(256) void gp_eval_compat_kernel(int d, double a, do
         for (int o = 32; o > 0; o >>= 1) acc[ox] += __shfl_xor(acc[ox], o);
     if (valid && lane == 0) {
         const double s2 = sigma * sigma;
-        const double u = acc[0], lp = acc[1], dt = acc[2], dv = acc[3];
-        const double eps = dt + mu * dv + 0.5 * s2 * lp + eq_f<double>(eq_id, u, sigma * dv, sigma, (double)d);   // models/GP.py:767-768
+        const double u = round16(acc[0], r16 & 2), lp = acc[1], dt = acc[2], dv = acc[3];                              // predict(...).astype(float16), models/GP.py:671
+        const double eps = round16(dt + mu * dv + 0.5 * s2 * lp + eq_f<double>(eq_id, u, sigma * dv, sigma, (double)d), r16 & 2);   // :767-769
         out4[row] = make_float4((float)u, (float)dv, (float)eps, (float)dt);
         if (lap_out) lap_out[row] = (float)lp;
+    }
+}
+
+// ---------------------------------------------------------------------------------- gradient (models/GP.py:673-687)
+// compute_gradient differentiates  u_hat(x) = dot(kernel_x_t_phi_single(x), right_vector)  by autodiff: through the float16 casts
+// (identity for the derivative) and through the shifted Hutchinson feature lap_y kappa(x, y') = h sg1 kappa1.  With r = x - y
+// (aligned), r1 = x - y' (y shifted), E0 = c0 + ct a r_t + cS a S:
+//   d u_hat / d x_i = sum_j  -a r_i kappa0 E0 + a kappa0 (ct [i = d] + cS [i < d])  +  cL h kappa1 r1_i (2 a^2 [i in idx] - a sg1).
+// One wavefront per point: lanes stride the collocation points for the pair scalars, then the coordinates for the d+1 sums.
+__global__ __launch_bounds__(256) void gp_gradient_compat_kernel(int d, double a, const double *colloc_t, int n_dom, int n_bdy, int64_t ldc,
+                                                                 const double *rv, CompatIdx ix, int r16, const float *points, int64_t n_inf,
+                                                                 int kp, float *grad) {
+    extern __shared__ double sh_all[];   // per wave: (d + 1) coordinates + 3 x 64 pair scalars
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int D = d + 1, N = n_dom + n_bdy;
+    int64_t row = (int64_t)blockIdx.x * 4 + wv;
+    const bool valid = row < n_inf;
+    if (!valid) row = n_inf - 1;
+    double *xs = sh_all + wv * (D + 192);
+    double *pa = xs + D, *pd = pa + 64, *pe = pd + 64;
+    for (int k = lane; k < D; k += 64) xs[k] = (double)points[row * kp + k];
+    __syncthreads();
+    const double h = (double)d / kMC, a2 = a * a;
+    double g[4] = {0.0, 0.0, 0.0, 0.0};          // coordinates lane, lane + 64, ...
+    double sA = 0.0, sB = 0.0, sC = 0.0, sD = 0.0, sE = 0.0;
+    for (int j0 = 0; j0 < N; j0 += 64) {
+        const int j = j0 + lane;
+        double al = 0.0, dl = 0.0, el = 0.0;
+        if (j < N) {
+            double r2 = 0.0, r2s = 0.0, S = 0.0;
+            for (int k = 0; k < D; ++k) {
+                const double yk = colloc_t[(int64_t)k * ldc + j], yn = colloc_t[(int64_t)(k + 1 < D ? k + 1 : 0) * ldc + j];
+                const double r = xs[k] - yk, rs = xs[k] - yn;
+                r2 = fma(r, r, r2);
+                r2s = fma(rs, rs, r2s);
+                if (k < d) S += r;
+            }
+            const double rt = xs[d] - colloc_t[(int64_t)d * ldc + j];
+            const double kap0 = exp(-0.5 * a * r2), kap1 = exp(-0.5 * a * r2s);
+            const double c0 = rv[j];
+            double cL = 0.0, ct = 0.0, cS = 0.0;
+            if (j < n_dom) {
+                cL = rv[(int64_t)N + j];
+                ct = rv[(int64_t)N + n_dom + j];
+                cS = rv[(int64_t)N + 2 * n_dom + j];
+            }
+            double sg1 = 0.0;
+#pragma unroll
+            for (int q = 0; q < kMC; ++q) {
+                const double r = xs[ix.i[q]] - colloc_t[(int64_t)(ix.i[q] + 1) * ldc + j];
+                sg1 += a2 * r * r - a;
+            }
+            const double E0 = c0 + ct * a * rt + cS * a * S;
+            al = -a * kap0 * E0;
+            dl = -a * h * cL * kap1 * sg1;
+            el = 2.0 * a2 * h * cL * kap1;
+            sA += al;
+            sB += a * kap0 * ct;
+            sC += a * kap0 * cS;
+            sD += dl;
+            sE += el;
+        }
+        pa[lane] = al;
+        pd[lane] = dl;
+        pe[lane] = el;
+        __syncthreads();
+        const int jn = N - j0 < 64 ? N - j0 : 64;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = lane + 64 * c;
+            if (i < D) {
+                bool in_idx = false;
+#pragma unroll
+                for (int q = 0; q < kMC; ++q) in_idx |= ix.i[q] == i;
+                const double *yi = colloc_t + (int64_t)i * ldc + j0, *ys = colloc_t + (int64_t)(i + 1 < D ? i + 1 : 0) * ldc + j0;
+                double acc = 0.0;
+                for (int jj = 0; jj < jn; ++jj) acc -= pa[jj] * yi[jj] + (pd[jj] + (in_idx ? pe[jj] : 0.0)) * ys[jj];
+                g[c] += acc;
+            }
+        }
+        __syncthreads();
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        sA += __shfl_xor(sA, o);
+        sB += __shfl_xor(sB, o);
+        sC += __shfl_xor(sC, o);
+        sD += __shfl_xor(sD, o);
+        sE += __shfl_xor(sE, o);
+    }
+    if (!valid) return;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int i = lane + 64 * c;
+        if (i < D) {
+            bool in_idx = false;
+#pragma unroll
+            for (int q = 0; q < kMC; ++q) in_idx |= ix.i[q] == i;
+            const double v = g[c] + xs[i] * (sA + sD + (in_idx ? sE : 0.0)) + (i < d ? sC : sB);
+            grad[row * D + i] = (float)round16(v, r16);
+        }
     }
 }
 
@@ -286,4 +386,21 @@ extern "C" int scasml_gp_eval_compat(int32_t d, double a, double sigma_eq, doubl
     hipLaunchKernelGGL(gp_eval_compat_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, d, a, sigma_eq, mu_eq, eq_id, colloc_t,
                        n_dom, n_bdy, ldc, rv, ix, round16, points, n_inf, kp, reinterpret_cast<float4 *>(out4), lap);
     return check_launch("gp_eval_compat launch");
+}
+
+extern "C" int scasml_gp_gradient_compat(int32_t d, double a, const double *colloc_t, int32_t n_dom, int32_t n_bdy, int64_t ldc, const double *rv,
+                                         const int32_t *idx_h, int32_t round16, const float *points, int64_t n_inf, int32_t kp, float *grad,
+                                         void *stream) {
+    if (n_inf == 0) return 0;
+    if (!colloc_t || !rv || !points || !grad || n_inf < 0) return fail(SCASML_ERR_ARG, "gp_gradient_compat: bad argument");
+    if (d < kMC || d > SCASML_MAX_DIM || n_dom < 1 || n_bdy < 0 || ldc < n_dom + n_bdy || kp < d + 1)
+        return fail(SCASML_ERR_ARG, "gp_gradient_compat: bad sizes");
+    CompatIdx ix;
+    if (int rc = check_idx(idx_h, d, ix, "gp_gradient_compat")) return rc;
+    const int64_t blocks = (n_inf + 3) / 4;
+    if (blocks > 0x7FFFFFFF) return fail(SCASML_ERR_UNSUPPORTED, "gp_gradient_compat: too many points");
+    const size_t lds = 4 * (size_t)(d + 1 + 192) * sizeof(double);
+    hipLaunchKernelGGL(gp_gradient_compat_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, d, a, colloc_t, n_dom, n_bdy, ldc, rv,
+                       ix, round16, points, n_inf, kp, grad);
+    return check_launch("gp_gradient_compat launch");
 }

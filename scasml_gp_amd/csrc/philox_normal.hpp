@@ -44,7 +44,7 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
 //
 // Round 2 until here used Box-Muller with Cephes ln / sin / cos polynomials (32 vector instructions per normal against 17 and
 // one LDS read): GENERATE was bound by them (1.34 ms; 0.89 ms with the transform ablated), 1.05 ms with the table.
-constexpr int kNormalTableRows = 768;
+constexpr int kNormalTableRows = SCASML_NORMAL_TABLE_ROWS;   // include/scasml_hip.h
 
 __device__ const float4 kNormalTable[kNormalTableRows] = {
 #include "normal_table.inc"

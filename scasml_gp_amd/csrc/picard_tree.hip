@@ -426,103 +426,6 @@ __global__ void debug_normals_kernel(uint32_t k0, uint32_t k1, uint32_t stream, 
 
 using namespace scasml;
 
-extern "C" int64_t scasml_points_per_root(const scasml_plan *plan_h) {
-    if (!plan_h || plan_h->n < 0 || plan_h->n > SCASML_MAX_LEVEL) return -1;
-    return (int64_t)plan_h->sites[plan_h->n] + 1;
-}
-
-// Site kinds in the kernels' enumeration order (terminal samples first, then per level / path / node the
-// Euler-Maruyama site followed by its child subtrees): 3 = terminal sample (only u_hat consumed, at t = T), 1 = only u_hat consumed (the root row),
-// 4 = Euler-Maruyama site of a level l > 0 term (u_hat and div u_hat consumed, eps_PDE not), 0 = everything consumed.
-static void site_kinds_rec(const scasml_plan *p, int n, uint8_t *&out) {
-    if (n == 0) return;
-    for (int m = 0; m < p->mg[n]; ++m) *out++ = 3;   // terminal samples: u_hat only, at t = T
-    for (int l = 0; l < n; ++l) {
-        const scasml_term &t = p->term[n][l];
-        for (int m = 0; m < t.mc; ++m)
-            for (int k = 0; k < t.q; ++k) {
-                *out++ = l > 0 ? 4 : 0;   // eps_PDE enters the sum only in the level-0 term (ScaSML.py:274-280)
-                site_kinds_rec(p, l, out);
-                if (l > 0) site_kinds_rec(p, l - 1, out);
-            }
-    }
-}
-
-// cost of the subtree of a level-n call, in the units of scasml_plan_deal_units (Euler-Maruyama site 1, terminal site 0.6)
-static double subtree_cost(const scasml_plan *p, int n) {
-    if (n == 0) return 0.0;
-    double c = 0.6 * p->mg[n];
-    for (int l = 0; l < n; ++l) {
-        const scasml_term &t = p->term[n][l];
-        c += (double)t.mc * t.q * (1.0 + subtree_cost(p, l) + (l > 0 ? subtree_cost(p, l - 1) : 0.0));
-    }
-    return c;
-}
-
-extern "C" int32_t scasml_plan_deal_units(const scasml_plan *plan_h, int32_t world, uint8_t *owner_h, int32_t capacity, double *load_h) {
-    if (!plan_h || !owner_h || plan_h->n < 1 || plan_h->n > SCASML_MAX_LEVEL) return fail(SCASML_ERR_ARG, "plan_deal_units: bad argument");
-    if (world < 1 || world > 255) return fail(SCASML_ERR_ARG, "plan_deal_units: world must be 1..255");
-    const int n = plan_h->n;
-    int64_t units = plan_h->mg[n];
-    for (int l = 0; l < n; ++l) units += plan_h->term[n][l].mc;
-    if (units > capacity) return fail(SCASML_ERR_ARG, "plan_deal_units: %lld units exceed the capacity %d", (long long)units, capacity);
-    // unit costs in enumeration order; the levels come in blocks of equal cost, the most expensive level last
-    double *cost = new double[units];
-    int64_t u = 0;
-    for (int m = 0; m < plan_h->mg[n]; ++m) cost[u++] = 0.6;
-    for (int l = 0; l < n; ++l) {
-        const scasml_term &t = plan_h->term[n][l];
-        const double c = t.q * (1.0 + subtree_cost(plan_h, l) + (l > 0 ? subtree_cost(plan_h, l - 1) : 0.0));
-        for (int m = 0; m < t.mc; ++m) cost[u++] = c;
-    }
-    double *load = new double[world]();
-    bool *done = new bool[units]();
-    for (int64_t k = 0; k < units; ++k) {           // longest processing time first (ties: lower unit index, lower rank)
-        int64_t best = -1;
-        for (int64_t i = 0; i < units; ++i)
-            if (!done[i] && (best < 0 || cost[i] > cost[best])) best = i;
-        int r = 0;
-        for (int j = 1; j < world; ++j)
-            if (load[j] < load[r]) r = j;
-        done[best] = true;
-        owner_h[best] = (uint8_t)r;
-        load[r] += cost[best];
-    }
-    if (load_h)
-        for (int j = 0; j < world; ++j) load_h[j] = load[j];
-    delete[] cost;
-    delete[] load;
-    delete[] done;
-    return (int32_t)units;
-}
-
-extern "C" int scasml_plan_site_kinds(const scasml_plan *plan_h, int32_t rank, int32_t world, const uint8_t *unit_owner_h, uint8_t *kinds_h) {
-    if (!plan_h || !kinds_h || plan_h->n < 0 || plan_h->n > SCASML_MAX_LEVEL) return fail(SCASML_ERR_ARG, "plan_site_kinds: bad argument");
-    if (world < 1 || rank < 0 || rank >= world) return fail(SCASML_ERR_ARG, "plan_site_kinds: bad rank/world");
-    uint8_t *w = kinds_h;
-    site_kinds_rec(plan_h, plan_h->n, w);
-    if (w - kinds_h != plan_h->sites[plan_h->n]) return fail(SCASML_ERR_ARG, "plan_site_kinds: plan.sites is inconsistent with its terms");
-    *w = 1;   // the root row (every rank evaluates it)
-    if (world > 1 && plan_h->n > 0) {   // units of the ROOT call, dealt exactly as Walker::owned() does
-        const int n = plan_h->n;
-        int unit = 0;
-        int64_t o = 0;
-        auto mine = [&](int un) { return unit_owner_h ? (int)unit_owner_h[un] == rank : un % world == rank; };
-        for (int m = 0; m < plan_h->mg[n]; ++m, ++unit, ++o)
-            if (!mine(unit)) kinds_h[o] = 2;
-        for (int l = 0; l < n; ++l) {
-            const scasml_term &t = plan_h->term[n][l];
-            const int64_t span = (int64_t)t.q * (1 + t.sites_l + t.sites_lm1);
-            for (int m = 0; m < t.mc; ++m, ++unit, o += span)
-                if (!mine(unit))
-                    for (int64_t k = 0; k < span; ++k) kinds_h[o + k] = 2;
-        }
-    }
-    return 0;
-}
-
-extern "C" int32_t scasml_point_stride(int32_t d) { return (d + 4 + 15) / 16 * 16; }
-
 extern "C" int scasml_picard_tree(const scasml_problem *prob, const scasml_plan *plan, int mode, const float *x_t,
                                   int64_t B, int64_t site_stride, scasml_rng rng, float *points, const float *gp_vals, float *out_uz,
                                   float *out_uhat, void *stream) {
@@ -613,17 +516,6 @@ extern "C" int scasml_debug_transform(uint32_t k0, int64_t n, float *out, void *
     if (n == 0) return 0;
     hipLaunchKernelGGL(debug_transform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, k0, n, out);
     return check_launch("debug_transform launch");
-}
-
-// the host's copy of the same rows (the .inc file is included twice: the kernels read kNormalTable)
-static const float kNormalTableHost[kNormalTableRows][4] = {
-#include "normal_table.inc"
-};
-
-extern "C" int scasml_normal_table(float *table_h) {
-    if (!table_h) return fail(SCASML_ERR_ARG, "normal_table: null argument");
-    memcpy(table_h, kNormalTableHost, sizeof(kNormalTableHost));
-    return 0;
 }
 
 extern "C" int scasml_debug_normals(scasml_rng rng, uint32_t site, int32_t d, int64_t B, float *out, void *stream) {

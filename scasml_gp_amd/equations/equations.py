@@ -59,6 +59,21 @@ class Equation(object):
         raise NotImplementedError
 
 
+def _logistic_wave_f16(x_t):
+    """1 - 1/(1 + exp(t + sum x)) for FLOAT16 rows exactly as the reference's jitted float16 graph evaluates it
+    (equations/equations.py:259, 317-322): jnp.sum accumulates float16 inputs in float32 and rounds once, every other operation is
+    a float16 operation (computed exactly, rounded to float16).  Pinned by the "Real Solution" value the reference printed:
+    ||exact||_2 / sqrt(n) of its test set agrees to all 16 digits at d = 20, 40, 60, 80 (tests/test_reference_logs.py)."""
+    f16, f32 = np.float16, np.float32
+    x = np.asarray(x_t, dtype=f16)
+    s = x[:, :-1].astype(f32).sum(axis=1, dtype=f32).astype(f16)
+    arg = (x[:, -1].astype(f32) + s.astype(f32)).astype(f16)
+    with np.errstate(over="ignore"):                 # exp overflows float16 at t + sum x > 11.09 (inf, as in the reference): 1 - 1/(1 + inf) = 1
+        e = np.exp(arg.astype(f32)).astype(f16)
+    q = (f32(1) / (f32(1) + e.astype(f32)).astype(f16).astype(f32)).astype(f16)
+    return (f32(1) - q.astype(f32)).astype(f16)[:, None]
+
+
 class _LogisticWave(Equation):
     """Shared by the registered equations: unit-cube geometry, terminal condition and closed-form solution
     1 - 1/(1 + exp(t + sum x)) (equations/equations.py:248-261, 306-323, 344-417), sigma = 0.25."""
@@ -69,6 +84,8 @@ class _LogisticWave(Equation):
         self.norm_estimation = 1         # :246
 
     def terminal_constraint(self, x_t):
+        if np.asarray(x_t).dtype == np.float16:       # the reference's own arrays (deepxde float16): its float16 graph, float16 out (:259-261)
+            return _logistic_wave_f16(x_t)
         x_t = np.asarray(x_t, dtype=np.float64)
         return (1 - 1 / (1 + np.exp(x_t[:, -1] + np.sum(x_t[:, :self.n_input - 1], axis=1))))[:, None]   # :259
 
@@ -86,6 +103,8 @@ class _LogisticWave(Equation):
         return -mu * z5 - (s ** 2 / 2) * z3 - f, (-fu, -(s ** 2 / 2) * np.ones_like(z1), -mu - s * fs)
 
     def exact_solution(self, x_t):
+        if np.asarray(x_t).dtype == np.float16:       # :317-323 on float16 rows: float16 out, as the harness receives it
+            return _logistic_wave_f16(x_t)
         x_t = np.asarray(x_t, dtype=np.float64)
         e = np.exp(x_t[:, -1] + np.sum(x_t[:, :-1], axis=1))       # :317-321
         return (1 - 1 / (1 + e))[:, None]
@@ -110,19 +129,28 @@ class _LogisticWave(Equation):
         return self
 
     def _sample(self, num_domain, num_boundary):
-        """Uniform interior points; boundary points = uniform in the cube with one random
-        coordinate snapped to a face, at a uniform random time (NumPy global RNG, as deepxde's
-        "pseudo" sampler; cast to float16 like dde's default float, experiment_run.py:30)."""
+        """deepxde's samplers restated call for call, so that -- NumPy's global generator being the
+        only source of randomness, ``sample(n, dim, "pseudo") = np.random.random((n, dim)).astype(float16)`` under
+        ``dde.config.set_default_float("float16")`` (experiment_run.py:30) -- a given ``np.random.seed`` yields the reference's
+        own points:
+        * ``GeometryXTime.random_points`` of a Hypercube geometry samples the (d+1)-dimensional box [xmin, t0] .. [xmax, T] in
+          ONE draw: ``(xmax - xmin) * sample(n, d + 1) + xmin``, float16 arithmetic;
+        * ``GeometryXTime.random_boundary_points``: ``Hypercube.random_boundary_points`` (``x = sample(n, d)``,
+          ``rand_dim = np.random.randint(d, size=n)``, that coordinate rounded to 0 or 1, then ``(xmax - xmin) * x + xmin``),
+          and ``TimeDomain.random_points`` (``diam * sample(n, 1) + l``) permuted by ``np.random.permutation``."""
         d = self.n_input - 1
-        lo, hi = self.geomx.lo, self.geomx.hi
-        dom = np.concatenate([np.random.random((num_domain, d)) * (hi - lo) + lo,
-                              np.random.permutation(np.random.random((num_domain, 1)) * (self.T - self.t0) + self.t0)], axis=1)
-        xb = np.random.random((num_boundary, d))
+        f16 = np.float16
+        lo = np.append(self.geomx.lo, self.t0).astype(f16)
+        hi = np.append(self.geomx.hi, self.T).astype(f16)
+        dom = (hi - lo) * np.random.random(size=(num_domain, d + 1)).astype(f16) + lo
+        xb = np.random.random(size=(num_boundary, d)).astype(f16)
         pick = np.random.randint(d, size=num_boundary)
         xb[np.arange(num_boundary), pick] = np.round(xb[np.arange(num_boundary), pick])
-        bdy = np.concatenate([xb * (hi - lo) + lo,
-                              np.random.permutation(np.random.random((num_boundary, 1)) * (self.T - self.t0) + self.t0)], axis=1)
-        return dom.astype(np.float16), bdy.astype(np.float16)
+        xb = (hi[:d] - lo[:d]) * xb + lo[:d]
+        t = (f16(self.T - self.t0) * np.random.random(size=(num_boundary, 1)).astype(f16) + f16(self.t0)).astype(f16)
+        t = np.random.permutation(t)
+        bdy = np.hstack((xb, t))
+        return dom.astype(f16), bdy.astype(f16)
 
     def generate_data(self, num_domain=100, num_boundary=20):
         self.geometry()                                             # :398-401

@@ -15,8 +15,12 @@ Two surrogates (``compat``):
 * ``"reference"``: the surrogate the reference's code actually builds: the 5-index
   Hutchinson "Laplacian" on a cyclically shifted argument (:28-39, 87-105, 119-179) with a caller-supplied index set
   (``laplacian_idx``; the reference's comes from JAX threefry), every kernel entry rounded to float16 (:43), K_p rounded
-  to float16 for the right_vector solve (:267-268, 599), z4 rounded to float16 (:719).  float64 kernels in
-  csrc/gp_compat.hip; CPU statement in oracle/gp_compat.py.
+  to float16 for the right_vector solve (:267-268, 599), z4 rounded to float16 (:719), u_hat and eps_PDE returned as float16
+  values (:671, 769).  Evaluation runs on the matrix cores (csrc/gp_eval_compat_mfma.hip: the three shifted geometries are one
+  x.y product against three cyclic shifts of the collocation rows) when the collocation points are exactly float16 -- the
+  reference's are -- and in float64 (csrc/gp_compat.hip, ``compat_eval = "float64"``) otherwise; Gram, gradient and the CPU
+  statement (oracle/gp_compat.py) are float64.  ``laplacian_idx`` may be the five indices or the name of the Threefry counter
+  layout ("original" / "partitionable") with which the reference's own draw is recomputed (scasml_gp_amd/threefry.py).
 Remaining deviations in both: Newton start at 0 instead of 1e-3*N(0,1) from PRNGKey(0) (:501); Cholesky instead of
 the SVD factor, so the float16 rounding of L itself (:266) has no counterpart (no measurable effect).
 """
@@ -41,6 +45,9 @@ class GP(object):
         self.compat = compat
         self.laplacian_idx = None
         if compat == "reference":
+            if isinstance(laplacian_idx, str):                   # the reference's own draw, models/GP.py:35
+                from ..threefry import reference_laplacian_idx
+                laplacian_idx = reference_laplacian_idx(equation.n_input - 1, laplacian_idx)
             idx = np.asarray(laplacian_idx if laplacian_idx is not None else [], dtype=np.int32).reshape(-1)
             if idx.size != 5 or len(set(idx.tolist())) != 5 or idx.min() < 0 or idx.max() >= equation.n_input - 1:
                 raise ValueError("compat='reference' needs laplacian_idx: five distinct indices in [0, d) "
@@ -60,6 +67,9 @@ class GP(object):
         # (products exact to fp32), 22 = two fp16 planes (22-bit products, half the MFMAs), 2 = two bf16
         # planes (~2^-16 per product), 0 = fp32-input MFMA
         self.eval_split = int(os.environ.get("SCASML_GP_SPLIT", "22"))
+        # compat="reference" evaluation kernel: "mfma" (matrix cores; needs float16-exact collocation points, else float64 is
+        # used) or "float64" (one wavefront per point, rounding decided exactly as the NumPy statement decides it)
+        self.compat_eval = os.environ.get("SCASML_GP_COMPAT_EVAL", "mfma")
         self.profile = False            # bench.py: HIP-event time of every training stage into self.stage_ms
         self.stage_ms = {}
 
@@ -120,7 +130,8 @@ class GP(object):
         back to the bf16 x 3 arithmetic instead of overflowing the fp16 planes."""
         torch = _lib.require_gpu()
         out = torch.empty((pts.shape[0], 4), dtype=torch.float32, device="cuda")
-        xb = float(pts.abs().max()) if pts.shape[0] and int(self.eval_split) == 22 and self.compat is None else 0.0
+        fp16_planes = (int(self.eval_split) == 22 and self.compat is None) or (self.compat == "reference" and self.compat_eval == "mfma")
+        xb = float(pts.abs().max()) if pts.shape[0] and fp16_planes else 0.0
         self._eval_rows(pts, pts.shape[0], 0, None, out, x_bound=max(xb, 2.0) if xb > 0 else 0.0)
         return out
 
@@ -131,10 +142,19 @@ class GP(object):
         if self.right_vector is None:
             raise _lib.ScasmlError("GP is not trained: call GPsolver(x_domain, x_boundary) first")
         if self.compat == "reference":
+            a = 1.0 / float(self.sigma) ** 2
+            xb = x_bound if x_bound > 0 else 2.0
+            if self.compat_eval == "mfma" and self._compat_model is not None and 0.7213 * a * xb * xb * (self.d + 1) <= 3.0e4:
+                _lib.check(lib.scasml_gp_eval_compat_sites(
+                    self.d, a, float(self.equation.sigma()), float(self.equation.mu()), int(self.equation.eq_id), _lib.ptr(self._compat_model),
+                    self.N_domain, self.N_boundary, self.laplacian_idx.ctypes.data_as(C.c_void_p), 3, float(x_bound), _lib.ptr(pts), n_rows,
+                    rows_per_site if kinds is not None else 0, _lib.ptr(kinds) if kinds is not None else None, _lib.ptr(out4), None,
+                    _lib.stream_ptr()), "gp_eval_compat_sites")
+                return
             N = self.N_domain + self.N_boundary
-            _lib.check(lib.scasml_gp_eval_compat(self.d, 1.0 / float(self.sigma) ** 2, float(self.equation.sigma()),
+            _lib.check(lib.scasml_gp_eval_compat(self.d, a, float(self.equation.sigma()),
                                                  float(self.equation.mu()), int(self.equation.eq_id), _lib.ptr(self._colloc_t), self.N_domain, self.N_boundary, N, _lib.ptr(self._rv_dev),
-                                                 self.laplacian_idx.ctypes.data_as(C.c_void_p), 1, _lib.ptr(pts), n_rows,
+                                                 self.laplacian_idx.ctypes.data_as(C.c_void_p), 3, _lib.ptr(pts), n_rows,
                                                  pts.shape[1], _lib.ptr(out4), None, _lib.stream_ptr()), "gp_eval_compat")
             return
         model = self._device_model(x_bound)
@@ -187,7 +207,12 @@ class GP(object):
         raise NotImplementedError
 
     def bdy_g(self, x_t_boundary):
-        return self.equation.g(x_t_boundary)[:, 0]                # models/GP.py:417-419
+        xb = np.asarray(x_t_boundary)
+        if self.compat == "reference" and np.array_equal(xb.astype(np.float16).astype(xb.dtype), xb):
+            xb = xb.astype(np.float16)      # the reference's boundary points are float16 arrays: g is then its float16 graph (equations.py:259-261)
+        else:
+            xb = xb.astype(np.float64)      # the documented operators: no float16 emulation anywhere
+        return np.asarray(self.equation.g(xb), dtype=np.float64)[:, 0]   # models/GP.py:417-419
 
     def time_der_rep(self, sol, rhs_f):
         raise NotImplementedError
@@ -293,6 +318,16 @@ class GP(object):
             _lib.check(lib.scasml_gp_compat_pack(self.d, _lib.ptr(self._xd), self.N_domain, _lib.ptr(self._xb), self.N_boundary,
                                                  _lib.ptr(self._colloc_t), N, _lib.stream_ptr()), "gp_compat_pack")
             self._rv_dev = rv.to(dtype=torch.float64).contiguous().clone()
+            # matrix-core form of the same surrogate: needs every collocation coordinate to be exactly float16
+            self._colloc_is_f16 = bool((self._xd.half().float() == self._xd).all()) and bool((self._xb.half().float() == self._xb).all())
+            self._compat_model = None
+            if self._colloc_is_f16:
+                n_pad = _round_up(N, _lib.GP_TILE)
+                self._compat_model = torch.empty((int(lib.scasml_gp_compat_model_floats(self.d, n_pad)),), dtype=torch.float32, device="cuda")
+                _lib.check(lib.scasml_gp_compat_pack_mfma(self.d, 1.0 / float(self.sigma) ** 2, _lib.ptr(self._xd), self.N_domain, _lib.ptr(self._xb),
+                                                          self.N_boundary, _lib.ptr(self._rv_dev), self.laplacian_idx.ctypes.data_as(C.c_void_p),
+                                                          _lib.ptr(self._compat_model), _lib.stream_ptr()), "gp_compat_pack_mfma")
+            torch.cuda.current_stream().synchronize()
             return
         kp = int(lib.scasml_point_stride(self.d))
         self._n_pad = _round_up(self.N_domain + self.N_boundary, _lib.GP_TILE)
@@ -362,11 +397,16 @@ class GP(object):
         '''(n, d+1) gradient of the posterior mean, time derivative last (models/GP.py:673-687).'''
         torch = _lib.require_gpu()
         lib = _lib.load()
-        if self.compat == "reference":
-            raise NotImplementedError("compat='reference': the per-coordinate gradient of the shifted Hutchinson features is not "
-                                      "built; the solvers use the spatial sum (column 1 of the fused evaluation)")
         pts, was_numpy = self._points_device(x_t_infer)
         grad = torch.empty((pts.shape[0], self.d + 1), dtype=torch.float32, device="cuda")
+        if self.compat == "reference":      # autodiff of the as-coded u_hat (through the float16 casts), result cast to float16 (:687)
+            if self.right_vector is None:
+                raise _lib.ScasmlError("GP is not trained: call GPsolver(x_domain, x_boundary) first")
+            N = self.N_domain + self.N_boundary
+            _lib.check(lib.scasml_gp_gradient_compat(self.d, 1.0 / float(self.sigma) ** 2, _lib.ptr(self._colloc_t), self.N_domain, self.N_boundary, N,
+                                                     _lib.ptr(self._rv_dev), self.laplacian_idx.ctypes.data_as(C.c_void_p), 1, _lib.ptr(pts),
+                                                     pts.shape[0], pts.shape[1], _lib.ptr(grad), _lib.stream_ptr()), "gp_gradient_compat")
+            return grad.cpu().numpy() if was_numpy else grad
         model = self._device_model()
         _lib.check(lib.scasml_gp_gradient(C.byref(model), _lib.ptr(pts), pts.shape[0], _lib.ptr(grad), _lib.stream_ptr()), "gp_gradient")
         return grad.cpu().numpy() if was_numpy else grad

@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_struct_layouts_and_version(lib):
-    assert lib.scasml_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.scasml_abi_version() == _lib.ABI_VERSION == 3
     for which, st in enumerate((_lib.Problem, _lib.Rng, _lib.Term, _lib.Plan, _lib.GpModel)):
         assert lib.scasml_sizeof(which) == C.sizeof(st)
     assert C.sizeof(_lib.Plan) < 3900          # travels by value in the kernarg segment (4 KiB)
@@ -76,10 +76,16 @@ def test_library_normal_table_equals_the_oracles_restatement(lib):
     """The normal transform's table is a committed constant of the library (csrc/normal_table.inc); the oracle restates its
     definition (oracle/philox.py normal_table).  Bit for bit, no GPU needed."""
     from oracle import philox
-    got = np.empty((768, 4), dtype=np.float32)
-    assert lib.scasml_normal_table(got.ctypes.data_as(C.c_void_p)) == 0
+    rows = lib.scasml_normal_table_rows()
+    assert rows == 768
+    got = np.empty((rows, 4), dtype=np.float32)
+    assert lib.scasml_normal_table(got.ctypes.data_as(C.c_void_p), rows) == 0
     assert np.array_equal(got.view(np.uint32), philox.normal_table().view(np.uint32))
-    assert lib.scasml_normal_table(None) == -1 and b"null" in lib.scasml_last_error()
+    assert lib.scasml_normal_table(None, rows) == -1 and b"null" in lib.scasml_last_error()
+    # a buffer that is too small is refused, not overrun (ABI 2 copied the whole table into whatever it was given)
+    small = np.full((rows, 4), 7.0, dtype=np.float32)
+    assert lib.scasml_normal_table(small.ctypes.data_as(C.c_void_p), rows - 1) == -1 and b"rows" in lib.scasml_last_error()
+    assert (small == 7.0).all()
 
 
 def test_stale_delta_t_schedule():

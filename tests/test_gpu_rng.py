@@ -30,8 +30,9 @@ def test_normal_transform_is_bit_identical_on_every_input():
     from oracle import philox
     from scasml_gp_amd import _lib
     lib = _lib.load()
-    table = np.empty((768, 4), dtype=np.float32)
-    _lib.check(lib.scasml_normal_table(table.ctypes.data_as(C.c_void_p)), "normal_table")
+    rows = lib.scasml_normal_table_rows()
+    table = np.empty((rows, 4), dtype=np.float32)
+    _lib.check(lib.scasml_normal_table(table.ctypes.data_as(C.c_void_p), rows), "normal_table")
     assert np.array_equal(table.view(np.uint32), philox.normal_table().view(np.uint32))
     n = 1 << 24
     out = torch.empty(n, dtype=torch.float32, device="cuda")

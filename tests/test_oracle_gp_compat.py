@@ -120,8 +120,34 @@ def test_factor_rounding_is_immaterial_and_K_stays_positive_definite():
     X = np.concatenate(sample_points(np.random.default_rng(8), d, 100, 30))
     preds = []
     for rf in (True, False):
-        gp = OracleGPCompat(GradDependentNonlinear(d + 1), idx, round16=True, round_factor=rf)
+        gp = OracleGPCompat(GradDependentNonlinear(d + 1), idx, round16=True, round_factor=rf, round_out=False)   # compare before the float16 cast of predict
         gp.GPsolver(dom, bdy, GN_steps=20)
         assert gp.K_eig_min > 0
         preds.append(gp.predict(X))
     assert np.abs(preds[0] - preds[1]).max() < 2e-4 * np.abs(preds[1]).max()
+
+
+def test_compat_gradient_is_the_derivative_of_the_as_coded_posterior_mean():
+    """compute_gradient (models/GP.py:673-687) is autodiff of dot(kernel_x_t_phi_single(x), right_vector): the oracle's closed form
+    against central differences of its own (unrounded) predict, and its spatial sum against the as-coded div row."""
+    rng = np.random.default_rng(21)
+    gp = _gp()
+    dom, bdy = sample_points(rng, D, 30, 9)
+    gp.x_t_domain, gp.x_t_boundary = dom.astype(np.float64), bdy.astype(np.float64)
+    gp.N_domain, gp.N_boundary, gp.phi_dim = 30, 9, 129
+    gp.right_vector = rng.normal(size=(129, 1))
+    X = rng.uniform(-0.5, 0.5, (11, D + 1))
+    got = gp.compute_gradient(X)
+    fd = np.zeros_like(got)
+    for i in range(D + 1):
+        e = np.zeros(D + 1)
+        e[i] = 1e-5
+        fd[:, i] = ((gp.predict(X + e) - gp.predict(X - e)) / 2e-5)[:, 0]
+    assert np.abs(got - fd).max() <= 1e-7 * max(1.0, np.abs(fd).max())
+    assert np.allclose(got[:, :D].sum(1), gp.div_x(X)[:, 0], rtol=1e-10, atol=1e-12)
+    assert np.allclose(got[:, D], gp.pde_parts(X)[0][:, 0], rtol=1e-10, atol=1e-12)
+    # with the float16 casts on, the result is a float16 value per coordinate (:687)
+    g16 = OracleGPCompat(GradDependentNonlinear(D + 1), IDX, round16=True)
+    g16.__dict__.update({k: v for k, v in gp.__dict__.items() if k not in ("round16", "round_out", "round_factor")})
+    r = g16.compute_gradient(X)
+    assert np.array_equal(r, f16(r)) and np.abs(r - got).max() <= 2.0 ** -11 * np.abs(got).max()

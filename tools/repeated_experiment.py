@@ -103,6 +103,35 @@ def run_case(d, train_seed, idx, reps, compat):
     return row
 
 
+# results/Grad_Dependent_Nonlinear/{d}d/SimpleUniform/SimpleUniform.log:4-6 (GP, MLP, SCaSML rel-L2 of the single run)
+LOGGED_SIMPLE = {20: (0.1466, 0.1604, 0.0701), 40: (0.1810, 0.2059, 0.0932), 60: (0.2401, 0.2521, 0.1356), 80: (0.2660, 0.2709, 0.1609)}
+
+
+def run_simple_uniform(d, idx, seed=1234):
+    """tests/SimpleUniform.py:46-136: ONE generator stream -- np.random.seed(1234) (experiment_run.py:32), the training set, then
+    the test set without reseeding."""
+    from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
+    from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
+    from scasml_gp_amd.solvers.MLP import MLP
+    from scasml_gp_amd.solvers.ScaSML import ScaSML
+    np.random.seed(seed)
+    eq = Grad_Dependent_Nonlinear(d + 1)
+    gp = GP_Grad_Dependent_Nonlinear(eq, compat="reference", laplacian_idx=idx)
+    dom, bdy = eq.generate_data(1000, 200)
+    gp.GPsolver(dom, bdy)                                   # SimpleUniform.py:81 (GN_steps default 20)
+    xt = np.concatenate(eq.generate_test_data(1000, 200), axis=0)
+    exact = eq.exact_solution(xt)
+    sols = {"GP": gp.predict(xt), "MLP": MLP(eq, compat_crn=True).u_solve(2, 2, xt), "ScaSML": ScaSML(eq, gp, compat_crn=True).u_solve(2, 2, xt)}
+    m = metrics(sols, exact)
+    e = np.asarray(exact, np.float64).ravel()
+    diff = np.asarray(sols["GP"], np.float64).ravel() - e
+    pde = np.asarray(gp.compute_PDE_loss(xt), np.float64)                       # SimpleUniform.py:139-141, 412-414
+    stats = lambda v: {"min": float(v.min()), "max": float(v.max()), "mean": float(v.mean()), "std": float(v.std())}
+    return {"protocol": "SimpleUniform", "d": d, "seed": seed, "idx": [int(i) for i in idx],
+            "rel_l2": {k: round(m[k][2], 5) for k in sols}, "logged": dict(zip(("GP", "MLP", "ScaSML"), LOGGED_SIMPLE.get(d, (None,) * 3))),
+            "real_solution": float(np.linalg.norm(e) / np.sqrt(e.size)), "pde_loss": stats(pde), "gp_l1": stats(np.abs(diff)), "gp_l2": stats(diff ** 2)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dims", type=int, nargs="+", default=[20, 40, 60, 80])
@@ -110,13 +139,26 @@ def main():
     ap.add_argument("--compat", choices=["reference"], default=None)
     ap.add_argument("--idx-sets", type=int, default=8, help="random Hutchinson index sets per training set (--compat reference)")
     ap.add_argument("--train-seeds", type=int, nargs="+", default=[1234])
+    ap.add_argument("--idx-mode", choices=["random", "original", "partitionable"], default="random",
+                    help="Hutchinson index set: random sets, or the reference's own draw choice(PRNGKey(0), d, (5,)) under either "
+                         "Threefry counter layout (scasml_gp_amd/threefry.py)")
+    ap.add_argument("--simple-uniform", action="store_true", help="also run tests/SimpleUniform.py's single-stream protocol (seed 1234)")
     args = ap.parse_args()
 
+    if args.simple_uniform:
+        from scasml_gp_amd.threefry import reference_laplacian_idx
+        for d in args.dims:
+            idx = reference_laplacian_idx(d, args.idx_mode) if args.idx_mode != "random" else np.random.default_rng(1000).choice(d, 5, replace=False)
+            print(json.dumps(run_simple_uniform(d, idx)), flush=True)
     summary = []
     for d in args.dims:
         rows = []
         for ts in args.train_seeds:
-            if args.compat:
+            if args.compat and args.idx_mode != "random":
+                from scasml_gp_amd.threefry import reference_laplacian_idx
+                rows.append(run_case(d, ts, reference_laplacian_idx(d, args.idx_mode), args.reps, True))
+                print(json.dumps(rows[-1]), flush=True)
+            elif args.compat:
                 rng = np.random.default_rng(1000 + ts)
                 for _ in range(args.idx_sets):
                     rows.append(run_case(d, ts, rng.choice(d, 5, replace=False), args.reps, True))
