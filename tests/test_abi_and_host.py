@@ -140,7 +140,12 @@ def test_equation_surface_and_sampler():
     assert dom.dtype == np.float16 and dom.shape == (50, 21) and bdy.shape == (20, 21)
     assert (np.abs(bdy[:, :-1]).max(axis=1) == 0.5).all() and (bdy[:, -1] >= 0).all() and (bdy[:, -1] <= 0.5).all()
     ora = GradDependentNonlinear(21)
-    assert np.allclose(eq.exact_solution(dom), ora.exact_solution(dom)) and np.allclose(eq.g(bdy), ora.g(bdy))
+    d64, b64 = dom.astype(np.float64), bdy.astype(np.float64)
+    assert np.allclose(eq.exact_solution(d64), ora.exact_solution(d64)) and np.allclose(eq.g(b64), ora.g(b64))
+    # float16 rows in, float16 values out -- the reference's own float16 graph (equations/equations.py:259-261, 317-323)
+    from oracle.equation import logistic_wave_f16
+    assert eq.exact_solution(dom).dtype == np.float16 and np.array_equal(eq.exact_solution(dom), logistic_wave_f16(dom))
+    assert np.array_equal(eq.g(bdy), logistic_wave_f16(bdy)) and np.abs(eq.g(bdy).astype(np.float64) - ora.g(b64)).max() < 2e-3
     u, z = np.random.rand(50, 1), np.random.rand(50, 20)
     assert np.allclose(eq.f(dom, u, z), ora.f(dom, u, z)) and eq.mu() == ora.mu()
     with pytest.raises(NotImplementedError):
