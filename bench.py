@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--M", type=int, default=3, help="sample base of the full-history solvers")
     ap.add_argument("--train-domain", type=int, default=1000)
     ap.add_argument("--train-boundary", type=int, default=200)
+    ap.add_argument("--compat", choices=["reference", "none"], default="reference",
+                    help="reference (default): the surrogate the reference's code builds (shifted 5-index Hutchinson features, float16 entries; "
+                         "GP(compat='reference'), matrix-core kernel gp_eval_compat_mfma); none: the operators it documents (gp_eval_bf16)")
     ap.add_argument("--cpu-sample", type=int, default=64, help="roots of the same workload timed on the CPU oracle")
     ap.add_argument("--shard", choices=["roots", "samples"], default="roots",
                     help="roots: each rank its own B roots, no collective (weak scaling, default); samples: every rank the same "
@@ -71,40 +74,71 @@ def rel_l2(sol, exact):
 
 def cpu_baseline(args, eq, gp, eng, n, par, x_t, x_dev, x_dom, x_bdy, steps_exec, B):
     """Time the oracle restatement (NumPy float64) on a bounded sample of the same workload, same inputs and
-    Philox streams, and report the GPU-vs-CPU difference on that sample."""
+    Philox streams, and report the GPU-vs-CPU difference on that sample: the relative L2 error of both against the exact
+    solution (tests/SimpleUniform.py:134-136) and their difference (north_star: within 1e-3)."""
     from oracle.equation import GradDependentNonlinear
     from oracle.gp import OracleGP
+    from oracle.gp_compat import OracleGPCompat
     from oracle.mlp import PicardOracle
     d = args.d
     oeq = GradDependentNonlinear(d + 1)
     ogp = None
     if gp is not None:
-        ogp = OracleGP(oeq)
+        ogp = OracleGPCompat(oeq, gp.laplacian_idx, round_factor=False) if gp.compat == "reference" else OracleGP(oeq)
         ogp.x_t_domain = np.asarray(x_dom, dtype=np.float64)     # same trained surrogate as the GPU run
         ogp.x_t_boundary = np.asarray(x_bdy, dtype=np.float64)
         ogp.N_domain, ogp.N_boundary = len(x_dom), len(x_bdy)
+        ogp.phi_dim = 4 * len(x_dom) + len(x_bdy)
         ogp.right_vector = gp.right_vector
-    ns = min(args.cpu_sample if gp is not None else 4096 * args.cpu_sample, B)   # ~10-20 s of CPU work either way
+    ns = min(args.cpu_sample if gp is not None else 4096 * args.cpu_sample, B)   # ~10-30 s of CPU work either way
     ora = PicardOracle(oeq, args.variant, gp=ogp, seed=0, stream=99)
     t0 = time.perf_counter()
     uz_cpu = ora.uz_solve(n, par, x_t[:ns])
     t_cpu = time.perf_counter() - t0
-    uz_gpu, _, _ = eng.solve(n, par, x_dev[:ns], stream_id=99)
+    uz_gpu, uhat_gpu, _ = eng.solve(n, par, x_dev[:ns], stream_id=99)
+    uz_gpu = uz_gpu.cpu().numpy().astype(np.float64)
+    u_cpu, u_gpu = uz_cpu[:, 0], uz_gpu[:, 0]
+    if gp is not None:                                     # u_solve = u_hat + u_breve (ScaSML.py:300-304)
+        u_cpu = u_cpu + ogp.predict(np.asarray(x_t[:ns], dtype=np.float64))[:, 0]
+        u_gpu = u_gpu + uhat_gpu.cpu().numpy().astype(np.float64)
+    exact = oeq.exact_solution(np.asarray(x_t[:ns], dtype=np.float64))[:, 0]
+    rel_cpu, rel_gpu = rel_l2(u_cpu, exact), rel_l2(u_gpu, exact)
     try:
         from threadpoolctl import threadpool_info
         threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
     except Exception:
         threads = os.cpu_count()
+    diff = np.abs(uz_gpu - uz_cpu)
     return {"value": round(ns * steps_exec / t_cpu, 1), "unit": "path-steps/s", "cores": threads, "kind": "port",
             "sample": "%d of the %d roots, same inputs and Philox streams, NumPy float64 oracle (oracle/mlp.py%s), %.1f s"
-                      % (ns, B, " + oracle/gp.py" if gp is not None else "", t_cpu),
-            "max_abs_diff_gpu_vs_cpu": float(np.nanmax(np.abs(uz_gpu.cpu().numpy() - uz_cpu)))}
+                      % (ns, B, (" + oracle/gp_compat.py" if gp.compat == "reference" else " + oracle/gp.py") if gp is not None else "", t_cpu),
+            "rel_l2_gpu": round(rel_gpu, 6), "rel_l2_cpu": round(rel_cpu, 6), "abs_diff": round(abs(rel_gpu - rel_cpu), 7),
+            "abs_diff_bound_north_star": 1e-3,
+            "max_abs_diff_u": float(np.nanmax(diff[:, 0])), "max_abs_diff_uz": float(np.nanmax(diff)),
+            "frac_elements_beyond_1e-4": round(float((diff > 1e-4).mean()), 5),
+            "note": "uz is clipped to +-%g; with the as-coded surrogate u_hat and eps_PDE are float16 VALUES, so one kernel entry whose float16 "
+                    "rounding is decided on a float32 value here and a float64 value there moves u_hat by a float16 ulp (2.4e-4..4.9e-4) and a z "
+                    "component by that times N / (MC delta_t)" % float(eng.problem().clip) if (gp is not None and gp.compat == "reference") else None}
+
+
+def kernel_source_sha1(files):
+    """Hash of the sources a kernel is built from: PMC summaries under profiles/ carry the hash of the code they were taken on, and
+    a summary of other code is not quoted."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in files:
+        h.update(open(os.path.join(ROOT, "scasml_gp_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
+GP_EVAL_SOURCES = {"reference": ["gp_eval_compat_mfma.hip", "gp_mfma16.hpp", "gp_common.hpp"], "none": ["gp_eval_bf16.hip", "gp_mfma16.hpp", "gp_common.hpp"]}
+PICARD_SOURCES = ["picard_tree.hip", "philox_normal.hpp", "equations.hpp"]
 
 
 FP64_MFMA_PEAK_TFLOPS = 78.6    # v_mfma_f64_16x16x4_f64 dense, MI355X_MICROARCH.md / SURVEY.md 8(d)
 
 
-def gp_train_block(d, n_dom, n_bdy):
+def gp_train_block(d, n_dom, n_bdy, compat=None):
     """GP training stages (models/GP.py:182-268, 487-604) with their rooflines: Gram, Cholesky (M^3/3 flop), K_p^-1 from the
     factor (2 M^3 / 3), the Newton iteration; HIP events per stage."""
     import torch
@@ -117,7 +151,7 @@ def gp_train_block(d, n_dom, n_bdy):
     np.random.set_state(st)
     out = None
     for rep in range(2):                                  # first pass warms code objects and the allocator
-        gp = GP_Grad_Dependent_Nonlinear(eq)
+        gp = GP_Grad_Dependent_Nonlinear(eq, compat=compat)
         gp.profile = rep == 1
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -131,7 +165,7 @@ def gp_train_block(d, n_dom, n_bdy):
             inv_tf = 2.0 * M ** 3 / 3.0 / (ms["inverse"] * 1e-3) / 1e12
             N = n_dom + n_bdy
             gram_tf = (2.0 * N * N * (d + 1) + 8.0 * M * M) / (ms["gram"] * 1e-3) / 1e12
-            out = {"d": d, "collocation": "%d+%d" % (n_dom, n_bdy), "M": M, "K_gb_f64": round(M * M * 8 / 1e9, 2), "fit_s": round(fit_s, 3),
+            out = {"d": d, "collocation": "%d+%d" % (n_dom, n_bdy), "surrogate": "as coded (compat='reference')" if compat else "documented operators", "M": M, "K_gb_f64": round(M * M * 8 / 1e9, 2), "fit_s": round(fit_s, 3),
                    "newton_steps": len(gp.loss_history) - 1,
                    "gram_ms": round(ms["gram"], 3), "gram_tflops": round(gram_tf, 2),
                    "cholesky_ms": round(ms["cholesky"], 3), "cholesky_tflops": round(chol_tf, 2),
@@ -214,11 +248,12 @@ def main():
     state = np.random.get_state()
     np.random.set_state(rs.get_state())
     x_dom, x_bdy = eq.generate_data(args.train_domain, args.train_boundary)
-    xt_h = np.concatenate(eq.generate_test_data(1000, 200)).astype(np.float32)   # harness test set
+    xt_h = np.concatenate(eq.generate_test_data(1000, 200))   # harness test set (float16, the stream continues: tests/SimpleUniform.py:75-86)
     np.random.set_state(state)
     gp, t_train = None, 0.0
     if args.solver == "scasml":
-        gp = GP_Grad_Dependent_Nonlinear(eq)
+        compat = "reference" if args.compat == "reference" else None
+        gp = GP_Grad_Dependent_Nonlinear(eq, compat=compat)      # reference: its own Hutchinson index draw (threefry.py)
         t0 = time.time()
         gp.GPsolver(x_dom, x_bdy, GN_steps=20)
         torch.cuda.synchronize()
@@ -333,17 +368,20 @@ def main():
     gp_ms = kernel_ms.get("gp_eval")
     traffic, traffic_source, issue = None, None, None
     # HBM bytes and issue-slot counters per launch come from separate rocprofv3 --pmc passes of this same command, condensed
-    # by profiles/summarize.py (they cannot be collected inside this process): NOT measured in this run, and labelled so
+    # by profiles/summarize.py (they cannot be collected inside this process): NOT measured in this run, labelled so, and quoted
+    # only if they were taken on the SAME kernel source (sha1 of the files the kernel is built from)
+    gp_sha = kernel_source_sha1(GP_EVAL_SOURCES[args.compat]) if gp is not None else None
     for prof in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gp_eval_pmc.json")), reverse=True):
         try:
             pj = json.load(open(prof))
-            if gp is not None and pj.get("n_inf") == n_inf and pj.get("d") == d and pj.get("split") == int(gp.eval_split):
+            if gp is not None and pj.get("n_inf") == n_inf and pj.get("d") == d and pj.get("source_sha1") == gp_sha:
                 traffic = pj.get("hbm_bytes_per_launch")
-                traffic_source = "%s (separate rocprofv3 --pmc passes of this command; FETCH_SIZE doubled per MI355X_MICROARCH.md)" % os.path.relpath(prof, ROOT)
+                traffic_source = "%s (separate rocprofv3 --pmc passes of this command on this kernel source; FETCH_SIZE doubled per MI355X_MICROARCH.md)" % os.path.relpath(prof, ROOT)
                 if pj.get("valu_active_frac") is not None:
                     issue = {"valu_active_frac": round(pj["valu_active_frac"], 3), "mfma_pipe_busy_frac": round(pj["mfma_pipe_busy_frac"], 3),
                              "coexec_frac_of_mfma_busy": round(pj["coexec_frac_of_mfma_busy"], 3),
                              "cycles_per_valu_instruction": round(pj["cycles_per_valu_instruction"], 2),
+                             "effective_clock_ghz": round(pj.get("effective_clock_ghz", 0.0), 3),
                              "source": os.path.relpath(prof, ROOT), "note": "the kernel is VALU-bound: the vector ALUs are busy this "
                              "fraction of the launch; the MFMA fraction quoted as `frac` is of a roof the kernel is not under"}
                 break
@@ -362,23 +400,43 @@ def main():
                             "its real traffic is the root rows in and out, and it is Philox/ALU-bound"}
     if gp_ms:
         ach = flops / (gp_ms * 1e-3) / 1e12
-        split = int(gp.eval_split)
         from scasml_gp_amd import _lib
         kp = int(_lib.load().scasml_point_stride(d))       # the kernels' padded row length (round_up(d + 4, 16))
         n_pad = (n_colloc + 31) // 32 * 32
-        products = {0: 1, 2: 3, 3: 6, 22: 2 if getattr(gp, "_colloc_is_f16", False) else 3}[split]
-        issued = products * 2.0 * n_inf * n_pad * kp / (gp_ms * 1e-3) / 1e12      # MFMA flops actually issued
-        peak = MFMA_F32_PEAK_TFLOPS if split == 0 else MFMA_BF16_PEAK_TFLOPS
-        roofline = {"kernel": "gp_eval_kernel (fp32 MFMA)" if split == 0 else ("gp_eval_bf16_kernel (2 fp16 planes, exponent-unit epilogue)" if split == 22 else "gp_eval_bf16_kernel (%d bf16 planes)" % split),
-                    "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_source, "valu_issue": issue,
-                    "avg_launch_ms": round(gp_ms, 4),
-                    "flops_per_launch": flops, "achieved_vs_fp32_mfma_peak": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
-                    "mfma_issued_tflops": round(issued, 1), "mfma_issued_frac": round(issued / peak, 4),
-                    "note": "achieved = algorithmic fp32 flops (SURVEY 8(d)); the split-precision kernel issues %dx as many "
-                            "16-bit MFMA flops to keep products exact to 2^-22 (plus one K = 8 MFMA per tile for the bilinear part of the epilogue); "
-                            "the vector ALUs are the busier pipe and the chip holds ~1.55 GHz here against 2.1 in the path kernels "
-                            "(valu_issue; DESIGN.md 4.2)" % products}
+        if gp.compat == "reference":
+            # issued 16-bit MFMA flops: per point and geometry two planes of (n_pad x kp) plus one K = 16 Hutchinson product; sites that
+            # consume eps_PDE run three geometries on domain tiles and two on boundary tiles, the others two and one
+            kinds = eng.site_kinds(n, par).cpu().numpy()
+            n_full, n_part = int((kinds == 0).sum()) * B, int(np.isin(kinds, (1, 3, 4)).sum()) * B
+            nd_pad = (args.train_domain + 31) // 32 * 32
+            per_geom = lambda rows, q: 2.0 * rows * (2 * kp + (16 if q else 0))
+            issued_flops = n_full * (3 * per_geom(nd_pad, True) + 2 * per_geom(n_pad - nd_pad, True)) \
+                + n_part * (2 * per_geom(nd_pad, True) + per_geom(n_pad - nd_pad, False))
+            issued = issued_flops / (gp_ms * 1e-3) / 1e12
+            peak = MFMA_BF16_PEAK_TFLOPS
+            roofline = {"kernel": "gp_eval_compat_mfma_kernel (as-coded surrogate: 3 shifted geometries x 2 fp16 planes, float16 entries)",
+                        "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                        "traffic": traffic, "traffic_source": traffic_source, "valu_issue": issue, "avg_launch_ms": round(gp_ms, 4),
+                        "flops_per_launch": flops, "mfma_issued_tflops": round(issued, 1), "mfma_issued_frac": round(issued / peak, 4),
+                        "note": "achieved = algorithmic flops of SURVEY 8(d) (2 N_inf N (d+1) + 10 N_inf M: ONE x.y product per pair); the as-coded "
+                                "surrogate needs three (aligned, y shifted, x shifted) in two fp16 planes each, and 13 separately float16-rounded "
+                                "entries per pair in the epilogue (~50 vector instructions + 3 exp against 14 + 1 for the documented operators): "
+                                "the kernel is bound by vector issue, not by the matrix pipe (valu_issue; DESIGN.md 4.4)"}
+        else:
+            split = int(gp.eval_split)
+            products = {0: 1, 2: 3, 3: 6, 22: 2 if getattr(gp, "_colloc_is_f16", False) else 3}[split]
+            issued = products * 2.0 * n_inf * n_pad * kp / (gp_ms * 1e-3) / 1e12      # MFMA flops actually issued
+            peak = MFMA_F32_PEAK_TFLOPS if split == 0 else MFMA_BF16_PEAK_TFLOPS
+            roofline = {"kernel": "gp_eval_kernel (fp32 MFMA)" if split == 0 else ("gp_eval_bf16_kernel (2 fp16 planes, exponent-unit epilogue)" if split == 22 else "gp_eval_bf16_kernel (%d bf16 planes)" % split),
+                        "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_source, "valu_issue": issue,
+                        "avg_launch_ms": round(gp_ms, 4),
+                        "flops_per_launch": flops, "achieved_vs_fp32_mfma_peak": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+                        "mfma_issued_tflops": round(issued, 1), "mfma_issued_frac": round(issued / peak, 4),
+                        "note": "achieved = algorithmic fp32 flops (SURVEY 8(d)); the split-precision kernel issues %dx as many "
+                                "16-bit MFMA flops to keep products exact to 2^-22 (plus one K = 8 MFMA per tile for the bilinear part of the epilogue); "
+                                "the vector ALUs are the busier pipe and the chip holds ~1.55 GHz here against 2.1 in the path kernels "
+                                "(valu_issue; DESIGN.md 4.2)" % products}
     # the path kernels, priced with the materialised-state model of SURVEY.md 8(d): 16*d bytes per path-step
     path_ms = (kernel_ms.get("picard_generate") or 0.0) + (kernel_ms.get("picard_accumulate") or 0.0)
     path_roof = None
@@ -387,27 +445,32 @@ def main():
     if path_ms:
         gbs = B * steps_exec * 16.0 * d / (path_ms * 1e-3) / 1e9
         path_roof = {"kernels": "picard_tree generate+accumulate", "bound": "hbm", "achieved": round(gbs, 2),
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                     "avg_launch_ms": round(path_ms, 4), "model": "16*d algorithmic bytes per path-step (SURVEY.md 8(d))"}
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "model_frac": round(gbs / HBM_PEAK_GBS, 4),
+                     "avg_launch_ms": round(path_ms, 4), "model": "16*d algorithmic bytes per path-step (SURVEY.md 8(d)): the materialised-state "
+                     "model counts X and W read and written per step; the kernels keep W in registers and move fewer real bytes, so model_frac "
+                     "overstates the HBM utilisation -- `frac` is real traffic (PMC) over peak"}
         # what the two kernels really move (rocprofv3 --pmc passes condensed by profiles/summarize.py; not measured in this run)
+        pic_sha = kernel_source_sha1(PICARD_SOURCES)
         for prof in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_picard_pmc.json")), reverse=True):
             try:
                 pj = json.load(open(prof))
-                real = sum(v["hbm_bytes_per_launch"] for v in pj.values() if v.get("grid_threads") in ((B * (int(kp_path) // 4) + 255) // 256 * 256, B * 32))
+                if pj.get("source_sha1") != pic_sha:
+                    continue
+                real = sum(v["hbm_bytes_per_launch"] for k, v in pj.items() if isinstance(v, dict) and v.get("grid_threads") in ((B * (int(kp_path) // 4) + 255) // 256 * 256, B * 32))
             except Exception:
                 continue
             if real:
                 path_roof.update({"traffic": real, "traffic_gb_per_s": round(real / (path_ms * 1e-3) / 1e9, 1),
-                                  "traffic_frac_of_hbm_peak": round(real / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                  "traffic_source": os.path.relpath(prof, ROOT)})
+                                  "frac": round(real / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                  "traffic_source": "%s (separate rocprofv3 --pmc passes on this kernel source)" % os.path.relpath(prof, ROOT)})
                 break
 
     # ---- GP training on record: the bench's own 1000 + 200 fit and the staged size of BASELINE configs[4] ----
     gp_train = None
     if world == 1 and gp is not None:
-        gp_train = [gp_train_block(d, args.train_domain, args.train_boundary)]
-        if not args.no_gp_train_large:
-            gp_train.append(gp_train_block(250, 8333, 1667))
+        gp_train = [gp_train_block(d, args.train_domain, args.train_boundary, gp.compat)]
+        if not args.no_gp_train_large:                       # staged configs[4]: the MFMA Gram exists for the documented operators
+            gp_train.append(gp_train_block(250, 8333, 1667, None))
 
     # ---- CPU baseline: the oracle restatement on a bounded sample of the same workload ----------
     cpu = None
@@ -425,10 +488,14 @@ def main():
         "value": round(value, 1), "unit": "path-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "weak" if main_step is roots_step else "strong", "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+        "rccl_note": "no multi-GPU node has been available to this build: the N > 1 path (init_process_group('nccl'), the in-group all-reduce) is "
+                     "rehearsed over gloo on one GPU only (tests/test_gpu_bench_contract.py) until a SCALE run exists",
         "backend": (dist.get_backend() if world > 1 else None), "samples_sharding": samples_leg,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "Grad_Dependent_Nonlinear d=%d, %s, B=%d roots/GPU%s" % (
                        d, name, B, " (BASELINE.json configs[2])" if (args.solver, args.variant, d, n) == ("scasml", "quad", 100, 3) else ""),
+                   "surrogate": ("reference's as-coded GP (compat='reference', Hutchinson indices %s)" % gp.laplacian_idx.tolist() if gp.compat == "reference"
+                                 else "documented operators (compat=None)") if gp is not None else None,
                    "roots_per_gpu": B, "gp_collocation": ("%d+%d" % (args.train_domain, args.train_boundary)) if gp is not None else None,
                    "path_steps_per_root": steps_exec, "path_steps_per_root_reference_count": steps_ref,
                    "gp_point_evals_per_root": ppr,
@@ -438,8 +505,9 @@ def main():
                            "performed); with the reference's own count the same run is value_reference_count"},
         "value_reference_count": round(work_ranks * B * steps_ref * args.steps / elapsed, 1),
         "l2_rel_error": {"solver_gpu": round(rel_gpu, 5), "gp_only": round(rel_gp, 5) if rel_gp is not None else None,
-                         "points": "1000+200 harness set",
-                         "logged_reference_d20": "0.069 (results/.../20d/RepeatedExperiment.log:21)"},
+                         "points": "1000+200 harness set (np.random.seed(1234): the training draw, then this one, as tests/SimpleUniform.py)",
+                         "vs_cpu_oracle": ({k: cpu[k] for k in ("rel_l2_gpu", "rel_l2_cpu", "abs_diff")} if cpu else None),
+                         "surrogate": ("as coded by the reference (compat='reference')" if gp.compat == "reference" else "documented operators (compat=None)") if gp is not None else None},
         "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
         "gp_train_s": round(t_train, 2),
         "roofline": roofline, "roofline_path": path_roof, "gp_train": gp_train, "cpu_baseline": cpu,

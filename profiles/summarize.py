@@ -19,6 +19,7 @@ import shutil
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
 
 
 def one(pattern):
@@ -51,7 +52,10 @@ def main():
     if pmc_dirs:
         big = max((k for k in groups if "gp_eval" in k[0]), key=lambda k: k[1])
         out = {"kernel": big[0], "grid_threads": big[1], "avg_ms_kernel_trace": sum(groups[big]) / len(groups[big])}
-        out.update({k: int(v) for k, v in extra.items()})
+        out.update({k: (int(v) if v.lstrip("-").isdigit() else v) for k, v in extra.items()})
+        # the code the counters were taken on: bench.py quotes a summary only for the same kernel sources
+        import bench
+        out["source_sha1"] = bench.kernel_source_sha1(bench.GP_EVAL_SOURCES["reference" if "compat" in big[0] else "none"])
         for d in pmc_dirs:
             for r in csv.DictReader(open(one(os.path.join(d, "*", "*_counter_collection.csv")))):
                 if r["Kernel_Name"] == big[0] and int(r["Grid_Size"]) == big[1]:
@@ -88,6 +92,7 @@ def main():
                 ent["hbm_frac_of_8tbs"] = ent["hbm_gb_per_s"] / 8000.0
             ent["counters_avg_per_launch"] = cnt
             pic[name] = ent
+        pic["source_sha1"] = bench.kernel_source_sha1(bench.PICARD_SOURCES)
         json.dump(pic, open(os.path.join(HERE, tag + "_picard_pmc.json"), "w"), indent=1)
 
 

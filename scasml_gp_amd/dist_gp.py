@@ -115,6 +115,7 @@ class DistCholesky:
         self.R = None
         self.diag = [None] * self.nblk          # replicated 256 x 256 diagonal factors
         self.info = torch.zeros(1, dtype=torch.int32, device="cuda")
+        self.bad = torch.zeros(1, dtype=torch.float64, device="cuda")   # blocks this rank found not positive definite (scasml_cholesky resets info per call)
 
     # -------------------------------------------------------------------------------------------- helpers
     def _slot0(self, k):
@@ -157,6 +158,7 @@ class DistCholesky:
                 slot = (k - rank) // w
                 Lkk.copy_(R[slot * BLK:(slot + 1) * BLK, k * BLK:(k + 1) * BLK])
                 _lib.check(lib.scasml_cholesky(_lib.ptr(Lkk), BLK, 0.0, _lib.ptr(self.info), s), "cholesky(diag)")
+                self.bad += (self.info != 0).to(torch.float64)                # accumulated on the device: no host read inside the loop
                 R[slot * BLK:(slot + 1) * BLK, k * BLK:(k + 1) * BLK] = Lkk
             cm.broadcast(Lkk, owner)
             self.diag[k] = Lkk
@@ -181,8 +183,11 @@ class DistCholesky:
                                                   self._ptr(R, s0 * BLK, k * BLK, Mp), Mp, _lib.ptr(P), BLK, BLK,
                                                   first, w, k + 1, s), "gemm_nt_sub")
             del P, got, send
-        if int(self.info.item()) != 0:
-            raise ValueError("distributed Cholesky: K + nugget I is not positive definite")
+        # a failed pivot is seen by the block's owner only: every rank learns of it through ONE all-reduce after the loop, so that all
+        # ranks raise together instead of the others walking into the collectives of solve() without the one that raised
+        failed = cm.all_reduce(self.bad.clone())
+        if float(failed.item()) != 0.0:
+            raise ValueError("distributed Cholesky: K + nugget I is not positive definite (%d diagonal block(s) failed)" % int(failed.item()))
         return self
 
     # -------------------------------------------------------------------------------------------- substitutions
@@ -261,6 +266,8 @@ class DistributedGP:
     right_vector (replicated, M doubles) and can hand it to GP.load_right_vector for the (root-sharded) evaluation."""
 
     def __init__(self, gp, comm=None):
+        if getattr(gp, "compat", None) is not None:
+            raise NotImplementedError("the distributed fit builds the documented operators (scasml_gp_gram_rows): construct the GP with compat=None")
         self.gp = gp
         self.comm = comm or Comm()
         self.cg_iterations = []

@@ -31,14 +31,37 @@ class Equation(object):
         self.n_input = n_input
         self.n_output = n_output
 
-    def f(self, x_t, u, z):
-        raise NotImplementedError
+    # the abstract surface of equations/equations.py:31-230: every method a subclass may define; the ones the solvers and the
+    # surrogate call (f, g / terminal_constraint, mu, sigma, exact_solution, geometry, generate_*) and the PINN-side ones the
+    # reference declares but this path never calls (PDE_loss, gPDE_loss, the other constraints, data_loss)
+    def PDE_loss(self, x_t, u, z):
+        raise NotImplementedError                      # :31-43
 
-    def g(self, x_t):
-        return self.terminal_constraint(x_t)          # equations.py:146-162
+    def gPDE_loss(self, x_t, u):
+        raise NotImplementedError                      # :45-56
 
     def terminal_constraint(self, x_t):
+        raise NotImplementedError                      # :58-68
+
+    def initial_constraint(self, x_t):
+        raise NotImplementedError                      # :70-80
+
+    def Dirichlet_boundary_constraint(self, x_t):
+        raise NotImplementedError                      # :82-92
+
+    def Neumann_boundary_constraint(self, x_t):
+        raise NotImplementedError                      # :94-104
+
+    def f(self, x_t, u, z):
+        raise NotImplementedError                      # :130-144
+
+    def g(self, x_t):
+        if hasattr(self, "terminal_constraint"):       # :146-162
+            return self.terminal_constraint(x_t)
         raise NotImplementedError
+
+    def data_loss(self, x_t):
+        raise NotImplementedError                      # :176-186
 
     def mu(self, x_t=0):
         raise NotImplementedError
@@ -51,6 +74,9 @@ class Equation(object):
 
     def geometry(self, t0=0, T=0.5):
         raise NotImplementedError
+
+    def test_geometry(self, t0=0, T=0.5):
+        raise NotImplementedError                      # :201-212
 
     def generate_data(self, num_domain=100, num_boundary=20):
         raise NotImplementedError

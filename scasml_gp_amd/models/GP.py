@@ -11,8 +11,8 @@ What runs where:
 * predict / compute_gradient / compute_PDE_loss (:653-687, 746-769) .. scasml_gp_eval, scasml_gp_gradient
 
 Two surrogates (``compat``):
-* ``None`` (default): the operators the reference documents -- exact Laplacian features, no float16 rounding.
-* ``"reference"``: the surrogate the reference's code actually builds: the 5-index
+* ``None``: the operators the reference documents -- exact Laplacian features, no float16 rounding.
+* ``"reference"`` (default): the surrogate the reference's code actually builds: the 5-index
   Hutchinson "Laplacian" on a cyclically shifted argument (:28-39, 87-105, 119-179) with a caller-supplied index set
   (``laplacian_idx``; the reference's comes from JAX threefry), every kernel entry rounded to float16 (:43), K_p rounded
   to float16 for the right_vector solve (:267-268, 599), z4 rounded to float16 (:719), u_hat and eps_PDE returned as float16
@@ -39,9 +39,17 @@ def _round_up(v, m):
 class GP(object):
     '''Gaussian Kernel Solver for high dimensional PDE'''
 
-    def __init__(self, equation, compat=None, laplacian_idx=None):
+    def __init__(self, equation, compat="reference", laplacian_idx="partitionable"):
+        """compat="reference" (default): the surrogate the reference's code builds, with its own Hutchinson index draw
+        (laplacian_idx: five indices, or the Threefry counter layout the draw is recomputed with -- "partitionable" reproduces the
+        reference's logged errors, "original" is jax < 0.5).  compat=None: the operators the reference documents."""
+        if compat == "exact":
+            compat = None
         if compat not in (None, "reference"):
-            raise ValueError("compat must be None or 'reference'")
+            raise ValueError("compat must be 'reference' or None")
+        if compat == "reference" and equation.n_input - 1 < 5:
+            raise ValueError("compat='reference' draws five distinct Hutchinson indices from d = %d < 5 coordinates (the reference's "
+                             "random.choice(..., replace=False) fails there too); use compat=None" % (equation.n_input - 1))
         self.compat = compat
         self.laplacian_idx = None
         if compat == "reference":
@@ -365,7 +373,7 @@ class GP(object):
         return {"n_input": np.int64(self.n_input), "x_t_domain": np.asarray(self.x_t_domain),
                 "x_t_boundary": np.asarray(self.x_t_boundary), "right_vector": np.asarray(self.right_vector),
                 "loss_history": np.asarray(getattr(self, "loss_history", []), dtype=np.float64),
-                "nugget": np.float64(self.nugget), "compat": np.str_(self.compat or ""),
+                "nugget": np.float64(self.nugget), "T": np.float64(self.T), "compat": np.str_(self.compat or ""),
                 "laplacian_idx": np.asarray(self.laplacian_idx if self.laplacian_idx is not None else [], dtype=np.int32)}
 
     def load_state_dict(self, state):
@@ -375,6 +383,8 @@ class GP(object):
                 self.compat and not np.array_equal(np.asarray(state["laplacian_idx"]), self.laplacian_idx)):
             raise ValueError("state was trained with compat=%r, laplacian_idx=%s" % (str(state.get("compat", "")), state.get("laplacian_idx")))
         self.nugget = float(state["nugget"])
+        if "T" in state and float(state["T"]) != float(self.T):
+            raise ValueError("state was trained with terminal time T = %g, this GP's equation has T = %g" % (float(state["T"]), float(self.T)))
         self.loss_history = list(np.asarray(state["loss_history"], dtype=np.float64))
         self.load_right_vector(state["x_t_domain"], state["x_t_boundary"], state["right_vector"])
         return self

@@ -93,14 +93,20 @@ class PicardEngine:
             self._kinds[key] = torch.from_numpy(host).cuda()
         return self._kinds[key]
 
-    def path_bound(self):
-        """Bound on |coordinate| of every tree point, from the geometry (no device read): the cube's half-width plus the
-        largest drift and 5.8 standard deviations of the diffusion over [t0, T] -- a normal of the 24-bit inverse-CDF transform
-        cannot exceed |Phi^-1(2^-25)| = 5.42.  Used as the stated precondition of the fp16 evaluation mode (scasml_gp_model.x_bound)."""
+    def path_bound(self, x_max=None, plan=None):
+        """Bound on |coordinate| of every tree point, the stated precondition of the fp16 evaluation planes
+        (scasml_gp_model.x_bound): the largest |coordinate| of the roots actually supplied (``x_max``; the cube's half-width if not
+        given) plus the largest drift plus the diffusion bound.  A tree point is reached through at most n levels of at most q_max
+        Euler-Maruyama steps; every increment is sigma sqrt(dt_i) N_i with |N_i| <= 5.42 (the 24-bit inverse-CDF transform cannot
+        exceed |Phi^-1(2^-25)|), so the sum is bounded by 5.42 sigma sum_i sqrt(dt_i) <= 5.42 sigma sqrt(steps * T) (Cauchy-Schwarz
+        on sum dt_i <= T) -- not by a multiple of sigma sqrt(T), which bounds one normal, not a sum of truncated ones."""
         eq = self.equation
-        radius = float(getattr(eq, "radius", 0.5))
+        radius = float(getattr(eq, "radius", 0.5)) if x_max is None else float(x_max)
         T = float(eq.T) - float(getattr(eq, "t0", 0.0))
-        return max(2.0, radius + abs(float(eq.mu())) * T + 5.8 * abs(float(eq.sigma())) * T ** 0.5)
+        steps = 1
+        if plan is not None and plan.n > 0:
+            steps = plan.n * max(int(plan.term[lev][l].q) for lev in range(1, plan.n + 1) for l in range(lev))
+        return max(2.0, radius + abs(float(eq.mu())) * T + 5.42 * abs(float(eq.sigma())) * (steps * T) ** 0.5)
 
     def problem(self):
         eq = self.equation
@@ -120,6 +126,10 @@ class PicardEngine:
             raise ValueError("x_t must have shape (batch, %d), got %s" % (d + 1, tuple(x.shape)))
         B = x.shape[0]
         plan, prob = self.plan(n, par), self.problem()
+        if self.gp is not None and float(getattr(self.gp, "T", self.equation.T)) != float(self.equation.T):
+            # the GP folds its terminal time into packed row constants (site kind 3); the tree emits terminal points at the equation's T
+            raise _lib.ScasmlError("the surrogate was built for terminal time T = %g, the equation now has T = %g: refit or reload the GP"
+                                   % (float(self.gp.T), float(self.equation.T)))
         flags = _lib.RNG_COMPAT_CRN if self.compat_crn else 0
         owner = self.unit_owners(n, par, world)[1].data_ptr() if world > 1 and n > 0 else None
         rng = _lib.Rng(self.seed, self.calls if stream_id is None else stream_id, root0, rank, world, flags, 0, owner)
@@ -141,6 +151,8 @@ class PicardEngine:
         pts, vals = self._buffers(stride * ppr, kp)   # rows of un-owned units and padding rows are never written: their (finite,
         # stale) content is evaluated or skipped by the GP kernel and never read back by ACCUMULATE
         kinds = self.site_kinds(n, par, rank, world) if n > 0 else None
+        # one reduction over the roots per solve: roots outside the training cube widen the bound instead of silently breaking it
+        x_bound = self.path_bound(float(x.abs().max()) if B else None, plan)
         for b0 in range(0, B, chunk):
             nb = min(chunk, B - b0)
             rng_c = _lib.Rng(rng.seed, rng.stream, root0 + b0, rank, world, flags, 0, owner)
@@ -150,7 +162,7 @@ class PicardEngine:
                 _lib.check(self._timed("picard_generate", lambda: lib.scasml_picard_tree(
                     C.byref(prob), C.byref(plan), _lib.MODE_GENERATE, _lib.ptr(xc), nb, stride, rng_c,
                     _lib.ptr(pts), None, None, None, s)), "picard_tree(generate)")
-                self._timed("gp_eval", lambda: self.gp._eval_rows(pts, stride * ppr, stride, kinds, vals, x_bound=self.path_bound()))
+                self._timed("gp_eval", lambda: self.gp._eval_rows(pts, stride * ppr, stride, kinds, vals, x_bound=x_bound))
                 _lib.check(self._timed("picard_accumulate", lambda: lib.scasml_picard_tree(
                     C.byref(prob), C.byref(plan), _lib.MODE_ACCUMULATE, _lib.ptr(xc), nb, stride, rng_c,
                     _lib.ptr(pts), _lib.ptr(vals), _lib.ptr(ob), _lib.ptr(ub), s)), "picard_tree(accumulate)")

@@ -119,7 +119,7 @@ def test_no_gpu_means_loud_failure_not_fallback():
     with pytest.raises(_lib.ScasmlError):
         MLP(eq).u_solve(1, 1, np.zeros((2, 11), dtype=np.float16))
     with pytest.raises(_lib.ScasmlError):
-        GP_Grad_Dependent_Nonlinear(eq).GPsolver(np.zeros((4, 11)), np.zeros((2, 11)))
+        GP_Grad_Dependent_Nonlinear(eq, compat=None).GPsolver(np.zeros((4, 11)), np.zeros((2, 11)))
 
 
 def test_product_never_imports_the_oracle():
@@ -128,6 +128,18 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+
+
+def test_abstract_equation_surface_raises_not_implemented():
+    """equations/equations.py:15-230: every abstract method exists and raises NotImplementedError (not AttributeError)."""
+    from scasml_gp_amd.equations.equations import Equation
+    e = Equation(5)
+    assert e.n_input == 5 and e.n_output == 1
+    for name, nargs in (("PDE_loss", 3), ("gPDE_loss", 2), ("terminal_constraint", 1), ("initial_constraint", 1), ("Dirichlet_boundary_constraint", 1),
+                        ("Neumann_boundary_constraint", 1), ("mu", 1), ("sigma", 1), ("f", 3), ("g", 1), ("exact_solution", 1), ("data_loss", 1),
+                        ("geometry", 0), ("test_geometry", 0), ("generate_data", 0), ("generate_test_data", 0)):
+        with pytest.raises(NotImplementedError):
+            getattr(e, name)(*([0] * nargs))
 
 
 def test_equation_surface_and_sampler():

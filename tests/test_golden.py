@@ -69,7 +69,7 @@ def test_hip_hits_the_fixtures():
         ok = ~np.isnan(want)
         assert np.all(np.abs(got[ok] - want[ok]) <= 2e-5 + 1e-4 * np.abs(want[ok])), key
     h = _load("oracle_gp_d6.npz")
-    gp = GP_Grad_Dependent_Nonlinear(eq)
+    gp = GP_Grad_Dependent_Nonlinear(eq, compat=None)
     gp.GPsolver(h["x_dom"], h["x_bdy"], GN_steps=20)
     assert np.abs(gp.right_vector - h["right_vector"]).max() <= 1e-7 * np.abs(h["right_vector"]).max()
     assert np.allclose(gp.loss_history, h["loss_history"], rtol=1e-8)

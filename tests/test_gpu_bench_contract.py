@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--solver", "mlp", "--d", "20", "--level", "2"]])
+@pytest.mark.parametrize("extra", [[], ["--compat", "none"], ["--solver", "mlp", "--d", "20", "--level", "2"]])
 def test_bench_prints_one_contract_line(extra):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "256",
            "--train-domain", "96", "--train-boundary", "32", "--cpu-sample", "2"] + extra
@@ -31,7 +31,10 @@ def test_bench_prints_one_contract_line(extra):
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and "traffic" in roof
     cpu = j["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["unit"] == "path-steps/s" and cpu["sample"]
-    assert cpu["max_abs_diff_gpu_vs_cpu"] < 1e-3
+    # north_star: L2 relative error within 1e-3 of the reference CPU path, on the same roots
+    assert cpu["abs_diff"] <= 1e-3 and abs(cpu["rel_l2_gpu"] - cpu["rel_l2_cpu"]) <= 1e-3 and cpu["max_abs_diff_u"] < 1e-3
+    if not extra:                                     # the default is the reference's as-coded surrogate
+        assert "as-coded" in j["config"]["surrogate"] and j["l2_rel_error"]["vs_cpu_oracle"]["abs_diff"] <= 1e-3
 
 
 @pytest.mark.gpu
@@ -71,7 +74,7 @@ def test_sample_sharded_result_does_not_depend_on_the_rank_count():
     d = 100
     dom, bdy = sample_points(np.random.default_rng(0), d, 96, 32)
     eq = Grad_Dependent_Nonlinear(d + 1)
-    gp = GP_Grad_Dependent_Nonlinear(eq)
+    gp = GP_Grad_Dependent_Nonlinear(eq, compat=None)
     gp.GPsolver(dom, bdy)
     eng = ScaSML_full_history(eq, gp, seed=1)._engine
     xt = np.concatenate(sample_points(np.random.default_rng(1), d, 24, 8))

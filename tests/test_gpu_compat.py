@@ -83,14 +83,18 @@ def test_compat_surrogate_differs_from_the_exact_one_and_needs_an_index_set():
     from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
     from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
     eq = Grad_Dependent_Nonlinear(21)
+    default = GP_Grad_Dependent_Nonlinear(eq)                  # the reference's surrogate with the reference's own index draw
+    assert default.compat == "reference" and default.laplacian_idx.tolist() == [0, 1, 19, 8, 12]
     with pytest.raises(ValueError):
-        GP_Grad_Dependent_Nonlinear(eq, compat="reference")
+        GP_Grad_Dependent_Nonlinear(eq, compat="reference", laplacian_idx=None)
+    with pytest.raises(ValueError):
+        GP_Grad_Dependent_Nonlinear(Grad_Dependent_Nonlinear(4))       # d = 3 < 5 indices
     with pytest.raises(ValueError):
         GP_Grad_Dependent_Nonlinear(eq, compat="reference", laplacian_idx=[1, 1, 2, 3, 4])
     with pytest.raises(ValueError):
         GP_Grad_Dependent_Nonlinear(eq, compat="reference", laplacian_idx=[1, 20, 2, 3, 4])
     dom, bdy = _points(20, 200, 50, seed=5)
-    exact = GP_Grad_Dependent_Nonlinear(eq)
+    exact = GP_Grad_Dependent_Nonlinear(eq, compat=None)
     exact.GPsolver(dom, bdy)
     compat = GP_Grad_Dependent_Nonlinear(eq, compat="reference", laplacian_idx=IDX20)
     compat.GPsolver(dom, bdy)
@@ -169,7 +173,7 @@ def test_points_one_float16_ulp_below_terminal_time():
     from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
     ogp = OracleGP(GradDependentNonlinear(21))
     ogp.GPsolver(dom, bdy)
-    gp = GP_Grad_Dependent_Nonlinear(eq)
+    gp = GP_Grad_Dependent_Nonlinear(eq, compat=None)
     gp.load_right_vector(dom, bdy, ogp.right_vector)
     xt = np.concatenate(_points(20, 48, 16, seed=31, f16=False))
     xt[:, -1] = np.float32(np.nextafter(np.float16(0.5), np.float16(0)))

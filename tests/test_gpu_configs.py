@@ -36,7 +36,7 @@ def test_config0_gp_only_d10_256_collocation_points():
     np.random.seed(1234)
     dom, bdy = eq.generate_data(213, 43)                         # 5 : 1 as tests/SimpleUniform.py:73-74
     xt = np.concatenate(eq.generate_test_data(1000, 200))
-    gp = GP_Grad_Dependent_Nonlinear(eq)
+    gp = GP_Grad_Dependent_Nonlinear(eq, compat=None)
     on_dom = gp.GPsolver(dom, bdy, GN_steps=20)
     ogp = OracleGP(GradDependentNonlinear(d + 1))
     want_dom = ogp.GPsolver(dom, bdy, GN_steps=20)
@@ -65,7 +65,7 @@ def config3():
     np.random.seed(1234)
     dom, bdy = eq.generate_data(1000, 200)
     np.random.set_state(state)
-    gp = GP_Grad_Dependent_Nonlinear(eq)
+    gp = GP_Grad_Dependent_Nonlinear(eq, compat=None)
     gp.GPsolver(dom, bdy, GN_steps=20)
     solver = ScaSML_full_history(eq, gp, seed=0)
     g = np.random.default_rng(4321)
@@ -116,7 +116,7 @@ def test_config4_d250_two_thousand_collocation_points_scasml_n3_matches_oracle()
     eq = Grad_Dependent_Nonlinear(d + 1)
     np.random.seed(1234)
     dom, bdy = eq.generate_data(1667, 333)
-    gp = GP_Grad_Dependent_Nonlinear(eq)
+    gp = GP_Grad_Dependent_Nonlinear(eq, compat=None)
     gp.GPsolver(dom, bdy, GN_steps=20)
     assert gp.phi_dim == 7001 and gp.loss_history[-1] < gp.loss_history[0] and gp.grad_norms[-1] < 1e-3 * gp.grad_norms[0]
     oeq, ogp = _oracle_with(gp, d)
@@ -135,7 +135,7 @@ def test_config4_fit_at_ten_thousand_collocation_points():
     eq = Grad_Dependent_Nonlinear(d + 1)
     np.random.seed(1234)
     dom, bdy = eq.generate_data(8333, 1667)
-    gp = GP_Grad_Dependent_Nonlinear(eq)
+    gp = GP_Grad_Dependent_Nonlinear(eq, compat=None)
     Kp = gp.kernel_phi_phi(dom, bdy)                      # K + nugget I (float64, 9.8 GB) and its factor
     M = gp.phi_dim
     assert M == 34999

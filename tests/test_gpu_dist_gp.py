@@ -21,7 +21,7 @@ def _problem(d, nd, nb, seed=1234):
 
 def _single_gpu_factor(eq, dom, bdy):
     from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
-    gp = GP_Grad_Dependent_Nonlinear(eq)
+    gp = GP_Grad_Dependent_Nonlinear(eq, compat=None)
     gp.kernel_phi_phi(dom, bdy)
     return gp, gp.cholesky_phi_phi_perturb
 
@@ -86,12 +86,25 @@ def _worker(rank, world, port, case, q):
             _lib.check(lib.scasml_trsm_lower(_lib.ptr(gp._L_pad), Mp32, _lib.ptr(ref), 1, 1, _lib.stream_ptr()), "trsm")
             err = float((x - ref[:ch.M, 0]).abs().max() / ref.abs().max())
             q.put((rank, rel, err, ch.memory_bytes(), ch.comm.bytes_moved))
+        elif case == "indefinite":
+            d, nd, nb = 20, 150, 30                                  # M = 630, 3 block rows over 2 ranks: the LAST one belongs to rank 0
+            eq, dom, bdy = _problem(d, nd, nb)
+            ch = DistCholesky(d, 1.0 / 5.0, dom, bdy, 1e-2, Comm()).build()
+            last = ch.nblk - 1
+            if last in ch.mine:                                      # make the last diagonal block indefinite on its owner only
+                slot = ch.mine.index(last)
+                ch.R[slot * 256 + 3, last * 256 + 3] = -50.0
+            try:
+                ch.factor()
+                q.put((rank, "no error"))
+            except ValueError as e:
+                q.put((rank, "ValueError: " + str(e)))
         else:
             d, nd, nb = 20, 350, 70                                  # M = 1470, 6 block rows over 3 ranks
             eq, dom, bdy = _problem(d, nd, nb)
-            one = GP_Grad_Dependent_Nonlinear(eq)
+            one = GP_Grad_Dependent_Nonlinear(eq, compat=None)
             one.GPsolver(dom, bdy, GN_steps=20)
-            gp = GP_Grad_Dependent_Nonlinear(eq)
+            gp = GP_Grad_Dependent_Nonlinear(eq, compat=None)
             fit = DistributedGP(gp, Comm())
             fit.fit(dom, bdy, GN_steps=20)
             rv_err = float(np.abs(gp.right_vector - one.right_vector).max() / np.abs(one.right_vector).max())
@@ -134,3 +147,10 @@ def test_three_ranks_newton_cg_fit_matches_the_single_gpu_fit():
     for rank, rv_err, pred_err, dsteps, dloss, cg_max in res:
         assert rv_err <= 1e-6 and pred_err <= 2e-5 and dsteps == 0 and dloss <= 1e-9, res
         assert cg_max <= 150, res
+
+
+def test_a_failed_pivot_on_one_rank_raises_on_every_rank():
+    """scasml_cholesky resets its status word per call and only the owner of a diagonal block sees its pivot fail; the
+    status is accumulated over the blocks and all-reduced once, so both ranks raise (instead of one leaving the other in a collective)."""
+    res = _run(2, "indefinite", 300)
+    assert len(res) == 2 and all(msg.startswith("ValueError") and "not positive definite" in msg for _, msg in res), res

@@ -37,7 +37,7 @@ def test_gp_training_and_residual_on_the_second_equation_match_oracle(d, nd, nb)
     from scasml_gp_amd.equations.equations import Cubic_Reaction_Diffusion
     from scasml_gp_amd.models.GP import GP_Cubic_Reaction_Diffusion
     dom, bdy = _points(d, nd, nb, 2)
-    gp = GP_Cubic_Reaction_Diffusion(Cubic_Reaction_Diffusion(d + 1))
+    gp = GP_Cubic_Reaction_Diffusion(Cubic_Reaction_Diffusion(d + 1), compat=None)
     ogp = OracleGP(CubicReactionDiffusion(d + 1))
     gp.GPsolver(dom, bdy, GN_steps=20)
     ogp.GPsolver(dom, bdy, GN_steps=20)
@@ -67,7 +67,7 @@ def test_scasml_on_the_second_equation_matches_oracle_and_improves_on_the_surrog
     eq, oeq = Cubic_Reaction_Diffusion(d + 1), CubicReactionDiffusion(d + 1)
     ogp = OracleGP(oeq)
     ogp.GPsolver(dom, bdy)
-    gp = GP_Cubic_Reaction_Diffusion(eq)
+    gp = GP_Cubic_Reaction_Diffusion(eq, compat=None)
     gp.load_right_vector(dom, bdy, ogp.right_vector)
     xt = np.concatenate(_points(d, 96, 32, 7))
     got, want = ScaSML(eq, gp, seed=2).uz_solve(2, 2, xt), PicardOracle(oeq, "quad", gp=ogp, seed=2).uz_solve(2, 2, xt)

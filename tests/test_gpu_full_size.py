@@ -1,5 +1,6 @@
 """BASELINE.json configs[2] at full size (d = 100, ScaSML n = rho = 3, 16384 roots, GP on 1000 + 200 points) through
-size-independent properties; the oracle is consulted on a 12-root sample only."""
+size-independent properties, on both surrogates (the reference's as-coded one -- the default and the benchmarked path -- and the
+documented operators); the oracle is consulted on a 64-root sample."""
 import numpy as np
 import pytest
 
@@ -8,8 +9,8 @@ pytestmark = pytest.mark.gpu
 D, N, B = 100, 3, 1 << 14
 
 
-@pytest.fixture(scope="module")
-def headline():
+@pytest.fixture(scope="module", params=["reference", None], ids=["as-coded", "documented"])
+def headline(request):
     import torch
     from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
     from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
@@ -20,8 +21,9 @@ def headline():
     np.random.seed(1234)
     x_dom, x_bdy = eq.generate_data(1000, 200)
     np.random.set_state(state)
-    gp = GP_Grad_Dependent_Nonlinear(eq)
+    gp = GP_Grad_Dependent_Nonlinear(eq, compat=request.param)
     gp.GPsolver(x_dom, x_bdy, GN_steps=20)
+    assert request.param is None or gp._compat_model is not None        # the matrix-core kernel serves the as-coded surrogate
     solver = ScaSML(eq, gp, seed=0)
     g = np.random.default_rng(1234)
     x_t = np.concatenate([g.uniform(-0.5, 0.5, (B, D)), g.uniform(0.0, 0.5, (B, 1))], axis=1).astype(np.float32)
@@ -34,7 +36,7 @@ def test_full_batch_is_finite_clipped_and_deterministic(headline):
     import torch
     solver, _, _, _, _, x_dev, full, uhat = headline
     assert full.shape == (B, D + 1) and bool(torch.isfinite(full).all()) and bool(torch.isfinite(uhat).all())
-    clip = float(solver.equation.norm_estimation)
+    clip = float(solver.equation.uncertainty)                             # ScaSML clips the defect at +-uncertainty (ScaSML.py:282-284)
     assert float(full.abs().max()) <= clip * (1 + 1e-6)
     again, uhat2, _ = solver._engine.solve(N, N, x_dev, stream_id=7)
     assert torch.equal(again, full) and torch.equal(uhat2, uhat)
@@ -67,15 +69,26 @@ def test_sample_sharded_partials_add_up_at_full_size(headline):
 def test_sample_of_the_full_batch_matches_the_oracle(headline):
     from oracle.equation import GradDependentNonlinear
     from oracle.gp import OracleGP
+    from oracle.gp_compat import OracleGPCompat
     from oracle.mlp import PicardOracle
     solver, gp, x_dom, x_bdy, x_t, _, full, _ = headline
     oeq = GradDependentNonlinear(D + 1)
-    ogp = OracleGP(oeq)                                   # the same trained surrogate as the GPU run
+    ogp = OracleGPCompat(oeq, gp.laplacian_idx, round_factor=False) if gp.compat == "reference" else OracleGP(oeq)   # the same trained surrogate
     ogp.x_t_domain, ogp.x_t_boundary = np.asarray(x_dom, dtype=np.float64), np.asarray(x_bdy, dtype=np.float64)
     ogp.N_domain, ogp.N_boundary = len(x_dom), len(x_bdy)
+    ogp.phi_dim = 4 * len(x_dom) + len(x_bdy)
     ogp.right_vector = gp.right_vector
-    rows = np.array([0, 1, 2, 3, 4097, 4098, 8191, 8192, 12345, B - 3, B - 2, B - 1])
     ora = PicardOracle(oeq, "quad", gp=ogp, seed=0, stream=7)
-    want = np.concatenate([ora.uz_solve(N, N, x_t[r:r + 1], root0=int(r)) for r in rows])
-    got = full[rows].cpu().numpy()
-    assert np.max(np.abs(got - want)) < 1e-4              # outputs are clipped to +-0.1: 1e-3 relative to the clip
+    got, want = [], []
+    for lo in (0, 4090, 8184, B - 16):                     # 4 x 16 roots spread over the batch
+        want.append(ora.uz_solve(N, N, x_t[lo:lo + 16], root0=lo))
+        got.append(full[lo:lo + 16].cpu().numpy())
+    got, want = np.concatenate(got), np.concatenate(want)
+    diff = np.abs(got - want)
+    if gp.compat == "reference":
+        # u_hat and eps_PDE are float16 values: an entry rounded differently (float32 value here, float64 there) moves u_hat by one
+        # float16 ulp and a z component by that times N / (MC delta_t) -- rare, bounded, and invisible in the error metric
+        assert diff[:, 0].max() < 3e-4 and (diff > 1e-4).mean() < 0.08 and diff.max() < 1e-2
+        assert abs(np.linalg.norm(got[:, 0]) - np.linalg.norm(want[:, 0])) <= 1e-3 * np.linalg.norm(want[:, 0])
+    else:
+        assert diff.max() < 1e-4                           # outputs are clipped to +-0.1: 1e-3 relative to the clip

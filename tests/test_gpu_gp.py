@@ -14,7 +14,7 @@ def _setup(d, nd, nb, seed=0):
     from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
     from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
     dom, bdy = sample_points(np.random.default_rng(seed), d, nd, nb)
-    return GP_Grad_Dependent_Nonlinear(Grad_Dependent_Nonlinear(d + 1)), OracleGP(GradDependentNonlinear(d + 1)), dom, bdy
+    return GP_Grad_Dependent_Nonlinear(Grad_Dependent_Nonlinear(d + 1), compat=None), OracleGP(GradDependentNonlinear(d + 1)), dom, bdy
 
 
 @pytest.mark.parametrize("d,nd,nb", [(5, 40, 9), (20, 70, 25), (100, 33, 7)])
@@ -169,10 +169,10 @@ def test_state_dict_round_trip(tmp_path):
     gp.save(path)
     from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
     from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
-    fresh = GP_Grad_Dependent_Nonlinear(Grad_Dependent_Nonlinear(13)).load(path)
+    fresh = GP_Grad_Dependent_Nonlinear(Grad_Dependent_Nonlinear(13), compat=None).load(path)
     assert np.array_equal(fresh.predict(X), want) and fresh._colloc_is_f16 and fresh.loss_history == gp.loss_history
     with pytest.raises(ValueError):
-        GP_Grad_Dependent_Nonlinear(Grad_Dependent_Nonlinear(14)).load(path)
+        GP_Grad_Dependent_Nonlinear(Grad_Dependent_Nonlinear(14), compat=None).load(path)
 
 
 def test_fp16_mode_refuses_out_of_range_length_scale():

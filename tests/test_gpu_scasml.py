@@ -23,7 +23,7 @@ def _setup(d, nd, nb, variant, seed):
     ogp = OracleGP(oeq)
     ogp.GPsolver(dom, bdy, GN_steps=20)
     eq = Grad_Dependent_Nonlinear(d + 1)
-    gp = GP_Grad_Dependent_Nonlinear(eq)
+    gp = GP_Grad_Dependent_Nonlinear(eq, compat=None)
     gp.GPsolver(dom, bdy, GN_steps=20)
     hip = ScaSML(eq, gp, seed=seed) if variant == "quad" else ScaSML_full_history(eq, gp, seed=seed)
     return hip, PicardOracle(oeq, variant, gp=ogp, seed=seed, stream=0), oeq
@@ -83,7 +83,7 @@ def test_untrained_gp_fails_loudly():
     from scasml_gp_amd.solvers.ScaSML import ScaSML
     eq = Grad_Dependent_Nonlinear(11)
     with pytest.raises(_lib.ScasmlError):
-        ScaSML(eq, GP_Grad_Dependent_Nonlinear(eq)).u_solve(1, 1, np.zeros((2, 11), dtype=np.float32))
+        ScaSML(eq, GP_Grad_Dependent_Nonlinear(eq, compat=None)).u_solve(1, 1, np.zeros((2, 11), dtype=np.float32))
 
 
 def test_terminal_time_rows_float16_inputs_and_deepcopy():

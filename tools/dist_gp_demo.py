@@ -47,7 +47,7 @@ def worker(rank, world, port, args, q):
                solve_s=round(t3 - t2, 3), matvec_s=round(t4 - t3, 3), collective_gb_per_rank=round(cm.bytes_moved / 1e9, 2))
     del ch
     torch.cuda.empty_cache()
-    gp = GP_Grad_Dependent_Nonlinear(eq)
+    gp = GP_Grad_Dependent_Nonlinear(eq, compat=None)
     fit = DistributedGP(gp, Comm())
     torch.cuda.synchronize(); t0 = time.perf_counter()
     fit.fit(dom, bdy, GN_steps=20)
@@ -58,7 +58,7 @@ def worker(rank, world, port, args, q):
     exact = eq.exact_solution(xt)
     out["gp_rel_l2"] = round(float(np.linalg.norm(pred - exact) / np.linalg.norm(exact)), 4)
     if rank == 0 and not args.no_single:
-        one = GP_Grad_Dependent_Nonlinear(eq)
+        one = GP_Grad_Dependent_Nonlinear(eq, compat=None)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         one.GPsolver(dom, bdy, GN_steps=20)
         torch.cuda.synchronize(); t1 = time.perf_counter()

@@ -27,7 +27,7 @@ def main():
     from scasml_gp_amd.solvers.ScaSML import ScaSML
     np.random.seed(1234)
     eq = Grad_Dependent_Nonlinear(args.d + 1)
-    gp = GP_Grad_Dependent_Nonlinear(eq)
+    gp = GP_Grad_Dependent_Nonlinear(eq, compat=None)
     dom, bdy = eq.generate_data(args.n_dom, args.n_bdy)
     M = 4 * args.n_dom + args.n_bdy
     print("d=%d N=%d+%d M=%d (K is %.1f GB float64)" % (args.d, args.n_dom, args.n_bdy, M, M * M * 8 / 1e9), flush=True)

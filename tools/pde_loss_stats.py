@@ -21,7 +21,7 @@ for compat in (False, True):
             np.random.seed(1234)
             eq = Grad_Dependent_Nonlinear(d + 1)
             idx = np.random.default_rng(2234 + k).choice(d, 5, replace=False)
-            gp = GP_Grad_Dependent_Nonlinear(eq, compat="reference", laplacian_idx=idx) if compat else GP_Grad_Dependent_Nonlinear(eq)
+            gp = GP_Grad_Dependent_Nonlinear(eq, compat="reference", laplacian_idx=idx) if compat else GP_Grad_Dependent_Nonlinear(eq, compat=None)
             gp.GPsolver(*eq.generate_data(1000, 200), GN_steps=20)
             xt = np.concatenate(eq.generate_test_data(1000, 200))
             e = gp.compute_PDE_loss(xt)[:, 0].astype(np.float64)

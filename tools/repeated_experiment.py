@@ -59,7 +59,7 @@ def run_case(d, train_seed, idx, reps, compat):
     from scasml_gp_amd.solvers.ScaSML_full_history import ScaSML_full_history
     np.random.seed(train_seed)                                   # experiment_run.py:32 (1234)
     eq = Grad_Dependent_Nonlinear(d + 1)
-    gp = GP_Grad_Dependent_Nonlinear(eq, compat="reference", laplacian_idx=idx) if compat else GP_Grad_Dependent_Nonlinear(eq)
+    gp = GP_Grad_Dependent_Nonlinear(eq, compat="reference", laplacian_idx=idx) if compat else GP_Grad_Dependent_Nonlinear(eq, compat=None)
     dom, bdy = eq.generate_data(1000, 200)
     t0 = time.time()
     gp.GPsolver(dom, bdy, GN_steps=20)
