@@ -25,9 +25,13 @@
 // reads the fp16 half directly: a rounding costs half a vector instruction.  A rounding decision can differ from the float64
 // statement's where the float32 value lands within ~2^-20 of a float16 midpoint (about 1 entry in 500); tests bound the effect.
 //
+// (Measured and not kept, profiles/r03_compat_eval_experiments.txt: the four sums as a second MFMA on the packed float16 entries --
+// the accumulator-as-operand idiom, coefficients as A fragments -- removes 16 of the ~50 vector instructions per pair but adds 32
+// MFMAs per tile to a kernel whose clock already sags when both pipes are busy: 21.25 ms against 19.75-19.96 on one box.)
+//
 // Structure (as gp_eval_bf16.hip): 4-wave workgroups, 32 points per wave held in VGPRs as two fp16 planes for the whole sweep;
 // the unit of work is a STAGE = (collocation tile of 32 rows, geometry): [KS KiB A fragments | 1 KiB Q fragment | 1 KiB row
-// constants], fetched two stages ahead into a ring of four LDS slots by LDS-DMA behind a counted vmcnt and one raw barrier per
+// constants], fetched two stages ahead into a ring of three LDS slots by LDS-DMA behind a counted vmcnt and one raw barrier per
 // stage.  Per site kind (scasml_plan_site_kinds) a wave runs only the geometries its outputs need:
 //     full (u, dt, div, lap -> eps_PDE)   al, ys, xs on domain tiles;  al, xs on boundary tiles
 //     u only / u and div                  al, ys on domain tiles;      al on boundary tiles
@@ -215,11 +219,16 @@ __device__ __forceinline__ void compat_epilogue(const float *rows_lds, const f32
     }
 }
 
+// Stage block, in floats (scasml_gp_compat_pack_mfma): KS*256 planes | 256 Q fragment | 256 row constants (32 x 8) = (KS + 2) KiB
+constexpr int kStageTail = 256 + 256;
+
 template <int KS, int BPC, bool R16>
 __global__ __launch_bounds__(256, BPC) void gp_eval_compat_mfma_kernel(const GpCompatArgs g) {
-    constexpr int WPB = 4, NSLOT = 4, AHEAD = 2;
-    constexpr int STAGE = (KS + 2) * 256;              // floats per LDS slot
-    constexpr int NCHUNK = KS + 2;
+    // three slots: stage s is read while s + 1 has landed or lands and s + 2 is issued into the slot stage s - 1 was read from, which
+    // every wave left before the barrier that ended step s - 1
+    constexpr int WPB = 4, NSLOT = 3, AHEAD = 2;
+    constexpr int STAGE = KS * 256 + kStageTail;       // floats per LDS slot
+    constexpr int NCHUNK = STAGE / 256;
     constexpr int CLO = NCHUNK / WPB, CREM = NCHUNK % WPB;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -488,7 +497,7 @@ __global__ void gp_compat_pack_mfma_kernel(int d, float a, const float *x_dom, i
         c0 = (float)rv[j];
     }
     const int tile = j / 32, i = j % 32;
-    const int stage_floats = (KS + 2) * 256;
+    const int stage_floats = KS * 256 + kStageTail;
     for (int g = 0; g < 3; ++g) {
         float *blk = model + ((int64_t)tile * 3 + g) * stage_floats;
         uint16_t *planes = reinterpret_cast<uint16_t *>(blk);
@@ -554,7 +563,7 @@ static int launch_compat(const GpCompatArgs &g, hipStream_t s) {
     const int64_t waves = (g.n_inf + 31) / 32;
     const int64_t blocks = (waves + 3) / 4;
     if (blocks > 0x7FFFFFFF) return fail(SCASML_ERR_UNSUPPORTED, "gp_eval_compat_sites: too many points");
-    constexpr size_t lds_bytes = 4 * (size_t)(KS + 2) * 1024;
+    constexpr size_t lds_bytes = 3 * (size_t)(KS * 256 + kStageTail) * sizeof(float);
     static_assert(lds_bytes * BPC <= 160 * 1024, "LDS slots exceed 160 KiB");
     auto kern = gp_eval_compat_mfma_kernel<KS, BPC, R16>;
     if (lds_bytes > 64 * 1024) {
@@ -594,7 +603,7 @@ using namespace scasml;
 
 extern "C" int64_t scasml_gp_compat_model_floats(int32_t d, int32_t n_pad) {
     const int64_t kp = scasml_point_stride(d);
-    return (int64_t)(n_pad / SCASML_GP_TILE) * 3 * (kp / 16 + 2) * 256;
+    return (int64_t)(n_pad / SCASML_GP_TILE) * 3 * ((kp / 16) * 256 + kStageTail);
 }
 
 extern "C" int scasml_gp_compat_pack_mfma(int32_t d, float a, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy,
