@@ -69,8 +69,13 @@ typedef struct {
  * the child calls of the q quadrature nodes of one sample path -- calls of equal shape -- share their terminal
  * draws: a call's terminal sample m is keyed by the site it would have at node k = 0 of every ancestor path.  In
  * the full-history solvers the level-0 normals equal the terminal ones (solvers/MLP_full_history.py:92-93,99,138).
- * Default (0): independent draws everywhere. */
-enum { SCASML_RNG_COMPAT_CRN = 1 };
+ * Default (0): independent draws everywhere.
+ * COMPAT_F16 applies the reference's solver-level float16 casts: Equation.g and Equation.f return
+ * float16 (equations/equations.py:261, 304), ScaSML.g / ScaSML.f subtract float16 from float16 (solvers/ScaSML.py:45-47, 62), and every
+ * uz_solve returns clip(...).astype(float16) (solvers/MLP.py:274, ScaSML.py:284, MLP_full_history.py:180; ScaSML_full_history.py:199
+ * does not cast), so a child's (u, z) is a float16 value before the parent's f sees it.  Sample-sharded partial sums (world > 1) are
+ * left unrounded: the cast follows the clip, which follows the all-reduce. */
+enum { SCASML_RNG_COMPAT_CRN = 1, SCASML_RNG_COMPAT_F16 = 2 };
 
 /* One (level n', sub-level l) term of the Picard sum: MLP.py:210-271 / MLP_full_history.py:131-177. */
 typedef struct {

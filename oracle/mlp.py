@@ -75,7 +75,7 @@ def reference_counts(variant, n, par, tab=None, scasml=False):
 
 # --------------------------------------------------------------------------- solver
 class PicardOracle:
-    def __init__(self, eq, variant="quad", gp=None, seed=0, stream=0, T=None, compat_crn=False):
+    def __init__(self, eq, variant="quad", gp=None, seed=0, stream=0, T=None, compat_crn=False, compat_f16=False):
         """compat_crn=True emulates the reference's fixed-key reuse:
         every ``uz_solve`` call draws its terminal normals from ``PRNGKey(0)`` again
         (MLP.py:167-168,178), so calls of equal shape -- the q quadrature nodes of one sample
@@ -84,6 +84,10 @@ class PicardOracle:
         against the relative-L2 errors logged under results*/ (tests/test_oracle_reference_band.py);
         the product path and the default oracle use independent draws."""
         self.compat_crn = bool(compat_crn)
+        # compat_f16: the reference's solver-level float16 casts -- Equation.g / Equation.f return float16 (equations.py:261, 304),
+        # ScaSML.g / ScaSML.f subtract float16 from float16 (ScaSML.py:45-47, 62), every uz_solve returns .astype(float16)
+        # (MLP.py:274, ScaSML.py:284, MLP_full_history.py:180; ScaSML_full_history.py:199 does not)
+        self.compat_f16 = bool(compat_f16)
         self.eq = eq
         self.variant = variant
         self.gp = gp
@@ -124,21 +128,28 @@ class PicardOracle:
     # pieces -------------------------------------------------------------------
     def _g(self, X, tcol):
         P = np.concatenate([X, tcol[:, None]], axis=1)
-        G = self.eq.g(P)[:, 0]
+        G = self._h(self.eq.g(P)[:, 0])
         if self.gp is not None:                      # ScaSML.py:61-63
-            G = G - self.gp.predict(P)[:, 0]
+            G = self._h(G - self.gp.predict(P)[:, 0])
         return G
+
+    def _h(self, v):
+        """.astype(float16) under compat_f16 (held in float64)."""
+        if not self.compat_f16:
+            return v
+        with np.errstate(over="ignore"):
+            return np.asarray(v, dtype=np.float64).astype(np.float16).astype(np.float64)
 
     def _f(self, X, tcol, u, z):
         P = np.concatenate([X, tcol[:, None]], axis=1)
         if self.gp is None:
-            return self.eq.f(P, u[:, None], z)[:, 0]             # MLP.py:27-41
+            return self._h(self.eq.f(P, u[:, None], z)[:, 0])    # MLP.py:27-41
         u_hat = self.gp.predict(P)                               # ScaSML.py:43-47
         grad_x = self.gp.compute_gradient(P)[:, :-1]
         s = self.eq.sigma()
-        val1 = self.eq.f(P, u[:, None] + u_hat, s * grad_x + z)
-        val2 = self.eq.f(P, u_hat, s * grad_x)
-        return (val1 - val2)[:, 0]
+        val1 = self._h(self.eq.f(P, u[:, None] + u_hat, s * grad_x + z))
+        val2 = self._h(self.eq.f(P, u_hat, s * grad_x))
+        return self._h(val1 - val2)[:, 0]
 
     def _owned(self, top, unit):
         rank, world = self._shard
@@ -152,7 +163,8 @@ class PicardOracle:
             return out                               # partial sums; caller reduces then clips
         c = self.clip
         # jnp.clip keeps NaN (MLP.py:274); np.clip does too
-        return np.clip(out, -c, c)
+        out = np.clip(out, -c, c)
+        return out if (self.variant == "fh" and self.gp is not None) else self._h(out)
 
     def _uz(self, n, x, t, roots, base, top=False, cbase=None):
         """base: first RNG site of this call's subtree.  cbase: where the call's TERMINAL draws

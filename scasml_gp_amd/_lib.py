@@ -12,6 +12,7 @@ ABI_VERSION = 3
 
 MODE_MLP, MODE_GENERATE, MODE_ACCUMULATE = 0, 1, 2
 RNG_COMPAT_CRN = 1
+RNG_COMPAT_F16 = 2
 EQ_GRAD_DEPENDENT_NONLINEAR = 0
 EQ_CUBIC_REACTION_DIFFUSION = 1
 

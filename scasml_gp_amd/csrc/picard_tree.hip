@@ -38,6 +38,7 @@ struct TreeArgs {
     int32_t rank, world;
     const uint8_t *owner;   // unit -> rank (scasml_plan_deal_units), or null: unit % world
     int32_t crn;  // SCASML_RNG_COMPAT_CRN: terminal draws keyed by the call's k = 0 position (reference key reuse, E-2/E-3)
+    int32_t f16;  // SCASML_RNG_COMPAT_F16: the reference's solver-level float16 casts (g, f and every uz_solve return; E-5)
     int32_t d, G, logG, kp;
     float T, mu, sigma, clip;
 };
@@ -50,6 +51,7 @@ __device__ __forceinline__ float4 add4(float4 a, float s) { return make_float4(a
 __device__ __forceinline__ float4 f4_scale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
 __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 __device__ __forceinline__ float clip1(float v, float c) { return v < -c ? -c : (v > c ? c : v); }  // keeps NaN (jnp.clip)
+__device__ __forceinline__ float r16(float v) { return (float)(_Float16)v; }                          // .astype(jnp.float16), RNE
 // Hardware reciprocal / square root / exp2 (<= 1 ulp) for the arithmetic that is NOT part of the bit-exact
 // RNG specification: the IEEE-correct expansions cost ~10 VALU instructions each and these kernels are
 // VALU-bound; the parity tolerance (1e-4 relative) is five orders of magnitude above the difference.
@@ -115,7 +117,11 @@ struct Walker {
     // Equation.g at time T (equations/equations.py:146-162, 248-261) through the registry; ScaSML.py:61-63 subtracts the surrogate
     __device__ __forceinline__ float g_terminal(float4 XT, float u_hat) const {
         float g = EqDef<EQ>::G(dim_sum(EqDef<EQ>::phi(XT)), a.T);
-        if constexpr (MODE == SCASML_MODE_ACCUMULATE) g -= u_hat;
+        if (a.f16) g = r16(g);                                    // terminal_constraint(...).astype(float16), equations.py:261
+        if constexpr (MODE == SCASML_MODE_ACCUMULATE) {
+            g -= u_hat;
+            if (a.f16) g = r16(g);                                // float16 - float16 (ScaSML.py:62): a float16 value
+        }
         return g;
     }
     // Equation.f (equations/equations.py:290-304, MLP.py:27-41); ScaSML.py:29-47: f(u_hat + u, sigma grad u_hat + z) - f(u_hat, sigma grad u_hat),
@@ -125,9 +131,11 @@ struct Walker {
         const float fd = (float)a.d;
         if constexpr (MODE == SCASML_MODE_ACCUMULATE) {
             const float sg = a.sigma * gp.y;
-            return EqDef<EQ>::f(uc + gp.x, sg + sz, a.sigma, fd) - EqDef<EQ>::f(gp.x, sg, a.sigma, fd);
+            const float v1 = EqDef<EQ>::f(uc + gp.x, sg + sz, a.sigma, fd), v2 = EqDef<EQ>::f(gp.x, sg, a.sigma, fd);
+            return a.f16 ? r16(r16(v1) - r16(v2)) : v1 - v2;      // generator(...).astype(float16) twice, then float16 - float16 (equations.py:304, ScaSML.py:45-47)
         } else {
-            return EqDef<EQ>::f(uc, sz, a.sigma, fd);
+            const float v = EqDef<EQ>::f(uc, sz, a.sigma, fd);
+            return a.f16 ? r16(v) : v;
         }
     }
 
@@ -303,6 +311,11 @@ struct Walker {
             if (!(TOP && a.world > 1)) {                         // MLP.py:272-274
                 u = clip1(u, a.clip);
                 z = make_float4(clip1(z.x, a.clip), clip1(z.y, a.clip), clip1(z.z, a.clip), clip1(z.w, a.clip));
+                // jnp.clip(...).astype(jnp.float16): MLP.py:274, ScaSML.py:284, MLP_full_history.py:180 -- ScaSML_full_history.py:199 does not cast
+                if (a.f16 && !(VAR == 1 && MODE != SCASML_MODE_MLP)) {
+                    u = r16(u);
+                    z = make_float4(r16(z.x), r16(z.y), r16(z.z), r16(z.w));
+                }
             }
             u_out = u;
             z_out = z;
@@ -476,6 +489,7 @@ extern "C" int scasml_picard_tree(const scasml_problem *prob, const scasml_plan 
     a.world = rng.world;
     a.owner = rng.world > 1 ? rng.unit_owner : nullptr;
     a.crn = (rng.flags & SCASML_RNG_COMPAT_CRN) ? 1 : 0;
+    a.f16 = (rng.flags & SCASML_RNG_COMPAT_F16) ? 1 : 0;
     a.d = prob->d;
     a.kp = scasml_point_stride(prob->d);
     a.G = ceil_pow2(a.kp / 4);

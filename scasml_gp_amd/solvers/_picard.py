@@ -19,7 +19,7 @@ def _as_device(x_t, torch):
 
 
 class PicardEngine:
-    def __init__(self, equation, variant, gp=None, seed=0, compat_crn=False):
+    def __init__(self, equation, variant, gp=None, seed=0, compat_crn=False, compat_f16=False):
         if getattr(equation, "eq_id", None) is None:
             raise NotImplementedError("no HIP kernels for equation %s (eq_id unset)" % type(equation).__name__)
         self.equation = equation
@@ -28,6 +28,8 @@ class PicardEngine:
         self.seed = int(seed)
         # reference key reuse (Appendix E-2/E-3) as counter keying: SCASML_RNG_COMPAT_CRN in include/scasml_hip.h
         self.compat_crn = bool(compat_crn)
+        # the reference's solver-level float16 casts (g, f, every uz_solve return): SCASML_RNG_COMPAT_F16 in include/scasml_hip.h
+        self.compat_f16 = bool(compat_f16)
         self.calls = 0                 # Philox stream id: advances once per uz_solve (E-9)
         self.profile = False           # bench.py: bracket every launch with HIP events on the launch stream
         self._events = []
@@ -130,7 +132,7 @@ class PicardEngine:
             # the GP folds its terminal time into packed row constants (site kind 3); the tree emits terminal points at the equation's T
             raise _lib.ScasmlError("the surrogate was built for terminal time T = %g, the equation now has T = %g: refit or reload the GP"
                                    % (float(self.gp.T), float(self.equation.T)))
-        flags = _lib.RNG_COMPAT_CRN if self.compat_crn else 0
+        flags = (_lib.RNG_COMPAT_CRN if self.compat_crn else 0) | (_lib.RNG_COMPAT_F16 if self.compat_f16 else 0)
         owner = self.unit_owners(n, par, world)[1].data_ptr() if world > 1 and n > 0 else None
         rng = _lib.Rng(self.seed, self.calls if stream_id is None else stream_id, root0, rank, world, flags, 0, owner)
         if stream_id is None:

@@ -182,3 +182,41 @@ def test_points_one_float16_ulp_below_terminal_time():
     hip = ScaSML(eq, gp, seed=5)
     got, want = hip.uz_solve(2, 2, xt), PicardOracle(ogp.eq, "quad", gp=ogp, seed=5, stream=0).uz_solve(2, 2, xt)
     assert np.all(np.abs(got - want) <= 5e-5 + 2e-4 * np.abs(want)), np.abs(got - want).max()
+
+
+@pytest.mark.parametrize("variant,n,par", [("quad", 2, 2), ("quad", 3, 3), ("fh", 2, 3)])
+def test_solver_level_float16_casts_match_oracle(variant, n, par):
+    """compat_f16 (SCASML_RNG_COMPAT_F16): Equation.g / Equation.f return float16, ScaSML.g / ScaSML.f subtract float16 values, and every
+    uz_solve returns clip(...).astype(float16) -- except ScaSML_full_history (solvers/ScaSML_full_history.py:199).  A cast decided on a
+    float32 value here and a float64 value in the oracle can differ by one float16 ulp on rare elements."""
+    from oracle.equation import GradDependentNonlinear
+    from oracle.mlp import PicardOracle
+    from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
+    from scasml_gp_amd.solvers.MLP import MLP
+    from scasml_gp_amd.solvers.MLP_full_history import MLP_full_history
+    from scasml_gp_amd.solvers.ScaSML import ScaSML
+    from scasml_gp_amd.solvers.ScaSML_full_history import ScaSML_full_history
+    d = 20
+    gp, ogp, dom, bdy, eq = _pair(d, IDX20, 60, 20, seed=7)
+    ogp.GPsolver(dom, bdy, GN_steps=20)
+    gp.load_right_vector(dom, bdy, ogp.right_vector)
+    gp.compat_eval = "float64"                       # rounding decisions of the surrogate as the oracle takes them
+    xt = np.concatenate(_points(d, 48, 16, seed=33, f16=False))
+    is16 = lambda v: np.array_equal(v.astype(np.float16).astype(v.dtype), v)
+    for scasml in (False, True):
+        if variant == "quad":
+            hip = ScaSML(eq, gp, seed=4, compat_f16=True) if scasml else MLP(eq, seed=4, compat_f16=True)
+            plain = ScaSML(eq, gp, seed=4) if scasml else MLP(eq, seed=4)
+            got, base = hip.uz_solve(n, par, xt), plain.uz_solve(n, par, xt)
+        else:
+            hip = ScaSML_full_history(eq, gp, seed=4, compat_f16=True) if scasml else MLP_full_history(eq, seed=4, compat_f16=True)
+            plain = ScaSML_full_history(eq, gp, seed=4) if scasml else MLP_full_history(eq, seed=4)
+            got, base = hip.uz_solve(n, None, xt, par), plain.uz_solve(n, None, xt, par)
+        ora = PicardOracle(ogp.eq, variant, gp=ogp if scasml else None, seed=4, stream=0, compat_f16=True)
+        want = ora.uz_solve(n, par, xt)
+        assert is16(got) == (not (scasml and variant == "fh")), (variant, scasml)
+        assert not np.array_equal(got, base)                         # the casts do something
+        diff = np.abs(got - want)
+        ulp = 2.0 ** -10 * np.maximum(np.abs(want), 2.0 ** -14)      # one float16 ulp
+        assert (diff > ulp + 1e-6).mean() <= 0.03, (variant, scasml, (diff > ulp + 1e-6).mean())
+        assert np.abs(got[:, 0] - want[:, 0]).max() <= 6e-4 and diff.max() <= 2e-2, (variant, scasml, diff.max())

@@ -123,7 +123,8 @@ def test_product_reproduces_the_logged_errors(d):
     assert abs(pde.std() - lp["std"]) <= 0.03 * lp["std"] and abs(pde.mean() - lp["mean"]) <= 0.1 * lp["std"], (pde.mean(), pde.std(), lp)
     assert abs(pde.min() - lp["min"]) <= 0.15 * abs(lp["min"]) and abs(pde.max() - lp["max"]) <= 0.15 * abs(lp["max"]), (pde.min(), pde.max(), lp)
     from scasml_gp_amd.solvers.ScaSML_full_history import ScaSML_full_history
-    mlp, sc, scf = MLP(eq, compat_crn=True), ScaSML(eq, gp, compat_crn=True), ScaSML_full_history(eq, gp, compat_crn=True)
+    kw = {"compat_crn": True, "compat_f16": True}           # the reference's key reuse and its solver-level float16 casts
+    mlp, sc, scf = MLP(eq, **kw), ScaSML(eq, gp, **kw), ScaSML_full_history(eq, gp, **kw)
     acc = {"GP": [], "MLP": [], "ScaSML": [], "ScaSML_fh": []}
     l1 = []
     for i in range(10):

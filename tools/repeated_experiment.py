@@ -65,8 +65,9 @@ def run_case(d, train_seed, idx, reps, compat):
     gp.GPsolver(dom, bdy, GN_steps=20)
     torch.cuda.synchronize()
     t_fit = time.time() - t0
-    solvers = {"MLP": MLP(eq, compat_crn=compat), "ScaSML": ScaSML(eq, gp, compat_crn=compat),
-               "MLP_fh": MLP_full_history(eq, compat_crn=compat), "ScaSML_fh": ScaSML_full_history(eq, gp, compat_crn=compat)}
+    kw = {"compat_crn": compat, "compat_f16": compat}        # the reference's key reuse and its solver-level float16 casts
+    solvers = {"MLP": MLP(eq, **kw), "ScaSML": ScaSML(eq, gp, **kw),
+               "MLP_fh": MLP_full_history(eq, **kw), "ScaSML_fh": ScaSML_full_history(eq, gp, **kw)}
     acc = {k: [] for k in NAMES}
     sec = {k: [] for k in NAMES}
     valid = []
@@ -121,7 +122,8 @@ def run_simple_uniform(d, idx, seed=1234):
     gp.GPsolver(dom, bdy)                                   # SimpleUniform.py:81 (GN_steps default 20)
     xt = np.concatenate(eq.generate_test_data(1000, 200), axis=0)
     exact = eq.exact_solution(xt)
-    sols = {"GP": gp.predict(xt), "MLP": MLP(eq, compat_crn=True).u_solve(2, 2, xt), "ScaSML": ScaSML(eq, gp, compat_crn=True).u_solve(2, 2, xt)}
+    sols = {"GP": gp.predict(xt), "MLP": MLP(eq, compat_crn=True, compat_f16=True).u_solve(2, 2, xt),
+            "ScaSML": ScaSML(eq, gp, compat_crn=True, compat_f16=True).u_solve(2, 2, xt)}
     m = metrics(sols, exact)
     e = np.asarray(exact, np.float64).ravel()
     diff = np.asarray(sols["GP"], np.float64).ravel() - e
