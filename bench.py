@@ -309,9 +309,10 @@ def main():
                 group = h
     g_lo, g_cnt = parallel.root_slice(B, my_group, G)
 
-    def samples_step():
-        sid = eng.calls
-        eng.calls += 1
+    def samples_step(sid=None):
+        if sid is None:
+            sid = eng.calls
+            eng.calls += 1
         out, uhat, _ = eng.solve(n, par, x_shared[g_lo:g_lo + g_cnt], root0=g_lo, rank=my_srank, world=S, stream_id=sid)
         if S > 1:
             if on_host:
@@ -348,6 +349,14 @@ def main():
                        "roots_leg": {"scaling": "weak", "roots_total": world * B, "ms_per_step": round(t_r / args.steps * 1e3, 3),
                                      "value": round(world * B * steps_exec * args.steps / t_r, 1)}}
 
+    if world > 1:
+        # the sample-sharded estimator against the unsharded one on the same roots and Philox streams (Philox is keyed by tree site,
+        # so only the order of the float additions differs): max |difference| over this group's roots, worst over ranks
+        sharded, _ = samples_step(sid=424242)
+        whole, _, _ = eng.solve(n, par, x_shared[g_lo:g_lo + g_cnt], root0=g_lo, stream_id=424242)
+        dmax = torch.tensor([float((sharded - whole).abs().max()) if g_cnt else 0.0], dtype=torch.float64, device="cpu" if on_host else "cuda")
+        dist.all_reduce(dmax, op=dist.ReduceOp.MAX)
+        samples_leg["max_abs_diff_vs_unsharded"] = float(dmax.item())
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()

@@ -147,42 +147,79 @@ class DistCholesky:
         return self
 
     # -------------------------------------------------------------------------------------------- factor
-    def factor(self):
+    def _panel(self, k):
+        """Block column k on the current stream: the owner factors the diagonal block and broadcasts it, every rank solves its blocks of
+        the column against it, one all-gather assembles the column panel in global block order.  -> P ((nb - k - 1) * BLK, BLK) or None."""
         torch = _lib.require_gpu()
         lib, s, cm = self.lib, _lib.stream_ptr(), self.comm
         R, Mp, nb, w, rank = self.R, self.Mp, self.nblk, cm.world, cm.rank
-        for k in range(nb):
-            owner = k % w
-            Lkk = torch.empty((BLK, BLK), dtype=torch.float64, device="cuda")
-            if rank == owner:
-                slot = (k - rank) // w
-                Lkk.copy_(R[slot * BLK:(slot + 1) * BLK, k * BLK:(k + 1) * BLK])
-                _lib.check(lib.scasml_cholesky(_lib.ptr(Lkk), BLK, 0.0, _lib.ptr(self.info), s), "cholesky(diag)")
-                self.bad += (self.info != 0).to(torch.float64)                # accumulated on the device: no host read inside the loop
-                R[slot * BLK:(slot + 1) * BLK, k * BLK:(k + 1) * BLK] = Lkk
-            cm.broadcast(Lkk, owner)
-            self.diag[k] = Lkk
-            rest = nb - k - 1
-            if rest == 0:
-                break
-            s0 = self._slot0(k)
-            rows = (len(self.mine) - s0) * BLK
-            if rows:
-                _lib.check(lib.scasml_trsm_right_lt(_lib.ptr(Lkk), BLK, BLK, self._ptr(R, s0 * BLK, k * BLK, Mp), Mp, rows, s), "trsm_right_lt")
-            # all-gather the column panel in global block order: rank q = (k + 1 + j) % w holds blocks k + 1 + j, k + 1 + j + w, ...
-            cnt = (rest + w - 1) // w
-            send = torch.zeros((cnt * BLK, BLK), dtype=torch.float64, device="cuda")
-            if rows:
-                send[:rows] = R[s0 * BLK:, k * BLK:(k + 1) * BLK]
-            got = cm.all_gather(send).view(w, cnt, BLK, BLK)
-            order = [(k + 1 + j) % w for j in range(w)]
-            P = got[order].transpose(0, 1).reshape(cnt * w * BLK, BLK)[:rest * BLK].contiguous()
-            if rows:
-                first = self.mine[s0]
-                _lib.check(lib.scasml_gemm_nt_sub(self._ptr(R, s0 * BLK, (k + 1) * BLK, Mp), Mp, rows, rest * BLK,
-                                                  self._ptr(R, s0 * BLK, k * BLK, Mp), Mp, _lib.ptr(P), BLK, BLK,
-                                                  first, w, k + 1, s), "gemm_nt_sub")
-            del P, got, send
+        owner = k % w
+        Lkk = torch.empty((BLK, BLK), dtype=torch.float64, device="cuda")
+        if rank == owner:
+            slot = (k - rank) // w
+            Lkk.copy_(R[slot * BLK:(slot + 1) * BLK, k * BLK:(k + 1) * BLK])
+            _lib.check(lib.scasml_cholesky(_lib.ptr(Lkk), BLK, 0.0, _lib.ptr(self.info), s), "cholesky(diag)")
+            self.bad += (self.info != 0).to(torch.float64)                # accumulated on the device: no host read inside the loop
+            R[slot * BLK:(slot + 1) * BLK, k * BLK:(k + 1) * BLK] = Lkk
+        cm.broadcast(Lkk, owner)
+        self.diag[k] = Lkk
+        rest = nb - k - 1
+        if rest == 0:
+            return None
+        s0 = self._slot0(k)
+        rows = (len(self.mine) - s0) * BLK
+        if rows:
+            _lib.check(lib.scasml_trsm_right_lt(_lib.ptr(Lkk), BLK, BLK, self._ptr(R, s0 * BLK, k * BLK, Mp), Mp, rows, s), "trsm_right_lt")
+        # all-gather the column panel in global block order: rank q = (k + 1 + j) % w holds blocks k + 1 + j, k + 1 + j + w, ...
+        cnt = (rest + w - 1) // w
+        send = torch.zeros((cnt * BLK, BLK), dtype=torch.float64, device="cuda")
+        if rows:
+            send[:rows] = R[s0 * BLK:, k * BLK:(k + 1) * BLK]
+        got = cm.all_gather(send).view(w, cnt, BLK, BLK)
+        order = [(k + 1 + j) % w for j in range(w)]
+        return got[order].transpose(0, 1).reshape(cnt * w * BLK, BLK)[:rest * BLK].contiguous()
+
+    def _update(self, k, P, col0, ncols):
+        """Trailing update of step k on the current stream, restricted to block columns [col0, col0 + ncols): this rank's block rows
+        > k minus (their column-k blocks) x (the panel rows of those columns)^T, tiles above the block diagonal skipped."""
+        lib, s, Mp, w = self.lib, _lib.stream_ptr(), self.Mp, self.comm.world
+        s0 = self._slot0(k)
+        rows = (len(self.mine) - s0) * BLK
+        if rows and ncols > 0:
+            _lib.check(lib.scasml_gemm_nt_sub(self._ptr(self.R, s0 * BLK, col0 * BLK, Mp), Mp, rows, ncols * BLK,
+                                              self._ptr(self.R, s0 * BLK, k * BLK, Mp), Mp,
+                                              C.c_void_p(P.data_ptr() + 8 * (col0 - k - 1) * BLK * BLK), BLK, BLK,
+                                              self.mine[s0], w, col0, s), "gemm_nt_sub")
+
+    def factor(self, lookahead=True):
+        """Right-looking blocked Cholesky over the block rows.  With ``lookahead`` the chain of block column k + 1 -- diagonal factor,
+        broadcast, panel solve, all-gather: short dependent kernels and latency-bound collectives -- runs on a second stream while the
+        caller's stream applies panel k to the block columns beyond k + 1 (the single-GPU factorisation gained 8 % from the same
+        reordering).  The only orderings needed: the chain of k + 1 follows the update of block column k + 1 by panel k,
+        and every update by panel k + 1 follows that chain."""
+        torch = _lib.require_gpu()
+        cm, nb = self.comm, self.nblk
+        main = torch.cuda.current_stream()
+        side = torch.cuda.Stream() if lookahead else main
+        P = self._panel(0)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        for k in range(nb - 1):
+            main.wait_event(ready)                                         # panel k (and diag k) are complete
+            self._update(k, P, k + 1, 1)                                   # block column k + 1 first: the next chain needs only this
+            done = torch.cuda.Event()
+            done.record(main)
+            side.wait_event(done)
+            with torch.cuda.stream(side):
+                Pn = self._panel(k + 1)
+                ready = torch.cuda.Event()
+                ready.record(side)
+            self._update(k, P, k + 2, nb - k - 2)                          # the rest of the trailing matrix, under the chain of k + 1
+            if Pn is not None:
+                Pn.record_stream(main)
+            P.record_stream(side)
+            P = Pn
+        main.wait_event(ready)
         # a failed pivot is seen by the block's owner only: every rank learns of it through ONE all-reduce after the loop, so that all
         # ranks raise together instead of the others walking into the collectives of solve() without the one that raised
         failed = cm.all_reduce(self.bad.clone())

@@ -58,6 +58,8 @@ def test_plain_invocation_spawns_its_ranks_and_reports_both_shardings(ranks, var
     assert s["unit_load_imbalance_max_over_mean"] <= 1.15 or s["sample_ranks"] == 1
     assert s["imbalance_if_all_ranks_shared_samples"] >= s["unit_load_imbalance_max_over_mean"] - 1e-9
     assert s["value"] > 0 and s["roots_leg"]["value"] > 0 and s["scaling"] == "strong"
+    # the sharded estimator IS the unsharded one: same sites, same draws, same surrogate values; only the order of the additions differs
+    assert s["max_abs_diff_vs_unsharded"] <= 2e-5, s["max_abs_diff_vs_unsharded"]
     assert abs(s["roots_leg"]["value"] - j["value"]) / j["value"] < 0.5      # same leg, timed twice
 
 

@@ -51,6 +51,10 @@ def test_world1_factor_and_solve_match_the_single_gpu_path():
     ch = DistCholesky(20, 1.0 / float(gp.sigma) ** 2, dom, bdy, gp.nugget).build().factor()
     assert ch.M == 2100 and ch.nblk == 9 and len(ch.mine) == 9
     _check_against_single_gpu(ch, L, 1e-12)
+    # the look-ahead (next block column's chain on a second stream) only reorders independent work: bit-identical factor
+    plain = DistCholesky(20, 1.0 / float(gp.sigma) ** 2, dom, bdy, gp.nugget).build().factor(lookahead=False)
+    torch.cuda.synchronize()
+    assert torch.equal(plain.R, ch.R) and all(torch.equal(a, b) for a, b in zip(plain.diag, ch.diag))
     Lg = ch.gather_factor()
     assert float((Lg - L).abs().max()) <= 1e-12 * float(L.abs().max())
     b = torch.from_numpy(np.random.default_rng(0).standard_normal(ch.M)).cuda()
