@@ -5,7 +5,7 @@
 // Storage: K (and then L) is cut into block rows of kDistBlock = 256 feature rows; block row i is owned by rank i % world
 // (1-D block-cyclic) and stored as a dense row-major panel of 256 x (i + 1) * 256 doubles -- the lower triangle only.
 // Everything here works on such panels through (pointer, leading dimension) pairs, so the same kernels serve any layout:
-//   scasml_gp_gram_rows    feature rows [row0, row0 + nrows) x feature columns [0, ncols) of K(phi, phi)
+//   (scasml_gp_gram_rows, the Gram rows of a block row, is the FP64-MFMA pair tile of gp_train.hip)
 //   scasml_gemm_nt_sub     C -= A B^T              (FP64 MFMA, v_mfma_f64_16x16x4_f64, 64 x 64 tile per workgroup)
 //   scasml_trsm_right_lt   X <- X L^-T             (the panel solve of the right-looking factorisation)
 //   scasml_gemv_sub        y -= A x  or  y -= A^T x  (the block steps of the distributed substitutions)
@@ -14,59 +14,6 @@
 namespace scasml {
 
 constexpr int kNB = 32;
-
-// ---------------------------------------------------------------------------------- Gram rows
-// One thread per (feature row, collocation point j): the pair geometry once, then the entries of that row against the 1 or
-// 4 operators of point j.  Closed forms: SURVEY.md Appendix C (the same table as gp_gram_kernel in gp_train.hip).
-__global__ void gp_gram_rows_kernel(int d, double a, const float *x_dom, int n_dom, const float *x_bdy, int n_bdy, int64_t row0,
-                                    int nrows, int64_t ncols, double *out, int64_t ld) {
-    const int N = n_dom + n_bdy;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int rr = blockIdx.y * blockDim.y + threadIdx.y;
-    if (rr >= nrows || j >= N) return;
-    const int64_t row = row0 + rr;
-    // feature row -> (operator, point): u(dom) | u(bdy) | Lap(dom) | dt(dom) | div(dom)
-    int ox, i;
-    if (row < N) {
-        ox = 0;
-        i = (int)row;
-    } else {
-        const int64_t q = row - N;
-        ox = 1 + (int)(q / n_dom);
-        i = (int)(q % n_dom);
-    }
-    const float *xi = i < n_dom ? x_dom + (int64_t)i * (d + 1) : x_bdy + (int64_t)(i - n_dom) * (d + 1);
-    const float *yj = j < n_dom ? x_dom + (int64_t)j * (d + 1) : x_bdy + (int64_t)(j - n_dom) * (d + 1);
-    double r2 = 0.0, S = 0.0;
-    for (int k = 0; k < d; ++k) {
-        const double r = (double)xi[k] - (double)yj[k];
-        r2 = fma(r, r, r2);
-        S += r;
-    }
-    const double rt = (double)xi[d] - (double)yj[d];
-    const double rho2 = r2;
-    r2 = fma(rt, rt, r2);
-    const double kap = exp(-0.5 * a * r2);
-    const double lap = a * a * rho2 - a * d;
-    double P[4];   // this row's operator against I, Lap, dt, div in y
-    if (ox == 0) {
-        P[0] = 1.0; P[1] = lap; P[2] = a * rt; P[3] = a * S;
-    } else if (ox == 1) {
-        P[0] = lap;
-        P[1] = a * a * a * a * rho2 * rho2 - (2.0 * d + 4.0) * a * a * a * rho2 + ((double)d * d + 2.0 * d) * a * a;
-        P[2] = a * rt * lap;
-        P[3] = a * S * lap - 2.0 * a * a * S;
-    } else if (ox == 2) {
-        P[0] = -a * rt; P[1] = -a * rt * lap; P[2] = a - a * a * rt * rt; P[3] = -a * a * rt * S;
-    } else {
-        P[0] = -a * S; P[1] = -(a * S * lap - 2.0 * a * a * S); P[2] = -a * a * rt * S; P[3] = a * d - a * a * S * S;
-    }
-    const int nops_j = j < n_dom ? 4 : 1;
-    for (int oy = 0; oy < nops_j; ++oy) {
-        const int64_t col = oy == 0 ? j : (int64_t)N + (int64_t)(oy - 1) * n_dom + j;
-        if (col < ncols) out[(int64_t)rr * ld + col] = P[oy] * kap;
-    }
-}
 
 // ---------------------------------------------------------------------------------- C -= A B^T
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -235,21 +182,6 @@ __global__ __launch_bounds__(256) void gemv_t_sub_kernel(const double *A, int64_
 }  // namespace scasml
 
 using namespace scasml;
-
-extern "C" int scasml_gp_gram_rows(int32_t d, double a, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy,
-                                   int64_t row0, int32_t nrows, int64_t ncols, double *out, int64_t ld, void *stream) {
-    if (!x_dom || !out || (n_bdy > 0 && !x_bdy)) return fail(SCASML_ERR_ARG, "gp_gram_rows: null argument");
-    const int64_t M = 4 * (int64_t)n_dom + n_bdy;
-    if (d < 1 || n_dom < 1 || n_bdy < 0 || row0 < 0 || nrows < 0 || row0 + nrows > M || ncols < 0 || ncols > M || ld < ncols)
-        return fail(SCASML_ERR_ARG, "gp_gram_rows: bad sizes");
-    if (nrows == 0 || ncols == 0) return 0;
-    const int N = n_dom + n_bdy;
-    const unsigned gy = (unsigned)((nrows + 3) / 4);
-    if (gy > 65535) return fail(SCASML_ERR_UNSUPPORTED, "gp_gram_rows: more than 262140 rows per call");
-    hipLaunchKernelGGL(gp_gram_rows_kernel, dim3((N + 63) / 64, gy), dim3(64, 4), 0, (hipStream_t)stream, d, a, x_dom, n_dom, x_bdy,
-                       n_bdy, row0, nrows, ncols, out, ld);
-    return check_launch("gp_gram_rows launch");
-}
 
 extern "C" int scasml_gemm_nt_sub(double *C, int64_t ldc, int64_t rows, int64_t cols, const double *A, int64_t lda, const double *B,
                                   int64_t ldb, int64_t K, int64_t tri_row0, int64_t tri_stride, int64_t tri_col0, void *stream) {

@@ -318,6 +318,93 @@ __global__ __launch_bounds__(256) void gp_gram_mfma_kernel(int d, double a, cons
     }
 }
 
+// The same tile for a RANGE OF FEATURE ROWS (block-row distributed fits, scasml_gp_gram_rows): the rows of one operator `ox` at the
+// points [i_lo, i_lo + n_i), against every collocation point j; each pair writes its 1 or 4 entries of that row (columns < ncols
+// only -- the distributed factor stores the lower triangle).  out points at the first of those rows; tiles whose smallest column
+// (the u column of their first point) is already >= ncols have nothing to write.
+__global__ __launch_bounds__(256) void gp_gram_rows_mfma_kernel(int d, double a, const float *x_dom, int n_dom, const float *x_bdy, int n_bdy,
+                                                                int ox, int i_lo, int n_i, int64_t ncols, double *out, int64_t ld) {
+    constexpr int NT = 2, TBX = 32 * NT, PER = TBX * NB / 256;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double stat[2 * TBX][4];
+    const int N = n_dom + n_bdy;
+    const int i0 = i_lo + blockIdx.y * TBX, j0 = blockIdx.x * TBX, i_end = i_lo + n_i;
+    if ((int64_t)j0 >= ncols) return;             // block-uniform: every column of this tile lies beyond the stored part of these rows
+    auto row_of = [&](int p) { return p < n_dom ? x_dom + (int64_t)p * (d + 1) : x_bdy + (int64_t)(p - n_dom) * (d + 1); };
+    {
+        const int q = threadIdx.x >> 1, par = threadIdx.x & 1;
+        const int p = q < TBX ? i0 + q : j0 + q - TBX;
+        const bool live = q < TBX ? p < i_end : p < N;
+        double n = 0.0, sx = 0.0, tt = 0.0;
+        if (live) {
+            const float *x = row_of(p);
+            for (int k = par; k < d; k += 2) {
+                const double v = (double)x[k];
+                n = fma(v, v, n);
+                sx += v;
+            }
+            tt = (double)x[d];
+        }
+        n += __shfl_xor(n, 1);
+        sx += __shfl_xor(sx, 1);
+        if (par == 0) {
+            stat[q][0] = fma(tt, tt, n);
+            stat[q][1] = sx;
+            stat[q][2] = tt;
+        }
+    }
+    TileAcc<NT> t;
+    mfma_tile_zero(t);
+    const int64_t kend = ((int64_t)d + 1 + NB - 1) / NB * NB;
+    mfma_tile_k_loop<NT>(smem, 0, kend, [&](int64_t kk, double (&ra)[PER], double (&rb)[PER]) {
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int idx = threadIdx.x + e * 256, rr = idx / NB, cc = idx % NB;
+            const int k = (int)kk + cc;
+            ra[e] = (i0 + rr < i_end && k <= d) ? (double)row_of(i0 + rr)[k] : 0.0;
+            rb[e] = (j0 + rr < N && k <= d) ? (double)row_of(j0 + rr)[k] : 0.0;
+        }
+    }, [] {}, t);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wr = (wv >> 1) * (16 * NT), wc = (wv & 1) * (16 * NT);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const double fd = (double)d;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+        const int j = j0 + wc + 16 * jt + l15;
+        if (j >= N) continue;
+        const double nj = stat[TBX + j - j0][0], sj = stat[TBX + j - j0][1], tj = stat[TBX + j - j0][2];
+        const int nops_j = j < n_dom ? 4 : 1;
+#pragma unroll
+        for (int it = 0; it < NT; ++it)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = i0 + wr + 16 * it + l4 + 4 * e;
+                if (i >= i_end) continue;
+                const double ni = stat[i - i0][0], si = stat[i - i0][1], ti = stat[i - i0][2];
+                double r2 = fma(-2.0, t.v[it][jt][e], ni + nj);
+                r2 = r2 < 0.0 ? 0.0 : r2;
+                const double rt = ti - tj, S = si - sj;
+                double rho2 = fma(-rt, rt, r2);
+                rho2 = rho2 < 0.0 ? 0.0 : rho2;
+                const double kap = exp(-0.5 * a * r2);
+                const double lap = a * a * rho2 - a * fd;
+                const double aS = a * S, art = a * rt, mix = aS * lap - 2.0 * a * aS;
+                // the operator table of gp_gram_mfma_kernel; this launch writes its row `ox`
+                const double P[4][4] = {
+                    {1.0, lap, art, aS},
+                    {lap, a * a * a * a * rho2 * rho2 - (2.0 * fd + 4.0) * a * a * a * rho2 + (fd * fd + 2.0 * fd) * a * a, art * lap, mix},
+                    {-art, -art * lap, a - art * art, -art * aS},
+                    {-aS, -mix, -art * aS, a * fd - aS * aS}};
+                double *orow = out + (int64_t)(i - i_lo) * ld;
+                for (int oy = 0; oy < nops_j; ++oy) {
+                    const int64_t col = oy == 0 ? j : (int64_t)N + (int64_t)(oy - 1) * n_dom + j;
+                    if (col < ncols) orow[col] = P[ox][oy] * kap;
+                }
+            }
+    }
+}
+
 // (3) trailing update with a panel of K columns [J, J + K), lower triangle only:
 //   C[r][c] -= sum_k A[r][J + k] * A[c][J + k]   for rows r >= R0, columns R0 <= c < col_end,
 // one tile per workgroup, the panel streamed through LDS NB columns at a time while the tile stays in the
@@ -887,3 +974,41 @@ extern "C" int scasml_gp_gram(int32_t d, double a, const float *x_dom, int32_t n
     return check_launch("gp_gram launch");
 }
 
+// Feature rows [row0, row0 + nrows) x columns [0, ncols) of K(phi, phi) for the block-row distributed factorisation: the row range is
+// cut at the operator boundaries of the feature order [u(dom), u(bdy), Lap(dom), dt(dom), div(dom)] and every piece -- one operator,
+// a contiguous range of points -- is one launch of the FP64-MFMA pair tile.
+extern "C" int scasml_gp_gram_rows(int32_t d, double a, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy,
+                                   int64_t row0, int32_t nrows, int64_t ncols, double *out, int64_t ld, void *stream) {
+    if (!x_dom || !out || (n_bdy > 0 && !x_bdy)) return fail(SCASML_ERR_ARG, "gp_gram_rows: null argument");
+    const int64_t M = 4 * (int64_t)n_dom + n_bdy;
+    if (d < 1 || n_dom < 1 || n_bdy < 0 || row0 < 0 || nrows < 0 || row0 + nrows > M || ncols < 0 || ncols > M || ld < ncols)
+        return fail(SCASML_ERR_ARG, "gp_gram_rows: bad sizes");
+    if (nrows == 0 || ncols == 0) return 0;
+    const int N = n_dom + n_bdy;
+    if (!reserve_lds(gp_gram_rows_mfma_kernel, tile_lds_bytes<2>())) return fail(SCASML_ERR_HIP, "gp_gram_rows: cannot reserve LDS");
+    const unsigned gx = (unsigned)((N + 63) / 64);
+    int64_t r = row0;
+    const int64_t r_end = row0 + nrows;
+    while (r < r_end) {
+        int ox, i_lo;
+        int64_t seg_end;                          // first row past this operator's block
+        if (r < N) {
+            ox = 0;
+            i_lo = (int)r;
+            seg_end = N;
+        } else {
+            const int64_t q = r - N;
+            ox = 1 + (int)(q / n_dom);
+            i_lo = (int)(q % n_dom);
+            seg_end = (int64_t)N + (int64_t)ox * n_dom;
+        }
+        const int64_t stop = seg_end < r_end ? seg_end : r_end;
+        const int n_i = (int)(stop - r);
+        const unsigned gy = (unsigned)((n_i + 63) / 64);
+        if (gy > 65535) return fail(SCASML_ERR_UNSUPPORTED, "gp_gram_rows: too many rows per call");
+        hipLaunchKernelGGL(gp_gram_rows_mfma_kernel, dim3(gx, gy), dim3(256), tile_lds_bytes<2>(), (hipStream_t)stream, d, a, x_dom, n_dom, x_bdy,
+                           n_bdy, ox, i_lo, n_i, ncols, out + (r - row0) * ld, ld);
+        r = stop;
+    }
+    return check_launch("gp_gram_rows launch");
+}

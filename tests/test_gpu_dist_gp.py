@@ -64,6 +64,28 @@ def test_world1_factor_and_solve_match_the_single_gpu_path():
     assert float((ch.matvec(b) - Kp @ b).abs().max()) <= 1e-11 * float((Kp @ b).abs().max())
 
 
+@pytest.mark.parametrize("row0,nrows,ncols", [(0, 630, 630), (100, 300, 400), (170, 20, 190), (329, 257, 586), (480, 150, 37), (629, 1, 630)])
+def test_gram_rows_tile_kernel_equals_the_rows_of_the_full_gram(row0, nrows, ncols):
+    """scasml_gp_gram_rows (FP64-MFMA pair tiles, one launch per operator segment of the row range) against the same rows of
+    scasml_gp_gram, for ranges that start and end inside, and straddle, the operator blocks [u(dom) u(bdy) | Lap | dt | div]."""
+    import torch
+    from scasml_gp_amd import _lib
+    lib = _lib.load()
+    d, nd, nb = 20, 150, 30
+    eq, dom, bdy = _problem(d, nd, nb)
+    xd = torch.from_numpy(np.ascontiguousarray(dom, dtype=np.float32)).cuda()
+    xb = torch.from_numpy(np.ascontiguousarray(bdy, dtype=np.float32)).cuda()
+    M = 4 * nd + nb
+    a = 1.0 / (0.25 ** 2 * d)
+    K = torch.empty((M, M), dtype=torch.float64, device="cuda")
+    _lib.check(lib.scasml_gp_gram(d, a, _lib.ptr(xd), nd, _lib.ptr(xb), nb, _lib.ptr(K), _lib.stream_ptr()), "gp_gram")
+    ld = ncols + 5
+    out = torch.full((nrows, ld), -7.0, dtype=torch.float64, device="cuda")
+    _lib.check(lib.scasml_gp_gram_rows(d, a, _lib.ptr(xd), nd, _lib.ptr(xb), nb, row0, nrows, ncols, _lib.ptr(out), ld, _lib.stream_ptr()), "gp_gram_rows")
+    assert torch.equal(out[:, :ncols], K[row0:row0 + nrows, :ncols])
+    assert bool((out[:, ncols:] == -7.0).all())                     # nothing beyond the requested columns is touched
+
+
 def _worker(rank, world, port, case, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch
