@@ -226,7 +226,10 @@ template <int KS, int BPC, bool R16>
 __global__ __launch_bounds__(256, BPC) void gp_eval_compat_mfma_kernel(const GpCompatArgs g) {
     // three slots: stage s is read while s + 1 has landed or lands and s + 2 is issued into the slot stage s - 1 was read from, which
     // every wave left before the barrier that ended step s - 1
-    constexpr int WPB = 4, NSLOT = 3, AHEAD = 2;
+#ifndef SCASML_COMPAT_NSLOT
+#define SCASML_COMPAT_NSLOT 3
+#endif
+    constexpr int WPB = 4, NSLOT = SCASML_COMPAT_NSLOT, AHEAD = 2;
     constexpr int STAGE = KS * 256 + kStageTail;       // floats per LDS slot
     constexpr int NCHUNK = STAGE / 256;
     constexpr int CLO = NCHUNK / WPB, CREM = NCHUNK % WPB;
@@ -563,7 +566,7 @@ static int launch_compat(const GpCompatArgs &g, hipStream_t s) {
     const int64_t waves = (g.n_inf + 31) / 32;
     const int64_t blocks = (waves + 3) / 4;
     if (blocks > 0x7FFFFFFF) return fail(SCASML_ERR_UNSUPPORTED, "gp_eval_compat_sites: too many points");
-    constexpr size_t lds_bytes = 3 * (size_t)(KS * 256 + kStageTail) * sizeof(float);
+    constexpr size_t lds_bytes = SCASML_COMPAT_NSLOT * (size_t)(KS * 256 + kStageTail) * sizeof(float);
     static_assert(lds_bytes * BPC <= 160 * 1024, "LDS slots exceed 160 KiB");
     auto kern = gp_eval_compat_mfma_kernel<KS, BPC, R16>;
     if (lds_bytes > 64 * 1024) {
