@@ -10,6 +10,7 @@ __global__ __launch_bounds__(1024) void k(float *out, int iters, float a, float 
     asm volatile("" : "+v"(av), "+v"(bv));
     typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
     typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     h16x8 ab = {1, 2, 3, 4, 5, 6, 7, 8};
     f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -41,6 +42,28 @@ __global__ __launch_bounds__(1024) void k(float *out, int iters, float a, float 
                 if (MODE == 20) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(v[i]) : "v"(av));
                 if (MODE == 21) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(v[i]) : "v"(av));
                 if (MODE == 16) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(v[i]) : "v"(av));
+                // float16 forms of the as-coded surrogate's epilogue (round 3)
+                if (MODE == 22) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[0,1,0]" : "+v"(v[i]) : "v"(av), "v"(bv));
+                if (MODE == 23) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(v[i]) : "v"(av), "v"(bv));
+                if (MODE == 24) asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(v[i]) : "v"(av));
+                if (MODE == 25) asm volatile("v_cvt_f16_f32 %0, %0" : "+v"(v[i]));
+                if (MODE == 26) asm volatile("v_fma_mixlo_f16 %0, %0, %1, 0" : "+v"(v[i]) : "v"(av));
+                if (MODE == 27) asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(v[i]) : "v"(av), "v"(bv));
+                if (MODE == 28) asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(v[i]) : "v"(av));
+                if (MODE == 29) asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(v[i]) : "v"(av), "v"(bv));
+                if (MODE == 30) asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(v[i]) : "v"(av), "v"(bv));
+                if (MODE == 31) asm volatile("v_cvt_f32_f16 %0, %0" : "+v"(v[i]));
+                if (MODE == 32) asm volatile("v_exp_f16 %0, %0" : "+v"(v[i]));
+                if (MODE == 33) asm volatile("v_fma_f16 %0, %0, %1, %2" : "+v"(v[i]) : "v"(av), "v"(bv));
+                if (MODE == 34 && i < 16) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(*(f32x2 *)&v[2 * i]) : "v"(*(f32x2 *)&v[2 * ((i + 5) & 15)]));
+                if (MODE == 35 && i < 16) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(*(f32x2 *)&v[2 * i]) : "v"(*(f32x2 *)&v[2 * ((i + 5) & 15)]), "v"(*(f32x2 *)&v[2 * ((i + 9) & 15)]));
+                if (MODE == 36) asm volatile("v_mul_f16 %0, %0, %1" : "+v"(v[i]) : "v"(av));
+                if (MODE == 37) asm volatile("v_log_f32 %0, %0" : "+v"(v[i]));
+                if (MODE == 38) asm volatile("v_rcp_f32 %0, %0" : "+v"(v[i]));
+                if (MODE == 39) {   // the epilogue's pattern: an exp every 8 plain instructions
+                    if (i % 8 == 0) asm volatile("v_exp_f32 %0, %0" : "+v"(v[i]));
+                    else asm volatile("v_mul_f32 %0, %0, %1" : "+v"(v[i]) : "v"(av));
+                }
                 if (MODE >= 10 && MODE <= 13) {   // v_fma stream with an MFMA every 16 (10, 12) or 8 (11, 13) of them
                     const int every = (MODE & 1) ? 8 : 16;
                     if (i % every == 0) {
@@ -97,6 +120,25 @@ int main() {
     run<14>(out, "v_mad_u64_u32 + v_xor_b32 (pair)");
     run<15>(out, "v_mul_hi_u32");
     run<16>(out, "v_mul_u32_u24");
+    printf("float16 forms (round 3; v_pk_*_f32 lines: 32 instructions per iteration counted as 64, i.e. cycles per TWO results)\n");
+    run<22>(out, "v_fma_mix_f32 (f32 x f16lo + f32)");
+    run<23>(out, "v_fma_mix_f32 (f32 x f16hi + f32)");
+    run<24>(out, "v_cvt_pk_f16_f32");
+    run<25>(out, "v_cvt_f16_f32");
+    run<26>(out, "v_fma_mixlo_f16");
+    run<27>(out, "v_pk_fma_f16");
+    run<28>(out, "v_pk_mul_f16");
+    run<29>(out, "v_dot2_f32_f16");
+    run<30>(out, "v_dot2c_f32_f16");
+    run<31>(out, "v_cvt_f32_f16");
+    run<32>(out, "v_exp_f16");
+    run<33>(out, "v_fma_f16");
+    run<36>(out, "v_mul_f16");
+    run<34>(out, "v_pk_mul_f32 (per 2 results)");
+    run<35>(out, "v_pk_fma_f32 (per 2 results)");
+    run<37>(out, "v_log_f32");
+    run<38>(out, "v_rcp_f32");
+    run<39>(out, "1 v_exp_f32 per 7 v_mul_f32");
     printf("64 v_fma_f32 per iteration plus MFMAs (cycles per v_fma, MFMA time included)\n");
     run<10>(out, "+ 4 x mfma 16x16x32 (1 per 16)");
     run<11>(out, "+ 8 x mfma 16x16x32 (1 per 8)");
