@@ -391,8 +391,9 @@ def main():
                              "coexec_frac_of_mfma_busy": round(pj["coexec_frac_of_mfma_busy"], 3),
                              "cycles_per_valu_instruction": round(pj["cycles_per_valu_instruction"], 2),
                              "effective_clock_ghz": round(pj.get("effective_clock_ghz", 0.0), 3),
-                             "source": os.path.relpath(prof, ROOT), "note": "the kernel is VALU-bound: the vector ALUs are busy this "
-                             "fraction of the launch; the MFMA fraction quoted as `frac` is of a roof the kernel is not under"}
+                             "source": os.path.relpath(prof, ROOT), "note": "vector time and matrix time ADD on this chip (ablation and instruction-level "
+                             "microbenchmarks: profiles/r03_compat_eval_experiments.txt, DESIGN.md 4.4): the launch is t_vector + t_matrix, the "
+                             "counters' busy fractions overlap only in issue; `frac` is of the matrix roof alone"}
                 break
         except Exception:
             continue
@@ -438,7 +439,7 @@ def main():
                         "note": "achieved = algorithmic flops of SURVEY 8(d) (2 N_inf N (d+1) + 10 N_inf M: ONE x.y product per pair); the as-coded "
                                 "surrogate needs three (aligned, y shifted, x shifted) in two fp16 planes each, and 13 separately float16-rounded "
                                 "entries per pair in the epilogue (~50 vector instructions + 3 exp against 14 + 1 for the documented operators): "
-                                "the kernel is bound by vector issue, not by the matrix pipe (valu_issue; DESIGN.md 4.4)"}
+                                "the launch time is vector time plus matrix time, which do not overlap on this chip (valu_issue; DESIGN.md 4.4)"}
         else:
             split = int(gp.eval_split)
             products = {0: 1, 2: 3, 3: 6, 22: 2 if getattr(gp, "_colloc_is_f16", False) else 3}[split]

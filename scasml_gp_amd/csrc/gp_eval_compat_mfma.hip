@@ -25,9 +25,12 @@
 // reads the fp16 half directly: a rounding costs half a vector instruction.  A rounding decision can differ from the float64
 // statement's where the float32 value lands within ~2^-20 of a float16 midpoint (about 1 entry in 500); tests bound the effect.
 //
-// (Measured and not kept, profiles/r03_compat_eval_experiments.txt: the four sums as a second MFMA on the packed float16 entries --
-// the accumulator-as-operand idiom, coefficients as A fragments -- removes 16 of the ~50 vector instructions per pair but adds 32
-// MFMAs per tile to a kernel whose clock already sags when both pipes are busy: 21.25 ms against 19.75-19.96 on one box.)
+// Measured and not kept (profiles/r03_compat_eval_experiments.txt).  On this chip a 32x32x16 MFMA and the vector instructions around it do not
+// overlap -- the launch time is vector time PLUS matrix time, whether the fifteen MFMAs of a stage come as a block (here) or one at a time
+// between the epilogue's instructions (a software pipeline inside the wave: built, 3 - 10 % slower) -- so moving the sums' ~16 v_fma_mix_f32 per
+// pair (43 % of the vector time) to the matrix pipe trades them one for one: as a second 32x32x16 MFMA on the packed entries 21.25 ms against
+// 19.75-19.96; as v_mfma_f32_4x4x4_16b_f16, whose A operand the float16 entries of four consecutive accumulator registers already are, 2.776
+// against 2.759 ms on 9216 workgroups.  tools/ubench_chain.hip, ubench_overlap.hip, ubench_valu_forms.hip are the instruction-level evidence.
 //
 // Structure (as gp_eval_bf16.hip): 4-wave workgroups, 32 points per wave held in VGPRs as two fp16 planes for the whole sweep;
 // the unit of work is a STAGE = (collocation tile of 32 rows, geometry): [KS KiB A fragments | 1 KiB Q fragment | 1 KiB row
