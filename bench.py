@@ -223,7 +223,12 @@ def main():
     if args.rehearse_on_one_gpu:
         local = 0
     torch.cuda.set_device(local)
-    if world > 1:
+    # SCASML_BENCH_FORCE_DIST=1: take the torch.distributed branches at WORLD_SIZE = 1 too, so that a one-GPU box can at least show
+    # init_process_group("nccl"), the barrier and an RCCL all-reduce of the path's (B, 1+d) buffer executing (tests/test_gpu_bench_contract.py)
+    dist_on = world > 1 or os.environ.get("SCASML_BENCH_FORCE_DIST") == "1"
+    if dist_on:
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
+            os.environ.setdefault(k, v)
         if args.rehearse_on_one_gpu:
             dist.init_process_group("gloo")
         else:
@@ -282,17 +287,17 @@ def main():
         """W untimed + K timed steps, barrier + synchronize on both sides, MAX over ranks (seconds)."""
         for _ in range(args.warmup):
             step_fn()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step_fn()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if dist_on:
             t = torch.tensor([dt], dtype=torch.float64, device="cpu" if on_host else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -357,8 +362,22 @@ def main():
         dmax = torch.tensor([float((sharded - whole).abs().max()) if g_cnt else 0.0], dtype=torch.float64, device="cpu" if on_host else "cuda")
         dist.all_reduce(dmax, op=dist.ReduceOp.MAX)
         samples_leg["max_abs_diff_vs_unsharded"] = float(dmax.item())
+    rccl_selftest = None
+    if dist_on and world == 1 and not on_host:
+        # one rank: the all-reduce of the path's partial-sum buffer through RCCL (a copy onto itself), timed with HIP events
+        buf = torch.randn((B, d + 1), dtype=torch.float32, device="cuda")
+        ref = buf.clone()
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)          # (parallel.allreduce_partial_sums skips the call on one rank)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        e1.record()
+        torch.cuda.synchronize()
+        rccl_selftest = {"ranks": 1, "buffer": "(%d, %d) f32" % (B, d + 1), "allreduce_ms": round(e0.elapsed_time(e1) / 10, 4),
+                         "unchanged": bool(torch.equal(buf, ref))}
     if rank != 0:
-        if world > 1:
+        if dist_on:
             dist.destroy_process_group()
         return
 
@@ -505,10 +524,11 @@ def main():
         "metric": "Euler-Maruyama path-steps/sec + L2 rel-error, Grad_Dependent_Nonlinear d=%d n=%d" % (d, n),
         "value": round(value, 1), "unit": "path-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-        "scaling": "weak" if main_step is roots_step else "strong", "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+        "scaling": "weak" if main_step is roots_step else "strong", "rccl_ranks": dist.get_world_size() if dist_on else 1,
         "rccl_note": "no multi-GPU node has been available to this build: the N > 1 path (init_process_group('nccl'), the in-group all-reduce) is "
-                     "rehearsed over gloo on one GPU only (tests/test_gpu_bench_contract.py) until a SCALE run exists",
-        "backend": (dist.get_backend() if world > 1 else None), "samples_sharding": samples_leg,
+                     "rehearsed over gloo on one GPU only (tests/test_gpu_bench_contract.py) until a SCALE run exists; with SCASML_BENCH_FORCE_DIST=1 the "
+                     "same branches run over RCCL with one rank (rccl_selftest)",
+        "backend": (dist.get_backend() if dist_on else None), "rccl_selftest": rccl_selftest, "samples_sharding": samples_leg,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "Grad_Dependent_Nonlinear d=%d, %s, B=%d roots/GPU%s" % (
                        d, name, B, " (BASELINE.json configs[2])" if (args.solver, args.variant, d, n) == ("scasml", "quad", 100, 3) else ""),
@@ -531,7 +551,7 @@ def main():
         "roofline": roofline, "roofline_path": path_roof, "gp_train": gp_train, "cpu_baseline": cpu,
     }
     print(json.dumps(line))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -89,3 +89,20 @@ def test_sample_sharded_result_does_not_depend_on_the_rank_count():
         assert torch.allclose(eng.finalize_partials(total), full, atol=2e-5, rtol=1e-5), world
     owner, _, load = eng.unit_owners(4, 3, 8)
     assert len(owner) == 201 and load.max() / load.mean() < 1.5
+
+
+@pytest.mark.gpu
+def test_the_rccl_branches_execute_on_one_rank():
+    """A one-GPU box cannot host two RCCL ranks; what it can show is that the branches the N > 1 run takes -- init_process_group("nccl"),
+    the barriers and MAX-reduction around the timed region, an all-reduce of the path's (B, 1+d) partial-sum buffer, the teardown --
+    execute on this image, with WORLD_SIZE = 1 (SCASML_BENCH_FORCE_DIST=1)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "256",
+           "--train-domain", "96", "--train-boundary", "32", "--no-cpu-baseline"]
+    env = dict(os.environ, SCASML_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 200),
+               RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["backend"] == "nccl" and j["rccl_ranks"] == 1 and j["value"] > 0
+    st = j["rccl_selftest"]
+    assert st["ranks"] == 1 and st["unchanged"] and st["allreduce_ms"] > 0

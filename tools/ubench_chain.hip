@@ -9,7 +9,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int WHAT, bool LDSA, bool CHAIN, bool EXPS, bool DSRD>
+template <int WHAT, bool LDSA, bool CHAIN, bool EXPS, bool DSRD, int VK = 0>
 __global__ __launch_bounds__(1024) void k(float *out, int iters, const float *rnd) {
     __shared__ f32x4 lds[16 * 64];
     f32x16 acc[2];
@@ -52,6 +52,9 @@ __global__ __launch_bounds__(1024) void k(float *out, int iters, const float *rn
                 for (int i = 0; i < 16; ++i) {
                     float &x = v[(s * 8 + i) & 31];
                     if (EXPS && i < 4) x = __builtin_amdgcn_exp2f(x);
+                    else if (VK == 1) asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[0,1,0]" : "+v"(x) : "v"(c0), "v"(c1));      // float32 x float16 + float32
+                    else if (VK == 2) asm("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(x) : "v"(c1));
+                    else if (VK == 3) asm("v_exp_f32 %0, %0" : "+v"(x));
                     else x = x * ((i & 1) ? c1 : c0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -65,27 +68,27 @@ __global__ __launch_bounds__(1024) void k(float *out, int iters, const float *rn
     out[blockIdx.x * blockDim.x + threadIdx.x] = sum;
 }
 static int g_blocks = 256;
-template <int WHAT, bool LDSA, bool CHAIN, bool EXPS, bool DSRD>
+template <int WHAT, bool LDSA, bool CHAIN, bool EXPS, bool DSRD, int VK = 0>
 float run(float *out, const float *rnd, int threads) {
     const int iters = 20000;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
-    hipLaunchKernelGGL((k<WHAT, LDSA, CHAIN, EXPS, DSRD>), dim3(g_blocks), dim3(threads), 0, 0, out, 100, rnd);
+    hipLaunchKernelGGL((k<WHAT, LDSA, CHAIN, EXPS, DSRD, VK>), dim3(g_blocks), dim3(threads), 0, 0, out, 100, rnd);
     (void)hipEventRecord(e0);
-    hipLaunchKernelGGL((k<WHAT, LDSA, CHAIN, EXPS, DSRD>), dim3(g_blocks), dim3(threads), 0, 0, out, iters, rnd);
+    hipLaunchKernelGGL((k<WHAT, LDSA, CHAIN, EXPS, DSRD, VK>), dim3(g_blocks), dim3(threads), 0, 0, out, iters, rnd);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
     float ms;
     (void)hipEventElapsedTime(&ms, e0, e1);
     return ms * 1e6f / iters / 4;   // ns per step (1 MFMA + 16 vector instructions per wave)
 }
-template <bool LDSA, bool CHAIN, bool EXPS, bool DSRD>
+template <bool LDSA, bool CHAIN, bool EXPS, bool DSRD, int VK = 0>
 void line(float *out, const float *rnd, const char *what) {
     printf("  %-44s", what);
     for (int threads = 256; threads <= 1024; threads *= 2) {
-        const float both = run<0, LDSA, CHAIN, EXPS, DSRD>(out, rnd, threads), m = run<1, LDSA, CHAIN, EXPS, DSRD>(out, rnd, threads),
-                    v = run<2, LDSA, CHAIN, EXPS, DSRD>(out, rnd, threads);
+        const float both = run<0, LDSA, CHAIN, EXPS, DSRD, VK>(out, rnd, threads), m = run<1, LDSA, CHAIN, EXPS, DSRD, VK>(out, rnd, threads),
+                    v = run<2, LDSA, CHAIN, EXPS, DSRD, VK>(out, rnd, threads);
         printf("   %dw: both %5.1f mfma %5.1f vec %5.1f", threads / 256, both, m, v);
     }
     printf("\n");
@@ -106,5 +109,8 @@ int main(int argc, char **argv) {
     line<true, true, true, false>(out, rnd, "A from LDS, one chain, 4 of 16 are v_exp");
     line<true, true, false, true>(out, rnd, "A from LDS, one chain, vector operands from LDS");
     line<true, true, true, true>(out, rnd, "A from LDS, one chain, v_exp, operands from LDS");
+    line<true, true, false, false, 1>(out, rnd, "A from LDS, one chain, 16 v_fma_mix_f32");
+    line<true, true, false, false, 2>(out, rnd, "A from LDS, one chain, 16 v_cvt_pk_f16_f32");
+    line<true, true, false, false, 3>(out, rnd, "A from LDS, one chain, 16 v_exp_f32");
     return 0;
 }
