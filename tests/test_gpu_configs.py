@@ -13,17 +13,33 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+SURROGATES = pytest.mark.parametrize("compat", ["reference", None], ids=["as-coded", "documented"])
+
+
 def _oracle_with(gp, d):
-    """The oracle surrogate carrying the coefficients the HIP fit produced (no second fit on the CPU)."""
+    """The oracle surrogate carrying the coefficients the HIP fit produced (no second fit on the CPU): the reference's as-coded
+    surrogate (oracle/gp_compat.py, same Hutchinson indices) for the default GP, the documented operators for GP(compat=None)."""
     from oracle.equation import GradDependentNonlinear
     from oracle.gp import OracleGP
+    from oracle.gp_compat import OracleGPCompat
     oeq = GradDependentNonlinear(d + 1)
-    ogp = OracleGP(oeq)
+    ogp = OracleGPCompat(oeq, gp.laplacian_idx, round_factor=False) if gp.compat == "reference" else OracleGP(oeq)
     ogp.x_t_domain = np.asarray(gp.x_t_domain, dtype=np.float64)
     ogp.x_t_boundary = np.asarray(gp.x_t_boundary, dtype=np.float64)
     ogp.N_domain, ogp.N_boundary = len(ogp.x_t_domain), len(ogp.x_t_boundary)
+    ogp.phi_dim = 4 * ogp.N_domain + ogp.N_boundary
     ogp.right_vector = gp.right_vector
     return oeq, ogp
+
+
+def _assert_close_to_oracle(gp, got, want):
+    diff = np.abs(got - want)
+    if gp.compat == "reference":
+        # u_hat and eps_PDE are float16 values: an entry rounded differently (float32 value here, float64 there) moves u_hat by one float16
+        # ulp and a z component by that times N / (MC delta_t) -- rare and bounded (tests/test_gpu_full_size.py uses the same bounds)
+        assert diff[:, 0].max() < 3e-4 and (diff > 1e-4).mean() < 0.08 and diff.max() < 1e-2, (diff[:, 0].max(), (diff > 1e-4).mean(), diff.max())
+    else:
+        assert np.all(diff <= 5e-5 + 2e-4 * np.abs(want)), diff.max()
 
 
 def test_config0_gp_only_d10_256_collocation_points():
@@ -54,8 +70,8 @@ def test_config0_gp_only_d10_256_collocation_points():
 D3, N3, M3, B3 = 100, 4, 3, 1 << 14
 
 
-@pytest.fixture(scope="module")
-def config3():
+@pytest.fixture(scope="module", params=["reference", None], ids=["as-coded", "documented"])
+def config3(request):
     import torch
     from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
     from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
@@ -65,7 +81,7 @@ def config3():
     np.random.seed(1234)
     dom, bdy = eq.generate_data(1000, 200)
     np.random.set_state(state)
-    gp = GP_Grad_Dependent_Nonlinear(eq, compat=None)
+    gp = GP_Grad_Dependent_Nonlinear(eq, compat=request.param)
     gp.GPsolver(dom, bdy, GN_steps=20)
     solver = ScaSML_full_history(eq, gp, seed=0)
     g = np.random.default_rng(4321)
@@ -83,7 +99,10 @@ def test_config3_full_history_n4_matches_oracle_on_sampled_roots(config3):
     ora = PicardOracle(oeq, "fh", gp=ogp, seed=0, stream=5)
     want = np.concatenate([ora.uz_solve(N3, M3, x_t[r:r + 1], root0=int(r)) for r in rows])
     got = full[rows].cpu().numpy()
-    assert np.max(np.abs(got - want)) < 1e-4              # outputs are clipped to +-0.1
+    if gp.compat == "reference":
+        _assert_close_to_oracle(gp, got, want)
+    else:
+        assert np.max(np.abs(got - want)) < 1e-4          # outputs are clipped to +-0.1
     from scasml_gp_amd import tables
     assert tables.executed_path_steps(solver._engine.plan(N3, M3)) == ora.sites_executed == 1650
     assert tables.reference_path_steps("fh", N3, M3) == 2523
@@ -107,7 +126,8 @@ def test_config3_full_batch_properties_and_eight_way_sample_split(config3):
 
 
 # ---------------------------------------------------------------------------------------------- configs[4], staged
-def test_config4_d250_two_thousand_collocation_points_scasml_n3_matches_oracle():
+@SURROGATES
+def test_config4_d250_two_thousand_collocation_points_scasml_n3_matches_oracle(compat):
     from oracle.mlp import PicardOracle
     from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
     from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
@@ -116,15 +136,16 @@ def test_config4_d250_two_thousand_collocation_points_scasml_n3_matches_oracle()
     eq = Grad_Dependent_Nonlinear(d + 1)
     np.random.seed(1234)
     dom, bdy = eq.generate_data(1667, 333)
-    gp = GP_Grad_Dependent_Nonlinear(eq, compat=None)
+    gp = GP_Grad_Dependent_Nonlinear(eq, compat=compat)
     gp.GPsolver(dom, bdy, GN_steps=20)
     assert gp.phi_dim == 7001 and gp.loss_history[-1] < gp.loss_history[0] and gp.grad_norms[-1] < 1e-3 * gp.grad_norms[0]
+    assert compat is None or gp._compat_model is not None          # d = 250: 16 K-steps, the widest instantiation of the matrix-core kernel
     oeq, ogp = _oracle_with(gp, d)
     xt = np.concatenate(eq.generate_test_data(1, 1)).astype(np.float32)
     hip = ScaSML(eq, gp, seed=2)
     got = hip.uz_solve(3, 3, xt)
     want = PicardOracle(oeq, "quad", gp=ogp, seed=2, stream=0).uz_solve(3, 3, xt)
-    assert np.all(np.abs(got - want) <= 5e-5 + 2e-4 * np.abs(want)), np.abs(got - want).max()
+    _assert_close_to_oracle(gp, got, want)
 
 
 def test_config4_fit_at_ten_thousand_collocation_points():
