@@ -1,0 +1,92 @@
+"""The reference's own runs of MLP.u_solve, replayed digit for digit (oracle/replay.py on oracle/jax_random.py).
+
+The reference cannot run here (no JAX), ships no golden vectors, and draws its normals from JAX's threefry -- but its logs print what its runs
+computed, to sixteen digits.  With the random stream, the key schedule and the dtype of every operation restated, the replay must print the
+same numbers; one float16 normal drawn or rounded differently among the ~300 000 of a solve moves the last digits."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LOGGED = json.load(open(os.path.join(HERE, "golden", "reference_logged.json")))["quadrature"]
+DIMS = [20, 40, 60, 80]
+
+
+def _line(d, prefix):
+    for l in LOGGED[str(d)]["simple_uniform"]["head"]:
+        if l.startswith(prefix):
+            return l
+    raise KeyError(prefix)
+
+
+def _numbers(line):
+    return [float(v) for v in re.findall(r"(?<=[:>] )-?\d+\.?\d*(?:e[-+]?\d+)?", line)]
+
+
+def test_the_normal_stream_is_counter_based_and_standard():
+    from oracle import jax_random as jr
+    key = jr.split(jr.prng_key(0), 1)[0]
+    a = jr.normal_f16(key, (50, 7, 20))
+    assert a.dtype == np.float16 and bool(np.isfinite(a).all())
+    assert abs(float(a.astype(np.float64).mean())) < 0.02 and abs(float(a.astype(np.float64).std()) - 1.0) < 0.02
+    idx = np.array([0, 19, 20, 6999, 3141])                           # random access = the array draw at those row-major positions
+    assert np.array_equal(jr.normal_f16_at(key, idx), a.reshape(-1)[idx])
+    assert np.array_equal(jr.normal_f16(key, (7000,)), a.reshape(-1))  # the shape does not enter: only the row-major index does
+    # float16 uniform grid: 1024 values, symmetric support (-1, 1) exclusive, so no infinite normals
+    assert float(np.abs(a).max()) < 4.0
+
+
+@pytest.mark.parametrize("d", DIMS)
+def test_simple_uniform_mlp_numbers_all_printed_digits(d):
+    """results/Grad_Dependent_Nonlinear/<d>d/SimpleUniform/SimpleUniform.log: a fresh MLP, n = rho = 2, on the harness's 1000 + 200 test points
+    (np.random.seed(1234): the training draw, then this one; tests/SimpleUniform.py:73-86, 134-136)."""
+    from oracle.equation import GradDependentNonlinear, deepxde_points, logistic_wave_f16
+    from oracle.replay import ReplayMLP
+    state = np.random.get_state()
+    np.random.seed(1234)
+    deepxde_points(d, 1000, 200)
+    xt = np.concatenate(deepxde_points(d, 1000, 200))
+    np.random.set_state(state)
+    exact = logistic_wave_f16(xt).astype(np.float64)
+    solver = ReplayMLP(GradDependentNonlinear(d + 1))
+    sol = solver.u_solve(2, 2, xt).astype(np.float64)
+    assert solver.splits == 15                                         # 3 (l = 0) + 3 x (1 + 3) (l = 1 and its level-1 children)
+    err = np.abs(sol - exact)
+    rel = float(np.linalg.norm(err) / np.linalg.norm(exact))
+    assert rel == _numbers(_line(d, "MLP rel L2"))[-1]                  # e.g. 0.1603708391443781 at d = 20: every digit
+    lo, hi, mean, std = _numbers(_line(d, "MLP L1"))[:4]
+    assert float(err.min()) == lo and float(err.max()) == hi
+    assert abs(float(err.mean()) - mean) <= 1e-15 and abs(float(err.std()) - std) <= 1e-15
+    sq = err ** 2
+    lo2, hi2, mean2, std2 = _numbers(_line(d, "MLP L2"))[:4]
+    assert float(sq.max()) == pytest.approx(hi2, rel=1e-12) and float(sq.mean()) == pytest.approx(mean2, rel=1e-12)
+
+
+@pytest.mark.parametrize("d", DIMS)
+def test_repeated_experiment_mlp_statistics_to_the_printed_digits(d):
+    """results/**/RepeatedExperiment.log: ten test sets (np.random.seed(42 + i)) through ONE solver object, whose key state carries over from
+    call to call (MLP.py:220); relative L2 with the harness's float16 norm of the exact solution (RepeatedExperiment.py:71, 125-127:
+    ``np.linalg.norm`` of a float16 array)."""
+    from oracle.equation import GradDependentNonlinear, deepxde_points, logistic_wave_f16
+    from oracle.replay import ReplayMLP
+    solver = ReplayMLP(GradDependentNonlinear(d + 1))
+    rel, l1, l2 = [], [], []
+    state = np.random.get_state()
+    for i in range(10):
+        np.random.seed(42 + i)
+        xt = np.concatenate(deepxde_points(d, 1000, 200))
+        exact16 = logistic_wave_f16(xt).ravel()
+        err = np.abs(solver.u_solve(2, 2, xt).astype(np.float64).ravel() - exact16)
+        rel.append(np.linalg.norm(err) / np.linalg.norm(exact16))
+        l1.append(err.mean())
+        l2.append((err ** 2).mean())
+    np.random.set_state(state)
+    want = LOGGED[str(d)]["repeated"]
+    for got, key in ((rel, "rel_l2"), (l1, "l1"), (l2, "l2")):
+        got = np.asarray(got, dtype=np.float64)
+        w = want[key]["MLP"]
+        for value, name in ((got.mean(), "mean"), (got.std(ddof=1), "std"), (got.min(), "min"), (got.max(), "max")):
+            assert value == pytest.approx(w[name], rel=2e-6), (key, name, value, w[name])      # seven printed digits
