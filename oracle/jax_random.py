@@ -73,3 +73,14 @@ def normal_f16_at(key, index):
 def normal_f16(key, shape):
     n = int(np.prod(shape))
     return normal_f16_at(key, np.arange(n, dtype=np.uint64)).reshape(shape)
+
+
+def uniform_f16_at(key, index):
+    """``random.uniform(key, shape, float16)`` (minval 0, maxval 1) at the row-major positions ``index``: one of the 1024 values k / 1024."""
+    one_two = ((bits16(key, index) >> np.uint16(6)) | np.uint16(0x3C00)).view(F16)
+    return np.maximum(F16(0.0), (one_two - F16(1.0)).astype(F16))
+
+
+def uniform_f16(key, shape):
+    n = int(np.prod(shape))
+    return uniform_f16_at(key, np.arange(n, dtype=np.uint64)).reshape(shape)

@@ -75,7 +75,7 @@ def reference_counts(variant, n, par, tab=None, scasml=False):
 
 # --------------------------------------------------------------------------- solver
 class PicardOracle:
-    def __init__(self, eq, variant="quad", gp=None, seed=0, stream=0, T=None, compat_crn=False, compat_f16=False):
+    def __init__(self, eq, variant="quad", gp=None, seed=0, stream=0, T=None, compat_crn=False, compat_f16=False, jax_stream=False):
         """compat_crn=True emulates the reference's fixed-key reuse:
         every ``uz_solve`` call draws its terminal normals from ``PRNGKey(0)`` again
         (MLP.py:167-168,178), so calls of equal shape -- the q quadrature nodes of one sample
@@ -84,6 +84,14 @@ class PicardOracle:
         against the relative-L2 errors logged under results*/ (tests/test_oracle_reference_band.py);
         the product path and the default oracle use independent draws."""
         self.compat_crn = bool(compat_crn)
+        # jax_stream=True (quadrature variant): the normals are the REFERENCE's -- jax.random.normal(float16) under its key schedule
+        # (oracle/jax_random.py; the terminal draws of every call from split(PRNGKey(0), 1)[0], the path draws from the solver's stateful
+        # key, which persists across calls) -- addressed by counter, so this path-by-path walk reads the same numbers the reference's
+        # batch-vectorised recursion does.  With compat_f16 the result differs from the reference's own (oracle/replay.py, which also
+        # follows its float16 ARITHMETIC at the root call) by float16 roundings only: tests/test_reference_replay.py.
+        self.jax_stream = bool(jax_stream)
+        self.jax_splits = 0                          # path sub-keys consumed so far (the state of MLP.key, solvers/MLP.py:25, 220)
+        self._jax_keys = None
         # compat_f16: the reference's solver-level float16 casts -- Equation.g / Equation.f return float16 (equations.py:261, 304),
         # ScaSML.g / ScaSML.f subtract float16 from float16 (ScaSML.py:45-47, 62), every uz_solve returns .astype(float16)
         # (MLP.py:274, ScaSML.py:284, MLP_full_history.py:180; ScaSML_full_history.py:199 does not)
@@ -112,7 +120,38 @@ class PicardOracle:
         self._shard = (rank, world)
         self._owner = None if owner is None else np.asarray(owner)
         self.sites_executed = 0
-        return self._uz(n, x_t[:, :-1].copy(), x_t[:, -1].copy(), roots, 0, top=True, cbase=0)
+        jx = None
+        if self.jax_stream:
+            if self.variant != "quad" or world != 1:
+                raise NotImplementedError("jax_stream: quadrature variant, unsharded")
+            jx = (self.jax_splits, np.arange(B, dtype=np.uint64))
+            self.jax_splits += self._jax_splits_in_call(n)
+        return self._uz(n, x_t[:, :-1].copy(), x_t[:, -1].copy(), roots, 0, top=True, cbase=0, jx=jx)
+
+    # the reference's random stream ----------------------------------------------------------------
+    def _jax_splits_in_call(self, n):
+        """Sub-keys one uz_solve(n) call draws from the stateful key, its children's included (MLP.py:213-220, 231, 253)."""
+        if n <= 0:
+            return 0
+        _, _, Q, _, _ = self.tab
+        return sum(int(Q[self.par - 1, n - l - 1]) * (1 + self._jax_splits_in_call(l) + (self._jax_splits_in_call(l - 1) if l else 0))
+                   for l in range(n))
+
+    def _jax_subkey(self, i):
+        from . import jax_random as jr
+        if self._jax_keys is None:
+            self._jax_state, self._jax_keys = jr.prng_key(0), []
+            self._jax_terminal = jr.split(jr.prng_key(0), 1)[0]
+        while len(self._jax_keys) <= i:
+            self._jax_state, sub = jr.split(self._jax_state, 2)
+            self._jax_keys.append(sub)
+        return self._jax_keys[i]
+
+    def _jax_normals(self, key, rows, width, m):
+        """Sample m of a (batch, width, d) float16 draw under ``key``, for the batch rows ``rows``."""
+        from . import jax_random as jr
+        idx = ((rows * np.uint64(width) + np.uint64(m))[:, None] * np.uint64(self.d) + np.arange(self.d, dtype=np.uint64)[None, :])
+        return jr.normal_f16_at(key, idx).astype(np.float64)
 
     def finalize(self, summed_partials):
         """Clip the all-reduced partial sums of a sample-sharded solve (world > 1)."""
@@ -166,7 +205,7 @@ class PicardOracle:
         out = np.clip(out, -c, c)
         return out if (self.variant == "fh" and self.gp is not None) else self._h(out)
 
-    def _uz(self, n, x, t, roots, base, top=False, cbase=None):
+    def _uz(self, n, x, t, roots, base, top=False, cbase=None, jx=None):
         """base: first RNG site of this call's subtree.  cbase: where the call's TERMINAL draws
         come from -- equal to base except under compat_crn, where it is the base the call
         would have at quadrature node k=0 of every ancestor path."""
@@ -174,10 +213,10 @@ class PicardOracle:
             return np.zeros((x.shape[0], 1 + self.d))
         if cbase is None or not self.compat_crn:
             cbase = base
-        return self._uz_quad(n, x, t, roots, base, top, cbase) if self.variant == "quad" \
+        return self._uz_quad(n, x, t, roots, base, top, cbase, jx) if self.variant == "quad" \
             else self._uz_fh(n, x, t, roots, base, top, cbase)
 
-    def _terminal(self, mg, x, t, roots, base, top, eps):
+    def _terminal(self, mg, x, t, roots, base, top, eps, jx=None):
         T, d = self.T, self.d
         tau = T - t
         su = np.zeros(x.shape[0])
@@ -185,7 +224,11 @@ class PicardOracle:
         for m in range(mg):                          # MLP.py:175-202
             if not self._owned(top, m):
                 continue
-            N = philox.normals(self.seed, self.stream, roots, base + m, d).astype(np.float64)
+            if jx is not None:
+                self._jax_subkey(0)
+                N = self._jax_normals(self._jax_terminal, jx[1], mg, m)
+            else:
+                N = philox.normals(self.seed, self.stream, roots, base + m, d).astype(np.float64)
             XT = x + self.mu * tau[:, None] + self.sigma * np.sqrt(tau)[:, None] * N
             G = self._g(XT, np.full_like(t, T))
             su += G
@@ -194,12 +237,13 @@ class PicardOracle:
         with np.errstate(all="ignore"):
             return su / mg, sz / (mg * (tau + eps))[:, None]
 
-    def _uz_quad(self, n, x, t, roots, base, top, cbase):
+    def _uz_quad(self, n, x, t, roots, base, top, cbase, jx=None):
         Mf, Mg, Q, c, w = self.tab
         rho, T = self.par, self.T
         tau = T - t
         mg = int(Mg[rho - 1, n])
-        u, z = self._terminal(mg, x, t, roots, cbase, top, 1e-6)
+        u, z = self._terminal(mg, x, t, roots, cbase, top, 1e-6, jx)
+        jsplit = jx[0] if jx is not None else 0      # sub-key index of node (l, k = 0) of this call
         o = mg
         unit = mg
         # delta_t carried across (l, k) exactly as the reference's loop nest does (MLP.py:201,249,270)
@@ -222,6 +266,9 @@ class PicardOracle:
                     if l:
                         stale = own                  # MLP.py:270
                 dminus.append(own)
+            if jx is not None and l:
+                lp = l - 1                           # nodes of the previous level: q_prev x (1 + children's sub-keys)
+                jsplit += int(Q[rho - 1, n - lp - 1]) * (1 + self._jax_splits_in_call(lp) + (self._jax_splits_in_call(lp - 1) if lp else 0))
             for m in range(mc):
                 owned = self._owned(top, unit)
                 unit += 1
@@ -232,7 +279,15 @@ class PicardOracle:
                 W = np.zeros_like(x)
                 o_k0 = o                             # offsets of this path's k=0 children (compat_crn)
                 for k in range(q):
-                    xi = philox.normals(self.seed, self.stream, roots, base + o, self.d).astype(np.float64)
+                    if jx is not None:
+                        per_node = 1 + self._jax_splits_in_call(l) + (self._jax_splits_in_call(l - 1) if l else 0)
+                        sk = jsplit + k * per_node
+                        xi = self._jax_normals(self._jax_subkey(sk), jx[1], mc, m)
+                        kid = (sk + 1, jx[1] * np.uint64(mc) + np.uint64(m))
+                        kid2 = (sk + 1 + self._jax_splits_in_call(l), kid[1])
+                    else:
+                        kid = kid2 = None
+                        xi = philox.normals(self.seed, self.stream, roots, base + o, self.d).astype(np.float64)
                     o += 1
                     self.sites_executed += 1
                     with np.errstate(invalid="ignore"):
@@ -240,13 +295,13 @@ class PicardOracle:
                     W = W + dW
                     X = X + self.mu * dts[:, k][:, None] + self.sigma * dW   # MLP.py:225
                     tk = cloc[:, k]
-                    sim = self._uz(l, X, tk, roots, base + o, cbase=cbase + o_k0 + 1)
+                    sim = self._uz(l, X, tk, roots, base + o, cbase=cbase + o_k0 + 1, jx=kid)
                     o += s_l
                     y = self._f(X, tk, sim[:, 0], sim[:, 1:])
                     u = u + wloc[:, k] * y / mc                              # MLP.py:248
                     z = z + (wloc[:, k] * y)[:, None] * W / (mc * dplus[k])[:, None]   # MLP.py:249
                     if l:
-                        sim = self._uz(l - 1, X, tk, roots, base + o, cbase=cbase + o_k0 + 1 + s_l)
+                        sim = self._uz(l - 1, X, tk, roots, base + o, cbase=cbase + o_k0 + 1 + s_l, jx=kid2)
                         o += s_lm
                         y = self._f(X, tk, sim[:, 0], sim[:, 1:])
                         u = u - wloc[:, k] * y / mc                          # MLP.py:269

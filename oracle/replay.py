@@ -128,3 +128,57 @@ class ReplayMLP:
 
     def u_solve(self, n, rho, x_t):                                                   # :276-288
         return self.uz_solve(n, rho, np.asarray(x_t))[:, 0:1]
+
+
+class ReplayMLPFullHistory:
+    """``solvers.MLP_full_history.MLP_full_history`` (solvers/MLP_full_history.py:64-196).  Every draw of every call -- the terminal normals,
+    the uniform times and the path normals of every level -- comes from the ONE key ``split(PRNGKey(0), 1)[0]`` (:92-93, 99, 133, 138): the time
+    ``tau`` and the normals of a sample are functions of overlapping threefry outputs, and calls of equal shape repeat each other's numbers.
+    With a float16 root batch nothing ever promotes (there are no float64 tables here): the whole recursion is float16 arithmetic."""
+
+    def __init__(self, eq):
+        self.eq, self.d, self.T = eq, eq.d, eq.T
+        self.sigma, self.mu = F16(eq.sigma()), F16(eq.mu())
+        self.key = jr.split(jr.prng_key(0), 1)[0]
+
+    @staticmethod
+    def _f(sigma, child):
+        return ((sigma * child[:, 0:1]).astype(F16) * _sum16(child[:, 1:], 1)).astype(F16)
+
+    def uz_solve(self, n, M, x_t):
+        assert x_t.dtype == F16
+        T, d, B = F16(self.T), self.d, x_t.shape[0]
+        x, t = x_t[:, :-1], x_t[:, -1]
+        tau = (T - t).astype(F16)
+        mg = M ** n
+        N = jr.normal_f16(self.key, (B, mg, d))                                                        # :99
+        dW = (np.sqrt(tau).astype(F16)[:, None, None] * N).astype(F16)
+        XT = ((x[:, None, :] + (self.mu * tau).astype(F16)[:, None, None]).astype(F16) + (self.sigma * dW).astype(F16)).astype(F16)   # :103
+        G = logistic_wave_f16(np.concatenate([XT, np.full((B, mg, 1), T, dtype=F16)], axis=2).reshape(-1, d + 1)).reshape(B, mg, 1)
+        u = _mean16(G, 1)                                                                              # :120
+        with np.errstate(over="ignore", divide="ignore", invalid="ignore"):
+            z = (_mean16((G * N).astype(F16), 1) / tau[:, None]).astype(F16)                           # :122-123
+        if n == 0:
+            return np.zeros((B, 1 + d), dtype=F16)                                                     # :126-128
+        for l in range(n):
+            mc = M ** (n - l)
+            step = (jr.uniform_f16(self.key, (B, mc)) * tau[:, None]).astype(F16)[:, :, None]          # :133-135
+            xi = jr.normal_f16(self.key, (B, mc, d))                                                   # :138
+            dW = (np.sqrt(step).astype(F16) * xi).astype(F16)                                          # :139
+            X = (x[:, None, :] + ((self.mu * step).astype(F16) + (self.sigma * dW).astype(F16)).astype(F16)).astype(F16)   # :141
+            node = np.concatenate([X, (t[:, None, None] + step).astype(F16)], axis=2).reshape(-1, d + 1)   # :145
+            root = np.sqrt((step + F16(1e-6)).astype(F16)).astype(F16)                                 # :158
+            for sign, level in ((1, l), (-1, l - 1)):
+                if level < 0 or (sign < 0 and not l):
+                    continue
+                y = self._f(self.sigma, self.uz_solve(level, M, node)).reshape(B, mc, 1)               # :147-155 / :166-173
+                with np.errstate(over="ignore", divide="ignore", invalid="ignore"):
+                    du = (tau[:, None] * _mean16(y, 1)).astype(F16)                                    # :157 / :175
+                    dz = (tau[:, None] * _mean16(((y * xi).astype(F16) / root).astype(F16), 1)).astype(F16)   # :159 / :177
+                    u = (u + du).astype(F16) if sign > 0 else (u - du).astype(F16)
+                    z = (z + dz).astype(F16) if sign > 0 else (z - dz).astype(F16)
+        bound = F16(self.eq.norm_estimation)
+        return np.clip(np.concatenate([u, z], axis=1), -bound, bound).astype(F16)                      # :178-180
+
+    def u_solve(self, n, M, x_t):
+        return self.uz_solve(n, M, np.asarray(x_t))[:, 0:1]
