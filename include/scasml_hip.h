@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SCASML_ABI_VERSION 3
+#define SCASML_ABI_VERSION 4
 #define SCASML_MAX_LEVEL 5   /* Picard level n <= 5 (kernels are instantiated per level)      */
 #define SCASML_MAX_Q 6       /* quadrature nodes per rule <= 6 (rho <= 5, solvers/MLP.py:132)  */
 #define SCASML_MAX_DIM 252   /* spatial dimension d <= 252 (one 4-dim quad per lane, +t, +3 spare columns) */
@@ -62,6 +62,9 @@ typedef struct {
     uint32_t reserved;
     const uint8_t *unit_owner;  /* DEVICE bytes, one per unit of the root call (terminal samples, then the sample paths of
                                    level 0, 1, ...): the rank that owns it, from scasml_plan_deal_units.  NULL: unit % world. */
+    const uint32_t *jax_keys;   /* SCASML_RNG_JAX_STREAM: DEVICE words [k0 k1] x (1 + S): the key every call's terminal draws use,
+                                   split(PRNGKey(0), 1)[0] (solvers/MLP.py:167-168), then the S sub-keys this solve takes from the solver's
+                                   stateful key (MLP.py:220) in the reference's call order.  NULL otherwise. */
 } scasml_rng;
 
 /* scasml_rng.flags.  COMPAT_CRN reproduces the reference's key reuse as pure counter
@@ -74,8 +77,12 @@ typedef struct {
  * float16 (equations/equations.py:261, 304), ScaSML.g / ScaSML.f subtract float16 from float16 (solvers/ScaSML.py:45-47, 62), and every
  * uz_solve returns clip(...).astype(float16) (solvers/MLP.py:274, ScaSML.py:284, MLP_full_history.py:180; ScaSML_full_history.py:199
  * does not cast), so a child's (u, z) is a float16 value before the parent's f sees it.  Sample-sharded partial sums (world > 1) are
- * left unrounded: the cast follows the clip, which follows the all-reduce. */
-enum { SCASML_RNG_COMPAT_CRN = 1, SCASML_RNG_COMPAT_F16 = 2 };
+ * left unrounded: the cast follows the clip, which follows the all-reduce.
+ * JAX_STREAM (quadrature solvers, n <= 3, no sample sharding) replaces the Philox stream by the REFERENCE's own normals --
+ * jax.random.normal(key, shape, float16) under jax_threefry_partitionable, each element addressed by the row-major index it has in the
+ * reference's batch-vectorised draw (one Threefry-2x32 per normal) -- under the keys in scasml_rng.jax_keys; seed / stream are ignored.
+ * With it a solve on the reference's test set lands on the numbers its runs logged (tests/test_gpu_jax_stream.py). */
+enum { SCASML_RNG_COMPAT_CRN = 1, SCASML_RNG_COMPAT_F16 = 2, SCASML_RNG_JAX_STREAM = 4 };
 
 /* One (level n', sub-level l) term of the Picard sum: MLP.py:210-271 / MLP_full_history.py:131-177. */
 typedef struct {
@@ -146,6 +153,9 @@ int scasml_clip(float *uz, int64_t count, float clip, void *stream);
 
 /* Raw RNG access for parity tests: normals of `site` for roots root0..root0+B-1 -> B x d. */
 int scasml_debug_normals(scasml_rng rng, uint32_t site, int32_t d, int64_t B, float *out, void *stream);
+/* Elements index0 .. index0 + count - 1 of jax.random.normal((key0, key1), shape, float16) under jax_threefry_partitionable, as float32
+ * values (SCASML_RNG_JAX_STREAM; the NumPy statement is oracle/jax_random.py: bit-identical, tests/test_gpu_jax_stream.py). */
+int scasml_debug_jax_normals(uint32_t key0, uint32_t key1, uint64_t index0, int64_t count, float *out, void *stream);
 /* The normal transform on its whole input domain, for exhaustive parity tests: a normal is a function of the top 24 bits of
  * its Philox word;  out[i] = N(word = (k0 + i) << 8)  for i < n, k0 + n <= 2^24 (device pointer). */
 int scasml_debug_transform(uint32_t k0, int64_t n, float *out, void *stream);

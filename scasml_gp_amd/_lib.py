@@ -8,11 +8,12 @@ MAX_Q = 6
 MAX_DIM = 252
 GP_TILE = 32
 DIST_BLOCK = 256
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 MODE_MLP, MODE_GENERATE, MODE_ACCUMULATE = 0, 1, 2
 RNG_COMPAT_CRN = 1
 RNG_COMPAT_F16 = 2
+RNG_JAX_STREAM = 4
 EQ_GRAD_DEPENDENT_NONLINEAR = 0
 EQ_CUBIC_REACTION_DIFFUSION = 1
 
@@ -25,7 +26,7 @@ class Problem(C.Structure):
 class Rng(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("stream", C.c_uint32), ("root0", C.c_uint32),
                 ("rank", C.c_int32), ("world", C.c_int32), ("flags", C.c_uint32), ("reserved", C.c_uint32),
-                ("unit_owner", C.c_void_p)]
+                ("unit_owner", C.c_void_p), ("jax_keys", C.c_void_p)]
 
 
 class Term(C.Structure):
@@ -63,6 +64,7 @@ SIGNATURES = {
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "scasml_clip": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
     "scasml_debug_normals": (C.c_int, [Rng, C.c_uint32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
+    "scasml_debug_jax_normals": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p]),
     "scasml_debug_transform": (C.c_int, [C.c_uint32, C.c_int64, C.c_void_p, C.c_void_p]),
     "scasml_normal_table_rows": (C.c_int32, []),
     "scasml_normal_table": (C.c_int, [C.c_void_p, C.c_int32]),

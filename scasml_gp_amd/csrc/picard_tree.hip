@@ -39,6 +39,7 @@ struct TreeArgs {
     const uint8_t *owner;   // unit -> rank (scasml_plan_deal_units), or null: unit % world
     int32_t crn;  // SCASML_RNG_COMPAT_CRN: terminal draws keyed by the call's k = 0 position (reference key reuse, E-2/E-3)
     int32_t f16;  // SCASML_RNG_COMPAT_F16: the reference's solver-level float16 casts (g, f and every uz_solve return; E-5)
+    const uint32_t *jk;   // SCASML_RNG_JAX_STREAM: key words [terminal k0 k1 | path sub-key 0 k0 k1 | sub-key 1 ...] (scasml_rng.jax_keys)
     int32_t d, G, logG, kp;
     float T, mu, sigma, clip;
 };
@@ -72,7 +73,66 @@ constexpr float kReadbackMinVol = 1e-2f;
 #endif
 constexpr int kAhead = SCASML_ACC_AHEAD;
 
-template <int VAR, int MODE, int EQ>
+// ---- SCASML_RNG_JAX_STREAM: the reference's own normals, jax.random.normal(key, shape, float16) under jax_threefry_partitionable,
+// addressed by counter (oracle/jax_random.py is the NumPy statement; tests/test_gpu_jax_stream.py compares the two bit for bit):
+// element with row-major index i of a draw under key (k0, k1) = low 16 bits of y0 ^ y1, (y0, y1) = Threefry-2x32-20(key, (i >> 32, i));
+// bits >> 6 | 0x3C00 is a float16 in [1, 2); minus 1, times 2, plus nextafter(-1, 0), clamped below (each a float16 operation);
+// sqrt(2) * erf_inv in float32 (XLA's ErfInv32) rounded to float16 before the float16 product.  One Threefry per normal: this is the
+// parity mode, ~7x the integer work of the Philox stream.
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+__device__ __forceinline__ uint32_t threefry_bits16(uint32_t k0, uint32_t k1, uint64_t index) {
+    const uint32_t ks[3] = {k0, k1, k0 ^ k1 ^ 0x1BD11BDAu};
+    uint32_t x0 = (uint32_t)(index >> 32) + ks[0], x1 = (uint32_t)index + ks[1];
+    const int rot[2][4] = {{13, 15, 26, 6}, {17, 29, 16, 24}};
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            x0 += x1;
+            x1 = rotl32(x1, rot[i & 1][j]) ^ x0;
+        }
+        x0 += ks[(i + 1) % 3];
+        x1 += ks[(i + 2) % 3] + (uint32_t)(i + 1);
+    }
+    return (x0 ^ x1) & 0xFFFFu;
+}
+__device__ __forceinline__ float jax_normal_f16(uint32_t k0, uint32_t k1, uint64_t index) {
+    const unsigned short hb = (unsigned short)((threefry_bits16(k0, k1, index) >> 6) | 0x3C00u);
+    const _Float16 lo = (_Float16)-0.99951171875f;                      // nextafter(float16(-1), 0)
+    _Float16 u = __builtin_bit_cast(_Float16, hb) - (_Float16)1.0f;
+    u = u * (_Float16)2.0f + lo;                                        // (1 - lo) rounds to 2 in float16; both operations are exact or rounded once
+    u = u < lo ? lo : u;
+    const float x = (float)u;
+    float w = -log1pf(-x * x);
+    float p;
+    if (w < 5.0f) {
+        w -= 2.5f;
+        p = 2.81022636e-08f;
+        p = fmaf(p, w, 3.43273939e-07f);
+        p = fmaf(p, w, -3.5233877e-06f);
+        p = fmaf(p, w, -4.39150654e-06f);
+        p = fmaf(p, w, 0.00021858087f);
+        p = fmaf(p, w, -0.00125372503f);
+        p = fmaf(p, w, -0.00417768164f);
+        p = fmaf(p, w, 0.246640727f);
+        p = fmaf(p, w, 1.50140941f);
+    } else {
+        w = sqrtf(w) - 3.0f;
+        p = -0.000200214257f;
+        p = fmaf(p, w, 0.000100950558f);
+        p = fmaf(p, w, 0.00134934322f);
+        p = fmaf(p, w, -0.00367342844f);
+        p = fmaf(p, w, 0.00573950773f);
+        p = fmaf(p, w, -0.0076224613f);
+        p = fmaf(p, w, 0.00943887047f);
+        p = fmaf(p, w, 1.00167406f);
+        p = fmaf(p, w, 2.83297682f);
+    }
+    const _Float16 e = (_Float16)(p * x);
+    return (float)((_Float16)1.4140625f * e);                           // float16(sqrt(2)) * float16(erf_inv): a float16 product
+}
+
+template <int VAR, int MODE, int EQ, bool JAX = false>
 struct Walker {
     const TreeArgs &a;
     float4 mask;       // 1 on this lane's live spatial dims, 0 on padding
@@ -94,6 +154,35 @@ struct Walker {
     }
     __device__ __forceinline__ float4 normals(uint32_t site) const {
         return mul4(normal4(gl, site, root, a.stream, a.k0, a.k1), mask);
+    }
+    // sample m of a (batch, width, d) draw under key (k0, k1), for this root's row of the reference's flattened batch
+    __device__ __forceinline__ float4 normals_jax(uint32_t kslot, uint64_t row, uint32_t width, uint32_t m) const {
+        const uint32_t k0 = a.jk[2 * kslot], k1 = a.jk[2 * kslot + 1];
+        const uint64_t first = (row * width + m) * (uint64_t)a.d + 4u * gl;
+        float4 v;
+        v.x = mask.x != 0.0f ? jax_normal_f16(k0, k1, first + 0) : 0.0f;
+        v.y = mask.y != 0.0f ? jax_normal_f16(k0, k1, first + 1) : 0.0f;
+        v.z = mask.z != 0.0f ? jax_normal_f16(k0, k1, first + 2) : 0.0f;
+        v.w = mask.w != 0.0f ? jax_normal_f16(k0, k1, first + 3) : 0.0f;
+        return v;
+    }
+    // path sub-keys one uz_solve call at level N consumes, its children's included (MLP.py:213-220, 231, 253)
+    template <int N>
+    __device__ __forceinline__ uint32_t nsplits() const {
+        if constexpr (N <= 0) {
+            return 0u;
+        } else {
+            return nsplits_from<N, 0>();
+        }
+    }
+    template <int N, int L>
+    __device__ __forceinline__ uint32_t nsplits_from() const {
+        if constexpr (L >= N) {
+            return 0u;
+        } else {
+            const uint32_t per = 1u + nsplits<L>() + nsplits<L - 1>();
+            return (uint32_t)a.plan.term[N][L].q * per + nsplits_from<N, L + 1>();
+        }
     }
     // Row addressing: row = site * B + local, so a site's rows start at a wave-uniform base (scalar 64-bit arithmetic) and
     // the lane contributes a fixed 32-bit element offset -- a 64-bit VGPR product per access costs three v_mad_u64_u32.
@@ -140,8 +229,10 @@ struct Walker {
     }
 
     // ---- one (n', l) term of the Picard sum ------------------------------------------------
+    // jrow: this root's row in the reference's flattened batch of THIS call; jfirst: sub-key index of node (L, k = 0) of this call
     template <int N, int L, bool TOP>
-    __device__ __forceinline__ void level(float4 x, float t, float tau, uint32_t base, uint32_t cbase, uint32_t &o, float &u, float4 &z) {
+    __device__ __forceinline__ void level(float4 x, float t, float tau, uint32_t base, uint32_t cbase, uint32_t &o, float &u, float4 &z,
+                                          uint64_t jrow = 0, uint32_t jfirst = 0) {
         const scasml_term &tm = a.plan.term[N][L];
         const int q = tm.q, mc = tm.mc;
         const uint32_t s_l = (uint32_t)tm.sites_l, s_lm = (uint32_t)tm.sites_lm1;
@@ -174,7 +265,9 @@ struct Walker {
                     dplus = rcp_fast(fmaf(tau, tm.dplus[k], 1e-6f));
                     dminus = rcp_fast(fmaf(tau, tm.cfrac[k], 1e-6f));
                 } else if constexpr (VAR == 0) {                 // MLP.py:219-225
-                    const float4 xi = normals(site);
+                    float4 xi;
+                    if constexpr (JAX) xi = normals_jax(1u + jfirst + (uint32_t)k * (1u + nsplits<L>() + nsplits<L - 1>()), jrow, (uint32_t)mc, (uint32_t)m);
+                    else xi = normals(site);
                     const float dk = tau * tm.dfrac[k];
                     const float sdk = sqrt_fast(dk);
                     W = fma4(sdk, xi, W);
@@ -203,7 +296,9 @@ struct Walker {
 
                 float uc;
                 float4 zc;
-                uz<L, false>(X, tk, base + o, (a.crn && VAR == 0) ? c_plus : base + o, uc, zc);
+                const uint32_t jkid = jfirst + (uint32_t)k * (1u + nsplits<L>() + nsplits<L - 1>()) + 1u;   // the children's first sub-key
+                const uint64_t jkrow = jrow * (uint32_t)mc + (uint32_t)m;
+                uz<L, false>(X, tk, base + o, (a.crn && VAR == 0) ? c_plus : base + o, uc, zc, jkrow, jkid);
                 o += s_l;
                 if constexpr (MODE != SCASML_MODE_GENERATE) {
                     const float y = f_eval(uc, zc, gp) * (wk * inv_mc);
@@ -211,7 +306,7 @@ struct Walker {
                     z = fma4(y * dplus, wvec, z);                // MLP.py:249
                 }
                 if constexpr (L > 0) {
-                    uz<L - 1, false>(X, tk, base + o, (a.crn && VAR == 0) ? c_minus : base + o, uc, zc);
+                    uz<L - 1, false>(X, tk, base + o, (a.crn && VAR == 0) ? c_minus : base + o, uc, zc, jkrow, jkid + nsplits<L>());
                     o += s_lm;
                     if constexpr (MODE != SCASML_MODE_GENERATE) {
                         const float y = f_eval(uc, zc, gp) * (wk * inv_mc);
@@ -225,12 +320,13 @@ struct Walker {
                 }
             }
         }
-        if constexpr (L + 1 < N) level<N, L + 1, TOP>(x, t, tau, base, cbase, o, u, z);
+        if constexpr (L + 1 < N) level<N, L + 1, TOP>(x, t, tau, base, cbase, o, u, z, jrow, jfirst + (uint32_t)q * (1u + nsplits<L>() + nsplits<L - 1>()));
     }
 
     // ---- uz_solve at compile-time level N -----------------------------------------------------
     template <int N, bool TOP>
-    __device__ __forceinline__ void uz(float4 x, float t, uint32_t base, uint32_t cbase, float &u_out, float4 &z_out) {
+    __device__ __forceinline__ void uz(float4 x, float t, uint32_t base, uint32_t cbase, float &u_out, float4 &z_out, uint64_t jrow = 0,
+                                       uint32_t jsplit = 0) {
         if constexpr (N == 0) {                                  // MLP.py:205-207
             u_out = 0.0f;
             z_out = f4(0.0f);
@@ -283,12 +379,14 @@ struct Walker {
                         const float rv = rcp_fast(vol);
                         nrm = mul4(fma4(rv, add4(XT, -drift), f4_scale(x, -rv)), mask);
                     } else {
-                        nrm = normals(cbase + (uint32_t)m);
+                        if constexpr (JAX) nrm = normals_jax(0u, jrow, (uint32_t)mg, (uint32_t)m);
+                        else nrm = normals(cbase + (uint32_t)m);
                         XT = fma4(vol, nrm, add4(x, drift));
                     }
                 } else {
                     if (!owned(TOP)) continue;
-                    nrm = normals(cbase + (uint32_t)m);
+                    if constexpr (JAX) nrm = normals_jax(0u, jrow, (uint32_t)mg, (uint32_t)m);   // every call: split(PRNGKey(0), 1)[0] (MLP.py:167-168, 178)
+                    else nrm = normals(cbase + (uint32_t)m);
                     XT = fma4(vol, nrm, add4(x, drift));
                 }
                 if constexpr (MODE == SCASML_MODE_GENERATE) {
@@ -307,7 +405,7 @@ struct Walker {
             float4 z = make_float4(mask.x != 0.0f ? sz.x * zs : 0.0f, mask.y != 0.0f ? sz.y * zs : 0.0f,
                                    mask.z != 0.0f ? sz.z * zs : 0.0f, mask.w != 0.0f ? sz.w * zs : 0.0f);
             uint32_t o = (uint32_t)mg;
-            level<N, 0, TOP>(x, t, tau, base, cbase, o, u, z);
+            level<N, 0, TOP>(x, t, tau, base, cbase, o, u, z, jrow, jsplit);
             if (!(TOP && a.world > 1)) {                         // MLP.py:272-274
                 u = clip1(u, a.clip);
                 z = make_float4(clip1(z.x, a.clip), clip1(z.y, a.clip), clip1(z.z, a.clip), clip1(z.w, a.clip));
@@ -325,7 +423,7 @@ struct Walker {
 
 // (An occupancy hint for ACCUMULATE was measured, profiles/r02_accumulate_prefetch.txt: 5 waves/SIMD 1.22 ms against 1.26, but the
 // deeper levels then spill inside their loops; 6 and 8 are slower.  No hint.)
-template <int VAR, int MODE, int N, int EQ>
+template <int VAR, int MODE, int N, int EQ, bool JAX = false>
 __global__ __launch_bounds__(256) void picard_tree_kernel(const TreeArgs a) {
     normal_table_to_lds();   // every thread, before any return below
     const int lane = threadIdx.x & 63;
@@ -348,7 +446,7 @@ __global__ __launch_bounds__(256) void picard_tree_kernel(const TreeArgs a) {
     const bool valid = local < a.B;
     if (!valid) local = a.B - 1;  // idle lanes shadow the last root; their stores are masked
 
-    Walker<VAR, MODE, EQ> w{a};
+    Walker<VAR, MODE, EQ, JAX> w{a};
     w.gl = gl;
     w.root = a.root0 + (uint32_t)local;
     w.local = local;
@@ -374,7 +472,7 @@ __global__ __launch_bounds__(256) void picard_tree_kernel(const TreeArgs a) {
     }
     float u;
     float4 z;
-    w.template uz<N, true>(x, t, 0u, 0u, u, z);
+    w.template uz<N, true>(x, t, 0u, 0u, u, z, (uint64_t)a.root0 + (uint64_t)local, 0u);
     if constexpr (MODE != SCASML_MODE_GENERATE) {
         if (valid) {
             float *out = a.out_uz + local * (a.d + 1);
@@ -394,6 +492,19 @@ __global__ __launch_bounds__(256) void picard_tree_kernel(const TreeArgs a) {
 
 template <int VAR, int MODE, int EQ>
 static int launch_level(const TreeArgs &a, int n, dim3 grid, hipStream_t s) {
+    if (a.jk) {   // the reference's own random stream: quadrature solvers, levels 1..3 (the logged runs are n = rho = 2)
+        if constexpr (VAR == 0) {
+            switch (n) {
+                case 1: hipLaunchKernelGGL((picard_tree_kernel<0, MODE, 1, EQ, true>), grid, dim3(256), 0, s, a); break;
+                case 2: hipLaunchKernelGGL((picard_tree_kernel<0, MODE, 2, EQ, true>), grid, dim3(256), 0, s, a); break;
+                case 3: hipLaunchKernelGGL((picard_tree_kernel<0, MODE, 3, EQ, true>), grid, dim3(256), 0, s, a); break;
+                default: return fail(SCASML_ERR_UNSUPPORTED, "picard_tree: SCASML_RNG_JAX_STREAM at level n=%d (1..3)", n);
+            }
+            return check_launch("picard_tree launch");
+        } else {
+            return fail(SCASML_ERR_UNSUPPORTED, "picard_tree: SCASML_RNG_JAX_STREAM is for the quadrature solvers");
+        }
+    }
     switch (n) {
         case 1: hipLaunchKernelGGL((picard_tree_kernel<VAR, MODE, 1, EQ>), grid, dim3(256), 0, s, a); break;
         case 2: hipLaunchKernelGGL((picard_tree_kernel<VAR, MODE, 2, EQ>), grid, dim3(256), 0, s, a); break;
@@ -433,6 +544,11 @@ __global__ void debug_normals_kernel(uint32_t k0, uint32_t k1, uint32_t stream, 
     const float v[4] = {n.x, n.y, n.z, n.w};
     for (int j = 0; j < 4; ++j)
         if (4 * q + j < d) out[b * d + 4 * q + j] = v[j];
+}
+
+__global__ void debug_jax_normals_kernel(uint32_t k0, uint32_t k1, uint64_t index0, int64_t count, float *out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = jax_normal_f16(k0, k1, index0 + (uint64_t)i);
 }
 
 }  // namespace scasml
@@ -490,6 +606,9 @@ extern "C" int scasml_picard_tree(const scasml_problem *prob, const scasml_plan 
     a.owner = rng.world > 1 ? rng.unit_owner : nullptr;
     a.crn = (rng.flags & SCASML_RNG_COMPAT_CRN) ? 1 : 0;
     a.f16 = (rng.flags & SCASML_RNG_COMPAT_F16) ? 1 : 0;
+    a.jk = (rng.flags & SCASML_RNG_JAX_STREAM) ? rng.jax_keys : nullptr;
+    if ((rng.flags & SCASML_RNG_JAX_STREAM) && !rng.jax_keys) return fail(SCASML_ERR_ARG, "picard_tree: SCASML_RNG_JAX_STREAM needs scasml_rng.jax_keys");
+    if (a.jk && rng.world != 1) return fail(SCASML_ERR_UNSUPPORTED, "picard_tree: SCASML_RNG_JAX_STREAM with sample sharding");
     a.d = prob->d;
     a.kp = scasml_point_stride(prob->d);
     a.G = ceil_pow2(a.kp / 4);
@@ -507,6 +626,13 @@ extern "C" int scasml_picard_tree(const scasml_problem *prob, const scasml_plan 
     int rc = SCASML_ERR_UNSUPPORTED;
     SCASML_EQ_SWITCH(prob->eq_id, rc = (plan->variant == 0 ? launch_mode<0, EQ>(a, mode, plan->n, grid, s) : launch_mode<1, EQ>(a, mode, plan->n, grid, s)));
     return rc;
+}
+
+extern "C" int scasml_debug_jax_normals(uint32_t key0, uint32_t key1, uint64_t index0, int64_t count, float *out, void *stream) {
+    if (!out || count < 0) return fail(SCASML_ERR_ARG, "debug_jax_normals: bad argument");
+    if (count == 0) return 0;
+    hipLaunchKernelGGL(debug_jax_normals_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, key0, key1, index0, count, out);
+    return check_launch("debug_jax_normals launch");
 }
 
 extern "C" int scasml_clip(float *uz, int64_t count, float clip, void *stream) {

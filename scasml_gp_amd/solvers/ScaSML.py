@@ -7,7 +7,7 @@ class ScaSML:
     '''Multilevel Picard Iteration calibrated GP for high dimensional semilinear PDE'''
     _variant = "quad"
 
-    def __init__(self, equation, GP, seed=0, compat_crn=False, compat_f16=False):
+    def __init__(self, equation, GP, seed=0, compat_crn=False, compat_f16=False, compat_rng=None):
         self.equation = equation
         self.sigma = equation.sigma
         self.mu = equation.mu
@@ -19,7 +19,7 @@ class ScaSML:
         self.GP = GP
         self.evaluation_counter = 0
         self.key = seed
-        self._engine = PicardEngine(equation, self._variant, gp=GP, seed=seed, compat_crn=compat_crn, compat_f16=compat_f16)
+        self._engine = PicardEngine(equation, self._variant, gp=GP, seed=seed, compat_crn=compat_crn, compat_f16=compat_f16, compat_rng=compat_rng)
 
     def __setattr__(self, name, value):
         object.__setattr__(self, name, value)

@@ -19,7 +19,7 @@ def _as_device(x_t, torch):
 
 
 class PicardEngine:
-    def __init__(self, equation, variant, gp=None, seed=0, compat_crn=False, compat_f16=False):
+    def __init__(self, equation, variant, gp=None, seed=0, compat_crn=False, compat_f16=False, compat_rng=None):
         if getattr(equation, "eq_id", None) is None:
             raise NotImplementedError("no HIP kernels for equation %s (eq_id unset)" % type(equation).__name__)
         self.equation = equation
@@ -30,6 +30,16 @@ class PicardEngine:
         self.compat_crn = bool(compat_crn)
         # the reference's solver-level float16 casts (g, f, every uz_solve return): SCASML_RNG_COMPAT_F16 in include/scasml_hip.h
         self.compat_f16 = bool(compat_f16)
+        # compat_rng="jax": the reference's own normals -- jax.random.normal(float16) under its key schedule (SCASML_RNG_JAX_STREAM in
+        # include/scasml_hip.h; quadrature solvers, n <= 3).  The state below is the solver's ``self.key`` of solvers/MLP.py:25, 220: it
+        # starts at PRNGKey(0) and every uz_solve advances it by the sub-keys that call consumes.
+        if compat_rng not in (None, "jax"):
+            raise ValueError("compat_rng must be None or 'jax'")
+        if compat_rng == "jax" and variant != "quad":
+            raise NotImplementedError("compat_rng='jax' is available for the quadrature solvers (MLP, ScaSML)")
+        self.compat_rng = compat_rng
+        self.jax_key = (0, 0)
+        self.jax_splits = 0
         self.calls = 0                 # Philox stream id: advances once per uz_solve (E-9)
         self.profile = False           # bench.py: bracket every launch with HIP events on the launch stream
         self._events = []
@@ -134,7 +144,14 @@ class PicardEngine:
                                    % (float(self.gp.T), float(self.equation.T)))
         flags = (_lib.RNG_COMPAT_CRN if self.compat_crn else 0) | (_lib.RNG_COMPAT_F16 if self.compat_f16 else 0)
         owner = self.unit_owners(n, par, world)[1].data_ptr() if world > 1 and n > 0 else None
-        rng = _lib.Rng(self.seed, self.calls if stream_id is None else stream_id, root0, rank, world, flags, 0, owner)
+        jax_keys = None
+        if self.compat_rng == "jax" and n > 0:
+            if world != 1:
+                raise NotImplementedError("compat_rng='jax' with Monte-Carlo sample sharding")
+            keys = self._jax_keys(plan)
+            jax_keys = keys.data_ptr()
+            flags |= _lib.RNG_JAX_STREAM
+        rng = _lib.Rng(self.seed, self.calls if stream_id is None else stream_id, root0, rank, world, flags, 0, owner, jax_keys)
         if stream_id is None:
             self.calls += 1
         out = torch.empty((B, d + 1), dtype=torch.float32, device="cuda")
@@ -157,7 +174,7 @@ class PicardEngine:
         x_bound = self.path_bound(float(x.abs().max()) if B else None, plan)
         for b0 in range(0, B, chunk):
             nb = min(chunk, B - b0)
-            rng_c = _lib.Rng(rng.seed, rng.stream, root0 + b0, rank, world, flags, 0, owner)
+            rng_c = _lib.Rng(rng.seed, rng.stream, root0 + b0, rank, world, flags, 0, owner, jax_keys)
             xc = x[b0:b0 + nb]
             if n > 0:
                 ob, ub = out[b0:b0 + nb], uhat[b0:b0 + nb]
@@ -173,13 +190,35 @@ class PicardEngine:
                 uhat[b0:b0 + nb] = self.gp._predict_device(xc)[:, 0]
         return out, uhat, was_numpy
 
+    def _jax_keys(self, plan):
+        """Device words [terminal key | the sub-keys this solve draws from the solver's stateful key]; advances that key."""
+        from .. import threefry
+        torch = _lib.require_gpu()
+
+        def splits(level):                                        # sub-keys one uz_solve(level) consumes, children included
+            if level <= 0:
+                return 0
+            return sum(int(plan.term[level][l].q) * (1 + splits(l) + splits(l - 1)) for l in range(level))
+        count = splits(plan.n)
+        words = [threefry.split((0, 0), 1, "partitionable")[0]]   # MLP.py:167-168: rebuilt from PRNGKey(0) in every call
+        key = self.jax_key
+        for _ in range(count):                                    # MLP.py:220: self.key, subkey = random.split(self.key)
+            pair = threefry.split(key, 2, "partitionable")
+            key = (int(pair[0][0]), int(pair[0][1]))
+            words.append(pair[1])
+        self.jax_key = key
+        self.jax_splits += count
+        self._work["jax_keys"] = torch.from_numpy(np.asarray(words, dtype=np.uint64).astype(np.uint32).view(np.int32).reshape(-1).copy()).cuda()
+        return self._work["jax_keys"]
+
     def _buffers(self, rows, kp):
         """The site-major point buffer and its GP values: owned by the engine and reused by later calls of the same
         shape, so a step allocates nothing (the caching allocator hid this after the first call; a first call did not)."""
         torch = _lib.require_gpu()
         have = self._work.get("pts")
         if have is None or have.shape[0] < rows or have.shape[1] != kp:
-            self._work.clear()
+            self._work.pop("pts", None)
+            self._work.pop("vals", None)
             self._work["pts"] = torch.zeros((rows, kp), dtype=torch.float32, device="cuda")    # zeroed once: rows nobody writes stay finite
             self._work["vals"] = torch.zeros((rows, 4), dtype=torch.float32, device="cuda")
         return self._work["pts"][:rows], self._work["vals"][:rows]

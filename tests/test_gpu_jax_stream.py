@@ -1,0 +1,107 @@
+"""SCASML_RNG_JAX_STREAM / ``compat_rng="jax"``: the HIP path on the REFERENCE's own random stream.
+
+With the normals the reference's runs drew (jax.random.normal(float16) under its key schedule, addressed by counter on the device) the product
+is no longer compared with the reference through a statistic: a solve on the reference's test set must land on the numbers its logs print
+-- up to the float16 arithmetic of the reference's root call and its float64 children, which the device (float32) does not imitate."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+LOGGED = json.load(open(os.path.join(HERE, "golden", "reference_logged.json")))["quadrature"]
+
+
+def _logged(d, prefix):
+    line = [l for l in LOGGED[str(d)]["simple_uniform"]["head"] if l.startswith(prefix)][0]
+    return float(re.findall(r"-> (-?\d+\.\d+(?:e[-+]?\d+)?)", line)[0])
+
+
+def _reference_test_set(d):
+    from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
+    eq = Grad_Dependent_Nonlinear(d + 1)
+    eq.geometry()
+    state = np.random.get_state()
+    np.random.seed(1234)
+    dom, bdy = eq.generate_data(1000, 200)
+    xt = np.concatenate(eq.generate_test_data(1000, 200))
+    np.random.set_state(state)
+    return eq, dom, bdy, xt
+
+
+def test_device_normals_are_jax_random_normal_float16_bit_for_bit():
+    import torch
+    from oracle import jax_random as jr
+    from scasml_gp_amd import _lib
+    lib = _lib.load()
+    for key, index0, count in (((0, 0), 0, 70000), (tuple(int(v) for v in jr.split(jr.prng_key(0), 1)[0]), 123456789, 4096),
+                               ((0xDEADBEEF, 0x12345678), (1 << 32) - 100, 300)):       # the last range crosses a 32-bit counter word
+        out = torch.empty((count,), dtype=torch.float32, device="cuda")
+        _lib.check(lib.scasml_debug_jax_normals(key[0], key[1], index0, count, _lib.ptr(out), _lib.stream_ptr()), "debug_jax_normals")
+        want = jr.normal_f16_at(np.asarray(key, dtype=np.uint64), np.arange(index0, index0 + count, dtype=np.uint64)).astype(np.float32)
+        got = out.cpu().numpy()
+        assert np.array_equal(got, want), (key, int((got != want).sum()))
+
+
+@pytest.mark.parametrize("d", [20, 80])
+def test_mlp_on_the_reference_stream_lands_on_the_logged_numbers(d):
+    """solvers.MLP on the reference's 1000 + 200 test points, n = rho = 2: against the replay (oracle/replay.py, which prints the log's sixteen
+    digits) point by point, and against the logged relative L2 itself (SimpleUniform.log:5)."""
+    from oracle.equation import GradDependentNonlinear
+    from oracle.mlp import PicardOracle
+    from oracle.replay import ReplayMLP
+    from scasml_gp_amd.solvers.MLP import MLP
+    eq, _, _, xt = _reference_test_set(d)
+    exact = np.asarray(eq.exact_solution(xt)).astype(np.float64)
+    solver = MLP(eq, compat_rng="jax", compat_f16=True)
+    got = solver.uz_solve(2, 2, xt).astype(np.float64)
+    replay = ReplayMLP(GradDependentNonlinear(d + 1))
+    want = replay.uz_solve(2, 2, xt).astype(np.float64)
+    du = np.abs(got[:, 0] - want[:, 0])
+    # the device computes the root call in float32 where the reference rounds every operation to float16 (more of them as d grows)
+    assert du.max() <= 4 * 2.0 ** -11 and (du <= 2.0 ** -11).mean() > 0.8, (du.max(), (du <= 2.0 ** -11).mean())
+    rel = float(np.linalg.norm(got[:, 0:1] - exact) / np.linalg.norm(exact))
+    assert abs(rel - _logged(d, "MLP rel L2")) <= 5e-4 * rel, (rel, _logged(d, "MLP rel L2"))
+    # the same normals through the float64 oracle (path by path): the usual HIP <-> oracle agreement, float16 casts at the same places
+    ora = PicardOracle(GradDependentNonlinear(d + 1), "quad", jax_stream=True, compat_f16=True).uz_solve(2, 2, xt.astype(np.float32))
+    diff = np.abs(got - ora)
+    assert (diff[:, 0] > 1e-4).mean() < 0.02 and diff[:, 0].max() <= 2 * 2.0 ** -11, ((diff[:, 0] > 1e-4).mean(), diff[:, 0].max())
+    # the solver's key state carries over to the next call, as the harness's solver object's does (RepeatedExperiment.py)
+    assert solver._engine.jax_splits == replay.splits == 15
+    again = solver.uz_solve(2, 2, xt[:64]).astype(np.float64)
+    want2 = replay.uz_solve(2, 2, xt[:64]).astype(np.float64)
+    assert solver._engine.jax_splits == 30 and np.abs(again[:, 0] - want2[:, 0]).max() <= 4 * 2.0 ** -11
+    assert not np.array_equal(again[:, 0], got[:64, 0])                      # other sub-keys: other normals
+
+
+def test_scasml_on_the_reference_stream_lands_on_the_logged_numbers_at_d20():
+    """solvers.ScaSML with the default surrogate (as coded by the reference, its training set and Hutchinson indices) and the reference's
+    normals: ScaSML rel L2 of 20d/SimpleUniform/SimpleUniform.log to 0.6 % (one standard deviation over test sets: 3.5 %)."""
+    from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
+    from scasml_gp_amd.solvers.ScaSML import ScaSML
+    d = 20
+    eq, dom, bdy, xt = _reference_test_set(d)
+    gp = GP_Grad_Dependent_Nonlinear(eq)
+    gp.GPsolver(dom, bdy, GN_steps=20)
+    exact = np.asarray(eq.exact_solution(xt)).astype(np.float64)
+    sol = ScaSML(eq, gp, compat_rng="jax", compat_f16=True).u_solve(2, 2, xt).astype(np.float64)
+    rel = float(np.linalg.norm(sol - exact) / np.linalg.norm(exact))
+    want = _logged(d, "ScaSML rel L2")
+    assert abs(rel - want) <= 6e-3 * want, (rel, want)
+
+
+def test_refusals():
+    from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
+    from scasml_gp_amd.solvers.MLP import MLP
+    from scasml_gp_amd.solvers.MLP_full_history import MLP_full_history
+    eq = Grad_Dependent_Nonlinear(11)
+    with pytest.raises(NotImplementedError):
+        MLP_full_history(eq, compat_rng="jax")
+    with pytest.raises(ValueError):
+        MLP(eq, compat_rng="threefry")
+    x = np.zeros((4, 11), dtype=np.float32)
+    with pytest.raises(Exception):
+        MLP(eq, compat_rng="jax").uz_solve(4, 4, x)                          # levels above 3 have no instantiation on this stream

@@ -49,7 +49,7 @@ def metrics(sols, exact):
     return out
 
 
-def run_case(d, train_seed, idx, reps, compat):
+def run_case(d, train_seed, idx, reps, compat, rng=None):
     import torch
     from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
     from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
@@ -66,7 +66,8 @@ def run_case(d, train_seed, idx, reps, compat):
     torch.cuda.synchronize()
     t_fit = time.time() - t0
     kw = {"compat_crn": compat, "compat_f16": compat}        # the reference's key reuse and its solver-level float16 casts
-    solvers = {"MLP": MLP(eq, **kw), "ScaSML": ScaSML(eq, gp, **kw),
+    kq = dict(kw, compat_rng=rng)                             # --rng jax: the quadrature solvers on the reference's own normals and key schedule
+    solvers = {"MLP": MLP(eq, **kq), "ScaSML": ScaSML(eq, gp, **kq),
                "MLP_fh": MLP_full_history(eq, **kw), "ScaSML_fh": ScaSML_full_history(eq, gp, **kw)}
     acc = {k: [] for k in NAMES}
     sec = {k: [] for k in NAMES}
@@ -94,12 +95,13 @@ def run_case(d, train_seed, idx, reps, compat):
             acc[k].append(mq[k])
         for k in ("MLP_fh", "ScaSML_fh"):
             acc[k].append(mf[k])
-    row = {"d": d, "train_seed": train_seed, "compat": "reference" if compat else None, "idx": None if idx is None else [int(i) for i in idx],
+    row = {"d": d, "train_seed": train_seed, "compat": "reference" if compat else None, "rng": rng or "philox", "idx": None if idx is None else [int(i) for i in idx],
            "gp_fit_s": round(t_fit, 2), "valid_points_min": [int(min(v[0] for v in valid)), int(min(v[1] for v in valid))]}
     for name in NAMES:
         a = np.asarray(acc[name])
         row[name] = {"l1": round(float(a[:, 0].mean()), 5), "l2": round(float(a[:, 1].mean()), 6),
-                     "rel_l2": round(float(a[:, 2].mean()), 4), "std": round(float(a[:, 2].std(ddof=1) if len(a) > 1 else 0.0), 4),
+                     "rel_l2": round(float(a[:, 2].mean()), 5), "std": round(float(a[:, 2].std(ddof=1) if len(a) > 1 else 0.0), 5),
+                     "min": round(float(a[:, 2].min()), 5), "max": round(float(a[:, 2].max()), 5),
                      "ms": round(1e3 * float(np.mean(sec[name][1:] or sec[name])), 2)}
     return row
 
@@ -108,7 +110,7 @@ def run_case(d, train_seed, idx, reps, compat):
 LOGGED_SIMPLE = {20: (0.1466, 0.1604, 0.0701), 40: (0.1810, 0.2059, 0.0932), 60: (0.2401, 0.2521, 0.1356), 80: (0.2660, 0.2709, 0.1609)}
 
 
-def run_simple_uniform(d, idx, seed=1234):
+def run_simple_uniform(d, idx, seed=1234, rng=None):
     """tests/SimpleUniform.py:46-136: ONE generator stream -- np.random.seed(1234) (experiment_run.py:32), the training set, then
     the test set without reseeding."""
     from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
@@ -122,15 +124,15 @@ def run_simple_uniform(d, idx, seed=1234):
     gp.GPsolver(dom, bdy)                                   # SimpleUniform.py:81 (GN_steps default 20)
     xt = np.concatenate(eq.generate_test_data(1000, 200), axis=0)
     exact = eq.exact_solution(xt)
-    sols = {"GP": gp.predict(xt), "MLP": MLP(eq, compat_crn=True, compat_f16=True).u_solve(2, 2, xt),
-            "ScaSML": ScaSML(eq, gp, compat_crn=True, compat_f16=True).u_solve(2, 2, xt)}
+    sols = {"GP": gp.predict(xt), "MLP": MLP(eq, compat_crn=True, compat_f16=True, compat_rng=rng).u_solve(2, 2, xt),
+            "ScaSML": ScaSML(eq, gp, compat_crn=True, compat_f16=True, compat_rng=rng).u_solve(2, 2, xt)}
     m = metrics(sols, exact)
     e = np.asarray(exact, np.float64).ravel()
     diff = np.asarray(sols["GP"], np.float64).ravel() - e
     pde = np.asarray(gp.compute_PDE_loss(xt), np.float64)                       # SimpleUniform.py:139-141, 412-414
     stats = lambda v: {"min": float(v.min()), "max": float(v.max()), "mean": float(v.mean()), "std": float(v.std())}
-    return {"protocol": "SimpleUniform", "d": d, "seed": seed, "idx": [int(i) for i in idx],
-            "rel_l2": {k: round(m[k][2], 5) for k in sols}, "logged": dict(zip(("GP", "MLP", "ScaSML"), LOGGED_SIMPLE.get(d, (None,) * 3))),
+    return {"protocol": "SimpleUniform", "d": d, "seed": seed, "rng": rng or "philox", "idx": [int(i) for i in idx],
+            "rel_l2": {k: round(m[k][2], 6) for k in sols}, "logged": dict(zip(("GP", "MLP", "ScaSML"), LOGGED_SIMPLE.get(d, (None,) * 3))),
             "real_solution": float(np.linalg.norm(e) / np.sqrt(e.size)), "pde_loss": stats(pde), "gp_l1": stats(np.abs(diff)), "gp_l2": stats(diff ** 2)}
 
 
@@ -144,6 +146,8 @@ def main():
     ap.add_argument("--idx-mode", choices=["random", "original", "partitionable"], default="random",
                     help="Hutchinson index set: random sets, or the reference's own draw choice(PRNGKey(0), d, (5,)) under either "
                          "Threefry counter layout (scasml_gp_amd/threefry.py)")
+    ap.add_argument("--rng", choices=["philox", "jax"], default="philox",
+                    help="jax: MLP and ScaSML draw the reference's own normals (jax.random.normal float16 under its key schedule, SCASML_RNG_JAX_STREAM)")
     ap.add_argument("--simple-uniform", action="store_true", help="also run tests/SimpleUniform.py's single-stream protocol (seed 1234)")
     args = ap.parse_args()
 
@@ -151,19 +155,19 @@ def main():
         from scasml_gp_amd.threefry import reference_laplacian_idx
         for d in args.dims:
             idx = reference_laplacian_idx(d, args.idx_mode) if args.idx_mode != "random" else np.random.default_rng(1000).choice(d, 5, replace=False)
-            print(json.dumps(run_simple_uniform(d, idx)), flush=True)
+            print(json.dumps(run_simple_uniform(d, idx, rng=None if args.rng == "philox" else args.rng)), flush=True)
     summary = []
     for d in args.dims:
         rows = []
         for ts in args.train_seeds:
             if args.compat and args.idx_mode != "random":
                 from scasml_gp_amd.threefry import reference_laplacian_idx
-                rows.append(run_case(d, ts, reference_laplacian_idx(d, args.idx_mode), args.reps, True))
+                rows.append(run_case(d, ts, reference_laplacian_idx(d, args.idx_mode), args.reps, True, rng=None if args.rng == "philox" else args.rng))
                 print(json.dumps(rows[-1]), flush=True)
             elif args.compat:
                 rng = np.random.default_rng(1000 + ts)
                 for _ in range(args.idx_sets):
-                    rows.append(run_case(d, ts, rng.choice(d, 5, replace=False), args.reps, True))
+                    rows.append(run_case(d, ts, rng.choice(d, 5, replace=False), args.reps, True, rng=None if args.rng == "philox" else args.rng))
                     print(json.dumps(rows[-1]), flush=True)
             else:
                 rows.append(run_case(d, ts, None, args.reps, False))
