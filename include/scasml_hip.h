@@ -64,7 +64,8 @@ typedef struct {
                                    level 0, 1, ...): the rank that owns it, from scasml_plan_deal_units.  NULL: unit % world. */
     const uint32_t *jax_keys;   /* SCASML_RNG_JAX_STREAM: DEVICE words [k0 k1] x (1 + S): the key every call's terminal draws use,
                                    split(PRNGKey(0), 1)[0] (solvers/MLP.py:167-168), then the S sub-keys this solve takes from the solver's
-                                   stateful key (MLP.py:220) in the reference's call order.  NULL otherwise. */
+                                   stateful key (MLP.py:220) in the reference's call order (quadrature solvers; the full-history solvers
+                                   draw everything from the first key: S = 0).  NULL otherwise. */
 } scasml_rng;
 
 /* scasml_rng.flags.  COMPAT_CRN reproduces the reference's key reuse as pure counter
@@ -78,7 +79,7 @@ typedef struct {
  * uz_solve returns clip(...).astype(float16) (solvers/MLP.py:274, ScaSML.py:284, MLP_full_history.py:180; ScaSML_full_history.py:199
  * does not cast), so a child's (u, z) is a float16 value before the parent's f sees it.  Sample-sharded partial sums (world > 1) are
  * left unrounded: the cast follows the clip, which follows the all-reduce.
- * JAX_STREAM (quadrature solvers, n <= 3, no sample sharding) replaces the Philox stream by the REFERENCE's own normals --
+ * JAX_STREAM (n <= 3, no sample sharding) replaces the Philox stream by the REFERENCE's own normals (and, full history, uniform times) --
  * jax.random.normal(key, shape, float16) under jax_threefry_partitionable, each element addressed by the row-major index it has in the
  * reference's batch-vectorised draw (one Threefry-2x32 per normal) -- under the keys in scasml_rng.jax_keys; seed / stream are ignored.
  * With it a solve on the reference's test set lands on the numbers its runs logged (tests/test_gpu_jax_stream.py). */

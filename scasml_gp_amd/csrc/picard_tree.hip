@@ -131,6 +131,11 @@ __device__ __forceinline__ float jax_normal_f16(uint32_t k0, uint32_t k1, uint64
     const _Float16 e = (_Float16)(p * x);
     return (float)((_Float16)1.4140625f * e);                           // float16(sqrt(2)) * float16(erf_inv): a float16 product
 }
+// jax.random.uniform(key, shape, float16): one of the 1024 values k / 1024 (0 included)
+__device__ __forceinline__ float jax_uniform_f16(uint32_t k0, uint32_t k1, uint64_t index) {
+    const unsigned short hb = (unsigned short)((threefry_bits16(k0, k1, index) >> 6) | 0x3C00u);
+    return (float)(__builtin_bit_cast(_Float16, hb) - (_Float16)1.0f);
+}
 
 template <int VAR, int MODE, int EQ, bool JAX = false>
 struct Walker {
@@ -278,12 +283,18 @@ struct Walker {
                     dplus = rcp_fast(fmaf(tau, tm.dplus[k], 1e-6f));   // MLP.py:249 (stale) / ScaSML.py:253
                     dminus = rcp_fast(fmaf(tau, tm.cfrac[k], 1e-6f));  // MLP.py:270
                 } else {                                         // MLP_full_history.py:133-145
-                    const float D = uniform_tau(site, root, a.stream, a.k0, a.k1) * tau;
+                    // JAX stream: the time and the normals of sample m of this call, and its terminal draws, all come from the ONE key
+                    // split(PRNGKey(0), 1)[0] (MLP_full_history.py:92-93, 99, 133, 138), each at its own row-major index
+                    float D;
+                    if constexpr (JAX) D = jax_uniform_f16(a.jk[0], a.jk[1], jrow * (uint32_t)mc + (uint32_t)m) * tau;
+                    else D = uniform_tau(site, root, a.stream, a.k0, a.k1) * tau;
                     const float sD = sqrt_fast(D);
                     // compat_crn: the level-0 draws ARE the terminal draws (MLP_full_history.py:92-93,99,138: one subkey).
                     // (ACCUMULATE replays these normals: reading the stored X back instead, as the terminal samples do, was
                     // measured slower -- 5.9 against 5.4 ms at n = 4, M = 3 -- the pass is bound by its reads, not its RNG.)
-                    const float4 xi = normals(a.crn && L == 0 ? base + (uint32_t)m : site);
+                    float4 xi;
+                    if constexpr (JAX) xi = normals_jax(0u, jrow, (uint32_t)mc, (uint32_t)m);
+                    else xi = normals(a.crn && L == 0 ? base + (uint32_t)m : site);
                     X = fma4(a.sigma * sD, xi, add4(x, a.mu * D));
                     tk = t + D;
                     wk = tau;
@@ -492,18 +503,14 @@ __global__ __launch_bounds__(256) void picard_tree_kernel(const TreeArgs a) {
 
 template <int VAR, int MODE, int EQ>
 static int launch_level(const TreeArgs &a, int n, dim3 grid, hipStream_t s) {
-    if (a.jk) {   // the reference's own random stream: quadrature solvers, levels 1..3 (the logged runs are n = rho = 2)
-        if constexpr (VAR == 0) {
-            switch (n) {
-                case 1: hipLaunchKernelGGL((picard_tree_kernel<0, MODE, 1, EQ, true>), grid, dim3(256), 0, s, a); break;
-                case 2: hipLaunchKernelGGL((picard_tree_kernel<0, MODE, 2, EQ, true>), grid, dim3(256), 0, s, a); break;
-                case 3: hipLaunchKernelGGL((picard_tree_kernel<0, MODE, 3, EQ, true>), grid, dim3(256), 0, s, a); break;
-                default: return fail(SCASML_ERR_UNSUPPORTED, "picard_tree: SCASML_RNG_JAX_STREAM at level n=%d (1..3)", n);
-            }
-            return check_launch("picard_tree launch");
-        } else {
-            return fail(SCASML_ERR_UNSUPPORTED, "picard_tree: SCASML_RNG_JAX_STREAM is for the quadrature solvers");
+    if (a.jk) {   // the reference's own random stream: levels 1..3 (the logged runs are n = 2)
+        switch (n) {
+            case 1: hipLaunchKernelGGL((picard_tree_kernel<VAR, MODE, 1, EQ, true>), grid, dim3(256), 0, s, a); break;
+            case 2: hipLaunchKernelGGL((picard_tree_kernel<VAR, MODE, 2, EQ, true>), grid, dim3(256), 0, s, a); break;
+            case 3: hipLaunchKernelGGL((picard_tree_kernel<VAR, MODE, 3, EQ, true>), grid, dim3(256), 0, s, a); break;
+            default: return fail(SCASML_ERR_UNSUPPORTED, "picard_tree: SCASML_RNG_JAX_STREAM at level n=%d (1..3)", n);
         }
+        return check_launch("picard_tree launch");
     }
     switch (n) {
         case 1: hipLaunchKernelGGL((picard_tree_kernel<VAR, MODE, 1, EQ>), grid, dim3(256), 0, s, a); break;

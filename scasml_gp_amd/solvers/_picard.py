@@ -35,8 +35,6 @@ class PicardEngine:
         # starts at PRNGKey(0) and every uz_solve advances it by the sub-keys that call consumes.
         if compat_rng not in (None, "jax"):
             raise ValueError("compat_rng must be None or 'jax'")
-        if compat_rng == "jax" and variant != "quad":
-            raise NotImplementedError("compat_rng='jax' is available for the quadrature solvers (MLP, ScaSML)")
         self.compat_rng = compat_rng
         self.jax_key = (0, 0)
         self.jax_splits = 0
@@ -199,7 +197,7 @@ class PicardEngine:
             if level <= 0:
                 return 0
             return sum(int(plan.term[level][l].q) * (1 + splits(l) + splits(l - 1)) for l in range(level))
-        count = splits(plan.n)
+        count = splits(plan.n) if self.variant == "quad" else 0   # the full-history solvers draw everything from the first key
         words = [threefry.split((0, 0), 1, "partitionable")[0]]   # MLP.py:167-168: rebuilt from PRNGKey(0) in every call
         key = self.jax_key
         for _ in range(count):                                    # MLP.py:220: self.key, subkey = random.split(self.key)

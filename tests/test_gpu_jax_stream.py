@@ -93,13 +93,36 @@ def test_scasml_on_the_reference_stream_lands_on_the_logged_numbers_at_d20():
     assert abs(rel - want) <= 6e-3 * want, (rel, want)
 
 
+FH = json.load(open(os.path.join(HERE, "golden", "reference_logged.json")))["full_history"]
+
+
+@pytest.mark.parametrize("d", [20, 60])
+def test_full_history_mlp_on_the_reference_stream(d):
+    """solvers.MLP_full_history, n = 2, M = 3: every draw from the one key of MLP_full_history.py:92-93.  On independent draws this solver sits at
+    0.150 where the log says 0.190 (d = 20); on the reference's stream the device lands on the log.  The reference's recursion is float16
+    arithmetic throughout (no float64 tables promote it), the device float32: measured 2e-5 relative at d = 20."""
+    from oracle.equation import GradDependentNonlinear
+    from oracle.replay import ReplayMLPFullHistory
+    from scasml_gp_amd.solvers.MLP_full_history import MLP_full_history
+    eq, _, _, xt = _reference_test_set(d)
+    exact = np.asarray(eq.exact_solution(xt)).astype(np.float64)
+    got = MLP_full_history(eq, compat_rng="jax", compat_f16=True).u_solve(2, None, xt, 3).astype(np.float64)
+    want = ReplayMLPFullHistory(GradDependentNonlinear(d + 1)).u_solve(2, 3, xt).astype(np.float64)
+    rel = float(np.linalg.norm(got - exact) / np.linalg.norm(exact))
+    head = FH[str(d)]["simple_uniform"]["head"]
+    logged = float(re.findall(r"-> (-?\d+\.\d+)", [l for l in head if l.startswith("MLP rel L2")][0])[0])
+    philox = MLP_full_history(eq, compat_crn=True, compat_f16=True).u_solve(2, None, xt, 3).astype(np.float64)
+    rel_philox = float(np.linalg.norm(philox - exact) / np.linalg.norm(exact))
+    du = np.abs(got - want)
+    print("full history d=%d: device on the reference stream %.6f, logged %.6f, Philox %.6f; |du| max %.4g, median %.4g" % (d, rel, logged, rel_philox, du.max(), np.median(du)))
+    assert abs(rel - logged) <= 2e-3 * logged and abs(rel_philox - logged) > 0.1 * logged
+    assert np.median(du) <= 2.0 ** -10
+
+
 def test_refusals():
     from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
     from scasml_gp_amd.solvers.MLP import MLP
-    from scasml_gp_amd.solvers.MLP_full_history import MLP_full_history
     eq = Grad_Dependent_Nonlinear(11)
-    with pytest.raises(NotImplementedError):
-        MLP_full_history(eq, compat_rng="jax")
     with pytest.raises(ValueError):
         MLP(eq, compat_rng="threefry")
     x = np.zeros((4, 11), dtype=np.float32)

@@ -66,9 +66,9 @@ def run_case(d, train_seed, idx, reps, compat, rng=None):
     torch.cuda.synchronize()
     t_fit = time.time() - t0
     kw = {"compat_crn": compat, "compat_f16": compat}        # the reference's key reuse and its solver-level float16 casts
-    kq = dict(kw, compat_rng=rng)                             # --rng jax: the quadrature solvers on the reference's own normals and key schedule
+    kq = dict(kw, compat_rng=rng)                             # --rng jax: the solvers on the reference's own normals, uniform times and key schedule
     solvers = {"MLP": MLP(eq, **kq), "ScaSML": ScaSML(eq, gp, **kq),
-               "MLP_fh": MLP_full_history(eq, **kw), "ScaSML_fh": ScaSML_full_history(eq, gp, **kw)}
+               "MLP_fh": MLP_full_history(eq, **kq), "ScaSML_fh": ScaSML_full_history(eq, gp, **kq)}
     acc = {k: [] for k in NAMES}
     sec = {k: [] for k in NAMES}
     valid = []
