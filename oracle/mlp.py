@@ -122,10 +122,11 @@ class PicardOracle:
         self.sites_executed = 0
         jx = None
         if self.jax_stream:
-            if self.variant != "quad" or world != 1:
-                raise NotImplementedError("jax_stream: quadrature variant, unsharded")
+            if world != 1:
+                raise NotImplementedError("jax_stream: unsharded solves only")
             jx = (self.jax_splits, np.arange(B, dtype=np.uint64))
-            self.jax_splits += self._jax_splits_in_call(n)
+            if self.variant == "quad":               # the full-history solvers draw everything from the one terminal key
+                self.jax_splits += self._jax_splits_in_call(n)
         return self._uz(n, x_t[:, :-1].copy(), x_t[:, -1].copy(), roots, 0, top=True, cbase=0, jx=jx)
 
     # the reference's random stream ----------------------------------------------------------------
@@ -214,7 +215,7 @@ class PicardOracle:
         if cbase is None or not self.compat_crn:
             cbase = base
         return self._uz_quad(n, x, t, roots, base, top, cbase, jx) if self.variant == "quad" \
-            else self._uz_fh(n, x, t, roots, base, top, cbase)
+            else self._uz_fh(n, x, t, roots, base, top, cbase, jx)
 
     def _terminal(self, mg, x, t, roots, base, top, eps, jx=None):
         T, d = self.T, self.d
@@ -313,11 +314,11 @@ class PicardOracle:
                         z = z + (wloc[:, k] * eps)[:, None] * W / (mc * dminus[k])[:, None]
         return self._finish(u, z, top)
 
-    def _uz_fh(self, n, x, t, roots, base, top, cbase):
+    def _uz_fh(self, n, x, t, roots, base, top, cbase, jx=None):
         M, T = self.par, self.T
         tau = T - t
         mg = M ** n
-        u, z = self._terminal(mg, x, t, roots, base, top, 0.0)   # MLP_full_history.py:122: no epsilon
+        u, z = self._terminal(mg, x, t, roots, base, top, 0.0, jx)   # MLP_full_history.py:122: no epsilon
         o = mg
         unit = mg
         for l in range(n):
@@ -333,21 +334,28 @@ class PicardOracle:
                 site = base + o
                 o += 1
                 self.sites_executed += 1
-                U = philox.uniform_tau(self.seed, self.stream, roots, site).astype(np.float64)
+                if jx is not None:                                 # one key for the time and the normals (MLP_full_history.py:92-93, 133, 138)
+                    from . import jax_random as jr
+                    U = jr.uniform_f16_at(self._jax_terminal, jx[1] * np.uint64(mc) + np.uint64(m)).astype(np.float64)
+                    xi = self._jax_normals(self._jax_terminal, jx[1], mc, m)
+                    kid = (0, jx[1] * np.uint64(mc) + np.uint64(m))
+                else:
+                    kid = None
+                    U = philox.uniform_tau(self.seed, self.stream, roots, site).astype(np.float64)
+                    nsite = base + m if (self.compat_crn and l == 0) else site   # E-3: l=0 reuses the terminal draws
+                    xi = philox.normals(self.seed, self.stream, roots, nsite, self.d).astype(np.float64)
                 D = U * tau                                        # MLP_full_history.py:135
-                nsite = base + m if (self.compat_crn and l == 0) else site   # E-3: l=0 reuses the terminal draws
-                xi = philox.normals(self.seed, self.stream, roots, nsite, self.d).astype(np.float64)
                 with np.errstate(invalid="ignore"):
                     X = x + self.mu * D[:, None] + self.sigma * np.sqrt(D)[:, None] * xi   # :139-141
                     wgt = xi / np.sqrt(D + 1e-6)[:, None]          # :158-159
                 tk = t + D
-                sim = self._uz(l, X, tk, roots, base + o)
+                sim = self._uz(l, X, tk, roots, base + o, jx=kid)
                 o += s_l
                 y = self._f(X, tk, sim[:, 0], sim[:, 1:])
                 u = u + tau * y / mc                               # :157
                 z = z + (tau * y)[:, None] * wgt / mc
                 if l:
-                    sim = self._uz(l - 1, X, tk, roots, base + o)
+                    sim = self._uz(l - 1, X, tk, roots, base + o, jx=kid)
                     o += s_lm
                     y = self._f(X, tk, sim[:, 0], sim[:, 1:])
                     u = u - tau * y / mc                           # :175

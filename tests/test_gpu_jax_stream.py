@@ -46,7 +46,7 @@ def test_device_normals_are_jax_random_normal_float16_bit_for_bit():
         assert np.array_equal(got, want), (key, int((got != want).sum()))
 
 
-@pytest.mark.parametrize("d", [20, 80])
+@pytest.mark.parametrize("d", [20, 40, 60, 80])
 def test_mlp_on_the_reference_stream_lands_on_the_logged_numbers(d):
     """solvers.MLP on the reference's 1000 + 200 test points, n = rho = 2: against the replay (oracle/replay.py, which prints the log's sixteen
     digits) point by point, and against the logged relative L2 itself (SimpleUniform.log:5)."""
@@ -77,12 +77,12 @@ def test_mlp_on_the_reference_stream_lands_on_the_logged_numbers(d):
     assert not np.array_equal(again[:, 0], got[:64, 0])                      # other sub-keys: other normals
 
 
-def test_scasml_on_the_reference_stream_lands_on_the_logged_numbers_at_d20():
+@pytest.mark.parametrize("d", [20, 40, 60, 80])
+def test_scasml_on_the_reference_stream_lands_on_the_logged_numbers(d):
     """solvers.ScaSML with the default surrogate (as coded by the reference, its training set and Hutchinson indices) and the reference's
-    normals: ScaSML rel L2 of 20d/SimpleUniform/SimpleUniform.log to 0.6 % (one standard deviation over test sets: 3.5 %)."""
+    normals: ScaSML rel L2 of <d>d/SimpleUniform/SimpleUniform.log to 0.6 % (one standard deviation over test sets: 2.5 - 3.5 %)."""
     from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
     from scasml_gp_amd.solvers.ScaSML import ScaSML
-    d = 20
     eq, dom, bdy, xt = _reference_test_set(d)
     gp = GP_Grad_Dependent_Nonlinear(eq)
     gp.GPsolver(dom, bdy, GN_steps=20)
@@ -96,7 +96,7 @@ def test_scasml_on_the_reference_stream_lands_on_the_logged_numbers_at_d20():
 FH = json.load(open(os.path.join(HERE, "golden", "reference_logged.json")))["full_history"]
 
 
-@pytest.mark.parametrize("d", [20, 60])
+@pytest.mark.parametrize("d", [20, 40, 60, 80])
 def test_full_history_mlp_on_the_reference_stream(d):
     """solvers.MLP_full_history, n = 2, M = 3: every draw from the one key of MLP_full_history.py:92-93.  On independent draws this solver sits at
     0.150 where the log says 0.190 (d = 20); on the reference's stream the device lands on the log.  The reference's recursion is float16
@@ -117,6 +117,11 @@ def test_full_history_mlp_on_the_reference_stream(d):
     print("full history d=%d: device on the reference stream %.6f, logged %.6f, Philox %.6f; |du| max %.4g, median %.4g" % (d, rel, logged, rel_philox, du.max(), np.median(du)))
     assert abs(rel - logged) <= 2e-3 * logged and abs(rel_philox - logged) > 0.1 * logged
     assert np.median(du) <= 2.0 ** -10
+    # the same stream through the float64 oracle: the HIP <-> oracle agreement of every other parity test
+    from oracle.mlp import PicardOracle
+    ora = PicardOracle(GradDependentNonlinear(d + 1), "fh", jax_stream=True, compat_f16=True).uz_solve(2, 3, xt.astype(np.float32))[:, 0:1]
+    diff = np.abs(got - ora)
+    assert (diff > 1e-4).mean() < 0.03 and diff.max() <= 4 * 2.0 ** -11, ((diff > 1e-4).mean(), diff.max())
 
 
 def test_refusals():

@@ -169,6 +169,32 @@ def test_the_philox_oracle_fed_the_reference_normals_follows_the_replay():
     assert ora.jax_splits == 30
 
 
+def test_the_philox_oracle_full_history_fed_the_reference_stream_follows_the_replay():
+    """The same for the full-history variant: uniform times and normals of every call from the one key (MLP_full_history.py:92-93, 133, 138).
+    On Philox draws this oracle gives 0.150 at d = 20; on the reference's stream 0.18997 -- the log's 0.1899677 to 2e-5, the rest being the
+    reference's float16 arithmetic, which here runs through the whole recursion and which only the replay follows."""
+    from oracle.equation import GradDependentNonlinear, deepxde_points, logistic_wave_f16
+    from oracle.mlp import PicardOracle
+    from oracle.replay import ReplayMLPFullHistory
+    d = 20
+    eq = GradDependentNonlinear(d + 1)
+    state = np.random.get_state()
+    np.random.seed(1234)
+    deepxde_points(d, 1000, 200)
+    xt = np.concatenate(deepxde_points(d, 1000, 200))
+    np.random.set_state(state)
+    exact = logistic_wave_f16(xt).astype(np.float64)
+    want = ReplayMLPFullHistory(eq).uz_solve(2, 3, xt).astype(np.float64)
+    got = PicardOracle(eq, "fh", jax_stream=True, compat_f16=True).uz_solve(2, 3, xt.astype(np.float32))
+    du = np.abs(got[:, 0] - want[:, 0])
+    assert du.max() <= 3 * 2.0 ** -11 and np.median(du) == 0.0
+    rel = np.linalg.norm(got[:, 0:1] - exact) / np.linalg.norm(exact)
+    rel_replay = np.linalg.norm(want[:, 0:1] - exact) / np.linalg.norm(exact)
+    assert abs(rel - rel_replay) <= 1e-4 * rel_replay
+    philox = PicardOracle(eq, "fh", compat_crn=True, compat_f16=True).uz_solve(2, 3, xt.astype(np.float32))
+    assert np.linalg.norm(philox[:, 0:1] - exact) / np.linalg.norm(exact) < 0.16          # independent draws: a different (better) estimator
+
+
 def test_scasml_oracle_on_the_reference_normals_lands_on_the_logged_numbers_at_d20():
     """ScaSML (solvers/ScaSML.py:149-304) = the same recursion on the defect of the surrogate.  oracle/mlp.py with the as-coded surrogate
     (oracle/gp_compat.py, fitted on the reference's training set with its Hutchinson indices) and the reference's normals gives the
