@@ -123,7 +123,7 @@ def logistic_wave_f16(x_t):
     s = x[:, :-1].astype(f32).sum(axis=1, dtype=f32).astype(f16)
     arg = (x[:, -1].astype(f32) + s.astype(f32)).astype(f16)
     with np.errstate(over="ignore"):                 # exp overflows float16 at t + sum x > 11.09 (inf, as in the reference): 1 - 1/(1 + inf) = 1
-        e = np.exp(arg.astype(f32)).astype(f16)
+        e = np.exp(arg.astype(np.float64)).astype(f32).astype(f16)       # the correctly rounded float32 exponential, then float16: machine-independent
     q = (f32(1) / (f32(1) + e.astype(f32)).astype(f16).astype(f32)).astype(f16)
     return (f32(1) - q.astype(f32)).astype(f16)[:, None]
 

@@ -46,9 +46,11 @@ def erf_inv32(x):
     """XLA's single-precision erf_inv."""
     x = np.asarray(x, dtype=F32)
     with np.errstate(divide="ignore", invalid="ignore"):
-        w = (-np.log1p((-(x * x)).astype(F32))).astype(F32)
+        # log1p and sqrt through float64 and one rounding: the correctly rounded float32 value on every machine (NumPy's float32 SIMD
+        # routines may differ in the last place between CPUs; the logged digits are reproduced either way)
+        w = (-(np.log1p((-(x * x)).astype(F32).astype(np.float64)).astype(F32))).astype(F32)
         central = _horner32(_GILES_CENTRAL, (w - F32(2.5)).astype(F32))
-        tail = _horner32(_GILES_TAIL, (np.sqrt(np.maximum(w, F32(0))).astype(F32) - F32(3.0)).astype(F32))
+        tail = _horner32(_GILES_TAIL, (np.sqrt(np.maximum(w, F32(0)).astype(np.float64)).astype(F32) - F32(3.0)).astype(F32))
     out = (np.where(w < F32(5.0), central, tail) * x).astype(F32)
     return np.where(np.abs(x) == 1, np.copysign(F32(np.inf), x), out)
 
