@@ -133,3 +133,39 @@ def test_refusals():
     x = np.zeros((4, 11), dtype=np.float32)
     with pytest.raises(Exception):
         MLP(eq, compat_rng="jax").uz_solve(4, 4, x)                          # levels above 3 have no instantiation on this stream
+
+
+@pytest.mark.parametrize("d", [20, 80])
+def test_repeated_experiment_on_the_reference_stream(d):
+    """RepeatedExperiment.py:143-207 on the HIP path: ten test sets (np.random.seed(42 + i)) through ONE solver object of each kind, whose key
+    state carries over from call to call; relative L2 with the harness's float16 norm of the exact solution.  Against the means, standard
+    deviations and ranges results/**/RepeatedExperiment.log prints."""
+    from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
+    from scasml_gp_amd.solvers.MLP import MLP
+    from scasml_gp_amd.solvers.MLP_full_history import MLP_full_history
+    from scasml_gp_amd.solvers.ScaSML import ScaSML
+    eq, dom, bdy, _ = _reference_test_set(d)
+    gp = GP_Grad_Dependent_Nonlinear(eq)
+    gp.GPsolver(dom, bdy, GN_steps=20)
+    kw = dict(compat_rng="jax", compat_f16=True)
+    solvers = {"MLP": MLP(eq, **kw), "ScaSML": ScaSML(eq, gp, **kw), "MLP_fh": MLP_full_history(eq, **kw)}
+    rel = {k: [] for k in solvers}
+    state = np.random.get_state()
+    for i in range(10):
+        np.random.seed(42 + i)
+        xt = np.concatenate(eq.generate_test_data(1000, 200))
+        exact16 = np.asarray(eq.exact_solution(xt)).ravel()
+        assert exact16.dtype == np.float16
+        for name, solver in solvers.items():
+            sol = solver.u_solve(2, None, xt, 3) if name == "MLP_fh" else solver.u_solve(2, 2, xt)
+            err = np.abs(np.asarray(sol, dtype=np.float64).ravel() - exact16)
+            rel[name].append(np.linalg.norm(err) / np.linalg.norm(exact16))
+    np.random.set_state(state)
+    want = {"MLP": LOGGED[str(d)]["repeated"]["rel_l2"]["MLP"], "ScaSML": LOGGED[str(d)]["repeated"]["rel_l2"]["ScaSML"],
+            "MLP_fh": FH[str(d)]["repeated"]["rel_l2"]["MLP"]}
+    for name, tol in (("MLP", 3e-4), ("MLP_fh", 5e-4), ("ScaSML", 6e-3)):
+        got, w = np.asarray(rel[name], dtype=np.float64), want[name]
+        assert abs(got.mean() - w["mean"]) <= tol * w["mean"], (name, got.mean(), w)
+        assert abs(got.std(ddof=1) - w["std"]) <= 0.02 * w["std"] + tol * w["mean"], (name, got.std(ddof=1), w)
+        assert abs(got.min() - w["min"]) <= 2 * tol * w["mean"] and abs(got.max() - w["max"]) <= 2 * tol * w["mean"], (name, got.min(), got.max(), w)
+    assert solvers["MLP"]._engine.jax_splits == 150
