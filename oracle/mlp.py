@@ -163,6 +163,7 @@ class PicardOracle:
         u = uz[:, 0:1]
         if self.gp is not None:                      # ScaSML.py:300-304
             u = u + self.gp.predict(np.asarray(x_t, dtype=np.float32).astype(np.float64))
+            u = self._h(u)                           # float16 + float16 on the harness's float16 points
         return u
 
     # pieces -------------------------------------------------------------------

@@ -54,4 +54,10 @@ class ScaSML:
         '''u_hat + u_breve, solvers/ScaSML.py:286-304.'''
         self.Mf, self.Mg, self.Q, self.c, self.w = self.approx_parameters(rho)
         uz, uhat, was_numpy = self._solve(n, rho, x_t)
-        return deliver(uz[:, 0:1] + uhat[:, None], was_numpy)
+        return deliver(self._sum16(uz[:, 0:1] + uhat[:, None]), was_numpy)
+
+    def _sum16(self, total):
+        """compat_f16: u_breve + u_hat is a float16 sum in the reference (:300-304: u_breve float16 by :284 -- in the full-history solver by
+        float16 arithmetic throughout -- and u_hat float16 by models/GP.py:671); held in float32."""
+        import torch
+        return total.to(torch.float16).to(torch.float32) if self._engine.compat_f16 else total

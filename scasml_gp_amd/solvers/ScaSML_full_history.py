@@ -14,4 +14,4 @@ class ScaSML_full_history(ScaSML):
 
     def u_solve(self, n, rho, x_t, M=3):
         uz, uhat, was_numpy = self._solve(n, M, x_t)               # :201-221
-        return deliver(uz[:, 0:1] + uhat[:, None], was_numpy)
+        return deliver(self._sum16(uz[:, 0:1] + uhat[:, None]), was_numpy)

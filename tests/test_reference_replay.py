@@ -217,7 +217,7 @@ def test_scasml_oracle_on_the_reference_normals_lands_on_the_logged_numbers_at_d
     gp.GPsolver(dom.astype(np.float64), bdy.astype(np.float64), GN_steps=20)
     exact = logistic_wave_f16(xt).astype(np.float64)
     sol = PicardOracle(eq, "quad", gp=gp, jax_stream=True, compat_f16=True).u_solve(2, 2, xt.astype(np.float32))
-    err = np.abs(sol.astype(np.float16).astype(np.float64) - exact)                  # ScaSML.u_solve returns float16 + float16 (ScaSML.py:300-304)
+    err = np.abs(sol - exact)                                                         # u_solve: float16 + float16 (ScaSML.py:300-304), compat_f16 rounds it
     rel = float(np.linalg.norm(err) / np.linalg.norm(exact))
     want = _numbers(_line(d, "ScaSML rel L2"))[-1]                                    # 0.07009992384811603
     assert abs(rel - want) <= 5e-3 * want, (rel, want)
