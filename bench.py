@@ -58,6 +58,7 @@ def parse():
                     help="samples leg: use the largest number of sample ranks (a divisor of the rank count) whose dealt load "
                          "max/mean stays below this; the remaining factor shards roots")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-logs-check", action="store_true", help="skip the d = 20 runs on the reference's own random stream (about a second)")
     ap.add_argument("--no-gp-train-large", action="store_true",
                     help="skip the M = 34 999 leg of the gp_train block (d = 250, 8333 + 1667 collocation points, ~30 GB, ~15 s)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -206,6 +207,48 @@ def sample_split(eng, n, par, world, max_imbalance):
             imb[s] = float(load.max() / load.mean())
     best = max(s for s, v in imb.items() if v <= max_imbalance or s == 1)
     return best, world // best, imb[best], imb[world]
+
+
+def reference_logs_check():
+    """The reference's own experiment at d = 20 (results/Grad_Dependent_Nonlinear/20d/SimpleUniform/SimpleUniform.log: its training set,
+    its 1000 + 200 test points, n = rho = 2) on the HIP path with the reference's own random stream (compat_rng="jax": jax.random's
+    float16 normals under its key schedule, drawn on the device) against the relative L2 errors that log prints.  Untimed; about a second."""
+    import re
+    path = os.path.join(ROOT, "tests", "golden", "reference_logged.json")
+    if not os.path.exists(path):
+        return None
+    from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
+    from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
+    from scasml_gp_amd.solvers.MLP import MLP
+    from scasml_gp_amd.solvers.MLP_full_history import MLP_full_history
+    from scasml_gp_amd.solvers.ScaSML import ScaSML
+    logged = json.load(open(path))
+    d = 20
+
+    def printed(kind, name):
+        line = [l for l in logged[kind][str(d)]["simple_uniform"]["head"] if l.startswith(name + " rel L2")][0]
+        return float(re.findall(r"-> (-?\d+\.\d+)", line)[0])
+    eq = Grad_Dependent_Nonlinear(d + 1)
+    eq.geometry()
+    state = np.random.get_state()
+    np.random.seed(1234)                                     # experiment_run.py:32
+    dom, bdy = eq.generate_data(1000, 200)
+    xt = np.concatenate(eq.generate_test_data(1000, 200))
+    np.random.set_state(state)
+    exact = eq.exact_solution(xt)
+    gp = GP_Grad_Dependent_Nonlinear(eq)
+    gp.GPsolver(dom, bdy, GN_steps=20)
+    kw = dict(compat_rng="jax", compat_f16=True)
+    out = {"d": d, "protocol": "SimpleUniform (seed 1234), n = rho = 2 / full history n = 2, M = 3; HIP solvers on the reference's random stream",
+           "rel_l2": {}, "logged": {}}
+    for name, sol, want in (("GP", gp.predict(xt), printed("quadrature", "GP")),
+                            ("MLP", MLP(eq, **kw).u_solve(2, 2, xt), printed("quadrature", "MLP")),
+                            ("ScaSML", ScaSML(eq, gp, **kw).u_solve(2, 2, xt), printed("quadrature", "ScaSML")),
+                            ("MLP_full_history", MLP_full_history(eq, **kw).u_solve(2, None, xt, 3), printed("full_history", "MLP"))):
+        out["rel_l2"][name] = round(rel_l2(sol, exact), 6)
+        out["logged"][name] = round(want, 6)
+    out["max_relative_difference"] = round(max(abs(out["rel_l2"][k] - out["logged"][k]) / out["logged"][k] for k in out["logged"]), 5)
+    return out
 
 
 def main():
@@ -386,6 +429,7 @@ def main():
     u_gpu = solver.u_solve(n, par, xt_h) if args.variant == "quad" else solver.u_solve(n, None, xt_h, args.M)
     rel_gpu = rel_l2(u_gpu, exact)
     rel_gp = rel_l2(gp.predict(xt_h), exact) if gp is not None else None
+    ref_logs = reference_logs_check() if not args.no_reference_logs_check else None
 
     # ---- roofline of the dominant kernel (fused GP evaluation, MFMA-bound) ----------------------
     n_colloc = args.train_domain + args.train_boundary
@@ -542,6 +586,7 @@ def main():
                    "note": "value counts only EXECUTED path-steps (the reference's discarded n=0 terminal draws are not "
                            "performed); with the reference's own count the same run is value_reference_count"},
         "value_reference_count": round(work_ranks * B * steps_ref * args.steps / elapsed, 1),
+        "reference_logs_check": ref_logs,
         "l2_rel_error": {"solver_gpu": round(rel_gpu, 5), "gp_only": round(rel_gp, 5) if rel_gp is not None else None,
                          "points": "1000+200 harness set (np.random.seed(1234): the training draw, then this one, as tests/SimpleUniform.py)",
                          "vs_cpu_oracle": ({k: cpu[k] for k in ("rel_l2_gpu", "rel_l2_cpu", "abs_diff")} if cpu else None),
