@@ -192,21 +192,10 @@ class PicardEngine:
         """Device words [terminal key | the sub-keys this solve draws from the solver's stateful key]; advances that key."""
         from .. import threefry
         torch = _lib.require_gpu()
-
-        def splits(level):                                        # sub-keys one uz_solve(level) consumes, children included
-            if level <= 0:
-                return 0
-            return sum(int(plan.term[level][l].q) * (1 + splits(l) + splits(l - 1)) for l in range(level))
-        count = splits(plan.n) if self.variant == "quad" else 0   # the full-history solvers draw everything from the first key
-        words = [threefry.split((0, 0), 1, "partitionable")[0]]   # MLP.py:167-168: rebuilt from PRNGKey(0) in every call
-        key = self.jax_key
-        for _ in range(count):                                    # MLP.py:220: self.key, subkey = random.split(self.key)
-            pair = threefry.split(key, 2, "partitionable")
-            key = (int(pair[0][0]), int(pair[0][1]))
-            words.append(pair[1])
-        self.jax_key = key
-        self.jax_splits += count
-        self._work["jax_keys"] = torch.from_numpy(np.asarray(words, dtype=np.uint64).astype(np.uint32).view(np.int32).reshape(-1).copy()).cuda()
+        q = [[int(plan.term[level][l].q) for l in range(level)] for level in range(plan.n + 1)]
+        words, self.jax_key = threefry.solver_key_words(q, plan.n, self.jax_key, quadrature=self.variant == "quad")
+        self.jax_splits += len(words) - 1
+        self._work["jax_keys"] = torch.from_numpy(words.view(np.int32).reshape(-1).copy()).cuda()
         return self._work["jax_keys"]
 
     def _buffers(self, rows, kp):

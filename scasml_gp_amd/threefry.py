@@ -83,3 +83,25 @@ def choice_without_replacement(key, n, k, layout="original"):
 def reference_laplacian_idx(d, layout="original"):
     """The index set of models/GP.py:35 for spatial dimension d: ``choice(PRNGKey(0), d, (5,), replace=False)``."""
     return choice_without_replacement((0, 0), int(d), 5, layout)
+
+
+def solver_key_words(q, n, key=(0, 0), quadrature=True):
+    """Key words a solve on the reference's own random stream needs (``compat_rng="jax"``, SCASML_RNG_JAX_STREAM), and the solver's key
+    state after it.  ``q[level][l]`` = quadrature nodes of sub-level l in a level-``level`` call (``scasml_plan.term[level][l].q``).
+
+    The reference rebuilds ``split(PRNGKey(0), 1)[0]`` in every ``uz_solve`` call for its terminal draws (solvers/MLP.py:167-168, 178) -- word
+    pair 0 -- and takes one sub-key per quadrature node from the solver's stateful key, ``self.key, subkey = random.split(self.key)``
+    (:220), in call order: a level-n call consumes S(n) = sum_l q[n][l] (1 + S(l) + S(l-1)) of them, its children's included.  The
+    full-history solvers draw everything from the first key (MLP_full_history.py:92-93): S = 0.
+    Returns (uint32 array of shape (1 + S, 2), new key)."""
+    def count(level):
+        if level <= 0:
+            return 0
+        return sum(int(q[level][l]) * (1 + count(l) + count(l - 1)) for l in range(level))
+    words = [split((0, 0), 1, "partitionable")[0]]
+    key = (int(key[0]), int(key[1]))
+    for _ in range(count(n) if quadrature else 0):
+        pair = split(key, 2, "partitionable")
+        key = (int(pair[0][0]), int(pair[0][1]))
+        words.append(pair[1])
+    return np.asarray(words, dtype=np.uint64).astype(np.uint32), key

@@ -38,3 +38,32 @@ def test_odd_counts_are_padded_like_jax():
     assert a.shape == (7,) and not np.array_equal(a, b[:7])      # halves move with the size: the layouts are size-dependent
     y0, y1 = tf.threefry2x32((1, 2), [0, 1, 2, 3], [4, 5, 6, 0])
     assert np.array_equal(a, np.concatenate([y0, y1])[:7])
+
+
+def test_solver_key_words_follow_the_reference_call_order():
+    """The host side of SCASML_RNG_JAX_STREAM (scasml_gp_amd/threefry.py::solver_key_words) against the replay of the reference's recursion
+    (oracle/replay.py), which consumes its sub-keys in the reference's call order: same sub-keys, same key state after one and two solves."""
+    from oracle import jax_random as jr
+    from oracle.equation import GradDependentNonlinear
+    from oracle.replay import ReplayMLP
+    from oracle.tables import approx_parameters
+    from scasml_gp_amd.threefry import solver_key_words
+    rho = n = 2
+    _, _, Q, _, _ = approx_parameters(rho, 0.5)
+    q = [[int(Q[rho - 1, level - l - 1]) for l in range(level)] for level in range(n + 1)]       # MLP.py:211
+    words, key = solver_key_words(q, n)
+    assert words.shape == (16, 2) and words.dtype == np.uint32
+    assert np.array_equal(words[0], jr.split(jr.prng_key(0), 1)[0].astype(np.uint32))
+    rep = ReplayMLP(GradDependentNonlinear(6))
+    drawn = []
+    take = rep._next_subkey
+    rep._next_subkey = lambda: drawn.append(take()) or drawn[-1]
+    x = np.zeros((2, 6), dtype=np.float16)
+    rep.uz_solve(n, rho, x)
+    assert len(drawn) == 15 and np.array_equal(np.asarray(drawn).astype(np.uint32), words[1:])
+    assert tuple(int(v) for v in rep.key) == key
+    words2, key2 = solver_key_words(q, n, key)
+    rep.uz_solve(n, rho, x)
+    assert np.array_equal(np.asarray(drawn[15:]).astype(np.uint32), words2[1:]) and tuple(int(v) for v in rep.key) == key2
+    fh, same = solver_key_words(q, n, key, quadrature=False)
+    assert fh.shape == (1, 2) and same == key and np.array_equal(fh[0], words[0])
