@@ -46,9 +46,14 @@ def parse():
     ap.add_argument("--M", type=int, default=3, help="sample base of the full-history solvers")
     ap.add_argument("--train-domain", type=int, default=1000)
     ap.add_argument("--train-boundary", type=int, default=200)
-    ap.add_argument("--compat", choices=["reference", "none"], default="reference",
+    ap.add_argument("--compat", choices=["reference", "reference-geometry", "none"], default="reference",
                     help="reference (default): the surrogate the reference's code builds (shifted 5-index Hutchinson features, float16 entries; "
-                         "GP(compat='reference'), matrix-core kernel gp_eval_compat_mfma); none: the operators it documents (gp_eval_bf16)")
+                         "GP(compat='reference'), matrix-core kernel gp_eval_compat_mfma); reference-geometry: the same fit evaluated without the "
+                         "per-entry float16 roundings (factored sums, one point plane); none: the operators it documents (gp_eval_bf16)")
+    ap.add_argument("--rng", choices=["philox", "jax"], default="philox",
+                    help="jax: the solvers draw the reference's own random stream on the device (compat_rng='jax': jax.random's float16 normals and "
+                         "uniform times under its key schedule) -- with --compat-f16 the mode that reproduces the reference's logged numbers")
+    ap.add_argument("--compat-f16", action="store_true", help="the reference's solver-level float16 casts (g, f, every uz_solve return)")
     ap.add_argument("--cpu-sample", type=int, default=64, help="roots of the same workload timed on the CPU oracle")
     ap.add_argument("--shard", choices=["roots", "samples"], default="roots",
                     help="roots: each rank its own B roots, no collective (weak scaling, default); samples: every rank the same "
@@ -92,7 +97,8 @@ def cpu_baseline(args, eq, gp, eng, n, par, x_t, x_dev, x_dom, x_bdy, steps_exec
         ogp.phi_dim = 4 * len(x_dom) + len(x_bdy)
         ogp.right_vector = gp.right_vector
     ns = min(args.cpu_sample if gp is not None else 4096 * args.cpu_sample, B)   # ~10-30 s of CPU work either way
-    ora = PicardOracle(oeq, args.variant, gp=ogp, seed=0, stream=99)
+    ora = PicardOracle(oeq, args.variant, gp=ogp, seed=0, stream=99, compat_f16=args.compat_f16, jax_stream=args.rng == "jax")
+    ora.jax_splits = eng.jax_splits                          # the replay below (stream_id given) reads the solver's key where it stands
     t0 = time.perf_counter()
     uz_cpu = ora.uz_solve(n, par, x_t[:ns])
     t_cpu = time.perf_counter() - t0
@@ -132,8 +138,9 @@ def kernel_source_sha1(files):
     return h.hexdigest()
 
 
-GP_EVAL_SOURCES = {"reference": ["gp_eval_compat_mfma.hip", "gp_mfma16.hpp", "gp_common.hpp"], "none": ["gp_eval_bf16.hip", "gp_mfma16.hpp", "gp_common.hpp"]}
-PICARD_SOURCES = ["picard_tree.hip", "philox_normal.hpp", "equations.hpp"]
+GP_EVAL_SOURCES = {"reference": ["gp_eval_compat_mfma.hip", "gp_mfma16.hpp", "gp_common.hpp"],
+                   "reference-geometry": ["gp_eval_compat_mfma.hip", "gp_mfma16.hpp", "gp_common.hpp"], "none": ["gp_eval_bf16.hip", "gp_mfma16.hpp", "gp_common.hpp"]}
+PICARD_SOURCES = ["picard_tree.hip", "picard_tree.hpp", "philox_normal.hpp", "equations.hpp"]
 
 
 FP64_MFMA_PEAK_TFLOPS = 78.6    # v_mfma_f64_16x16x4_f64 dense, MI355X_MICROARCH.md / SURVEY.md 8(d)
@@ -300,15 +307,17 @@ def main():
     np.random.set_state(state)
     gp, t_train = None, 0.0
     if args.solver == "scasml":
-        compat = "reference" if args.compat == "reference" else None
+        compat = None if args.compat == "none" else args.compat
         gp = GP_Grad_Dependent_Nonlinear(eq, compat=compat)      # reference: its own Hutchinson index draw (threefry.py)
         t0 = time.time()
         gp.GPsolver(x_dom, x_bdy, GN_steps=20)
         torch.cuda.synchronize()
         t_train = time.time() - t0
-        solver = (ScaSML if args.variant == "quad" else ScaSML_full_history)(eq, gp, seed=0)
+        skw = dict(seed=0, compat_f16=args.compat_f16, compat_rng="jax" if args.rng == "jax" else None)
+        solver = (ScaSML if args.variant == "quad" else ScaSML_full_history)(eq, gp, **skw)
     else:
-        solver = (MLP if args.variant == "quad" else MLP_full_history)(eq, seed=0)
+        skw = dict(seed=0, compat_f16=args.compat_f16, compat_rng="jax" if args.rng == "jax" else None)
+        solver = (MLP if args.variant == "quad" else MLP_full_history)(eq, **skw)
 
     # synthetic inputs: x ~ U[-0.5, 0.5]^d, t ~ U[0, 0.5), resident in HBM before timing
     def synth(seed):
@@ -482,7 +491,8 @@ def main():
             kinds = eng.site_kinds(n, par).cpu().numpy()
             n_full, n_part = int((kinds == 0).sum()) * B, int(np.isin(kinds, (1, 3, 4)).sum()) * B
             nd_pad = (args.train_domain + 31) // 32 * 32
-            per_geom = lambda rows, q: 2.0 * rows * (2 * kp + (16 if q else 0))
+            planes = 1 if (int(gp.eval_round16) & 4) else 2
+            per_geom = lambda rows, q: 2.0 * rows * (planes * kp + (16 if q else 0))
             issued_flops = n_full * (3 * per_geom(nd_pad, True) + 2 * per_geom(n_pad - nd_pad, True)) \
                 + n_part * (2 * per_geom(nd_pad, True) + per_geom(n_pad - nd_pad, False))
             issued = issued_flops / (gp_ms * 1e-3) / 1e12
@@ -492,7 +502,10 @@ def main():
             flops_ac = 2.0 * (d + 1) * (n_full * (3 * args.train_domain + 2 * args.train_boundary)
                                         + n_part * (2 * args.train_domain + args.train_boundary)) + 10.0 * n_inf * m_feat
             ach_ac = flops_ac / (gp_ms * 1e-3) / 1e12
-            roofline = {"kernel": "gp_eval_compat_mfma_kernel (as-coded surrogate: 3 shifted geometries x 2 fp16 planes, float16 entries)",
+            geometry = not (int(gp.eval_round16) & 1)
+            roofline = {"kernel": ("gp_eval_compat_mfma_kernel (compat='reference-geometry': the as-coded fit, 3 shifted geometries x %d fp16 plane%s, entries "
+                                   "not rounded: factored sums)" % (planes, "" if planes == 1 else "s")) if geometry else
+                                  "gp_eval_compat_mfma_kernel (as-coded surrogate: 3 shifted geometries x 2 fp16 planes, float16 entries)",
                         "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                         "traffic": traffic, "traffic_source": traffic_source, "valu_issue": issue, "avg_launch_ms": round(gp_ms, 4),
                         "flops_per_launch": flops, "mfma_issued_tflops": round(issued, 1), "mfma_issued_frac": round(issued / peak, 4),

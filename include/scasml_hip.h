@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SCASML_ABI_VERSION 4
+#define SCASML_ABI_VERSION 5
 #define SCASML_MAX_LEVEL 5   /* Picard level n <= 5 (kernels are instantiated per level)      */
 #define SCASML_MAX_Q 6       /* quadrature nodes per rule <= 6 (rho <= 5, solvers/MLP.py:132)  */
 #define SCASML_MAX_DIM 252   /* spatial dimension d <= 252 (one 4-dim quad per lane, +t, +3 spare columns) */
@@ -78,8 +78,8 @@ typedef struct {
  * float16 (equations/equations.py:261, 304), ScaSML.g / ScaSML.f subtract float16 from float16 (solvers/ScaSML.py:45-47, 62), and every
  * uz_solve returns clip(...).astype(float16) (solvers/MLP.py:274, ScaSML.py:284, MLP_full_history.py:180; ScaSML_full_history.py:199
  * does not cast), so a child's (u, z) is a float16 value before the parent's f sees it.  Sample-sharded partial sums (world > 1) are
- * left unrounded: the cast follows the clip, which follows the all-reduce.
- * JAX_STREAM (n <= 3, no sample sharding) replaces the Philox stream by the REFERENCE's own normals (and, full history, uniform times) --
+ * left unrounded: the cast follows the clip, which follows the all-reduce (scasml_clip_round16).
+ * JAX_STREAM (every level 1..SCASML_MAX_LEVEL, no sample sharding) replaces the Philox stream by the REFERENCE's own normals (and, full history, uniform times) --
  * jax.random.normal(key, shape, float16) under jax_threefry_partitionable, each element addressed by the row-major index it has in the
  * reference's batch-vectorised draw (one Threefry-2x32 per normal) -- under the keys in scasml_rng.jax_keys; seed / stream are ignored.
  * With it a solve on the reference's test set lands on the numbers its runs logged (tests/test_gpu_jax_stream.py). */
@@ -151,6 +151,9 @@ int scasml_picard_tree(const scasml_problem *prob_h, const scasml_plan *plan_h, 
 
 /* Clip all-reduced partial sums in place (world > 1): MLP.py:272-274 / ScaSML.py:281-284. */
 int scasml_clip(float *uz, int64_t count, float clip, void *stream);
+/* The same followed, when round16 != 0, by the root call's .astype(float16) (MLP.py:274, ScaSML.py:284, MLP_full_history.py:180 --
+ * ScaSML_full_history.py:199 does not cast): what a sample-sharded solve under SCASML_RNG_COMPAT_F16 still owes after its all-reduce. */
+int scasml_clip_round16(float *uz, int64_t count, float clip, int32_t round16, void *stream);
 
 /* Raw RNG access for parity tests: normals of `site` for roots root0..root0+B-1 -> B x d. */
 int scasml_debug_normals(scasml_rng rng, uint32_t site, int32_t d, int64_t B, float *out, void *stream);

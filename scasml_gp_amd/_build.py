@@ -8,7 +8,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libscasml_hip.so")
-SOURCES = ["plan_host.cpp", "picard_tree.hip", "gp_eval.hip", "gp_eval_bf16.hip", "gp_train.hip", "gp_compat.hip", "gp_eval_compat_mfma.hip", "dist_linalg.hip"]
+SOURCES = ["plan_host.cpp", "picard_tree_jax_deep.hip", "picard_tree.hip", "picard_tree_jax.hip", "gp_eval.hip", "gp_eval_bf16.hip", "gp_train.hip", "gp_compat.hip", "gp_eval_compat_mfma.hip", "dist_linalg.hip"]
 # -ffp-contract=off: the RNG transform is specified in separately rounded IEEE mul/add
 # (philox_normal.hpp); every fused multiply-add elsewhere is written as fmaf() explicitly.
 # -fno-slp-vectorize: hipcc otherwise packs the scalar f32 epilogue into v_pk_fma_f32 / v_pk_mul_f32 plus
@@ -45,7 +45,7 @@ def build_library(force=False, verbose=False):
         if r.returncode != 0:
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
         list(ex.map(run, jobs))
     if force or jobs or not os.path.exists(LIB):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)

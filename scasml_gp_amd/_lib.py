@@ -8,7 +8,7 @@ MAX_Q = 6
 MAX_DIM = 252
 GP_TILE = 32
 DIST_BLOCK = 256
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 MODE_MLP, MODE_GENERATE, MODE_ACCUMULATE = 0, 1, 2
 RNG_COMPAT_CRN = 1
@@ -63,6 +63,7 @@ SIGNATURES = {
     "scasml_picard_tree": (C.c_int, [C.POINTER(Problem), C.POINTER(Plan), C.c_int, C.c_void_p, C.c_int64, C.c_int64, Rng,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "scasml_clip": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
+    "scasml_clip_round16": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_int32, C.c_void_p]),
     "scasml_debug_normals": (C.c_int, [Rng, C.c_uint32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "scasml_debug_jax_normals": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p]),
     "scasml_debug_transform": (C.c_int, [C.c_uint32, C.c_int64, C.c_void_p, C.c_void_p]),

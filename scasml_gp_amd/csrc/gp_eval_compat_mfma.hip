@@ -93,30 +93,36 @@ __device__ __forceinline__ float pin(float x) {
     return x;
 }
 
-// one collocation tile's x.y' on the fp16 matrix cores: 2 MFMAs per K-step (point planes h, l against the one collocation plane)
-template <int KS>
-__device__ __forceinline__ void compat_mfma_lam(const float4 *lds_a, const s16x8 (&xb)[2][KS], f32x16 &acc, int lane) {
+// one collocation tile's x.y' on the fp16 matrix cores: 2 MFMAs per K-step (point planes h, l against the one collocation plane).
+// PLANES = 1 (the geometry mode's option, round16 bit 2): the high plane only -- the point's coordinates enter x.y' rounded to float16
+// (|x|^2 stays float32: the low part of its column is the accumulator's start value acc0), half the MFMAs.
+template <int KS, int PLANES>
+__device__ __forceinline__ void compat_mfma_lam(const float4 *lds_a, const s16x8 (&xb)[PLANES][KS], f32x16 &acc, int lane, float acc0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int r = 0; r < 16; ++r) acc[r] = acc0;
     Frag a[2];
     a[0].f = lds_a[lane];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         const int cur = s & 1, nxt = cur ^ 1;
         if (s + 1 < KS) a[nxt].f = lds_a[(s + 1) * 64 + lane];
-        Frag b0, b1;
+        Frag b0;
         b0.v = xb[0][s];
-        b1.v = xb[1][s];
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cur].h, b1.h, acc, 0, 0, 0);   // small terms first
+        if constexpr (PLANES == 2) {
+            Frag b1;
+            b1.v = xb[1][s];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cur].h, b1.h, acc, 0, 0, 0);   // small terms first
+        }
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cur].h, b0.h, acc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 // Row constants of a stage: 32 rows x 8 floats (scasml_gp_compat_pack_mfma)
-//   al: sy  ty  c0  cL | ct  cS  -   -            sy = a sum_{k<d} y_k, ty = a t_y
+//   al: sy  ty  c0  cL | ct  cS  act adcS         sy = a sum_{k<d} y_k, ty = a t_y;            act = a ct, adcS = a d cS
 //   ys: sy1 ay0 wy1 cL | -   -   -   -            sy1 = a sum_{k<d} y'_k, ay0 = a y_0, wy1 = 2 h a^2 sum_j y_{i_j+1}
-//   xs: sy  ty  wy2 c0 | ct  cS  -   -            wy2 = 2 h a^2 sum_j y_{i_j}
+//   xs: sy  ty  wy2 c0 | ct  cS  e0  cSw          wy2 = 2 h a^2 sum_j y_{i_j};                 e0 = c0 - ct ty - cS sy, cSw = cS wy2
+// (the last two of al and xs serve the factored epilogue only)
 struct CompatPoint {
     float sx, tx, ax0, sx2, wxa, wxb;   // a S_x, a t_x, a x_0, a (S_x - x_0 + t_x), 2 h a^2 sum_j x_{i_j+1}, 2 h a^2 sum_j x_{i_j}
 };
@@ -222,11 +228,84 @@ __device__ __forceinline__ void compat_epilogue(const float *rows_lds, const f32
     }
 }
 
+// The GEOMETRY mode (round16 bit 0 off; GP(compat="reference-geometry")): the same sixteen entries in the same three pair geometries with the
+// same Hutchinson sums, WITHOUT the float16 rounding of every entry.  Nothing then stops the four sums from factoring per geometry the way
+// gp_eval_bf16.hip's E does:   with  pp = a r_t,  ss = a S,  E = c0 + ct pp + cS ss
+//     al   u += kappa0 E      dt += kappa0 (a ct - pp E)      div += kappa0 (a d cS - ss E)      lap += cL kappa0 (G0 (G0 - 4 a h) - 10 a^2 h^2)
+//     ys   w = cL kappa1 G1:  u += w      dt -= (a t_x - a y_0) w      div += -s1 w + cL kappa1 (2 h a^2 R1)
+//     xs   lap += kappa2 (G2 (e0 + ct a x_0 + cS sx2) - cS (wxa - wy2)),   e0 = c0 - ct ty - cS sy  (a row constant)
+// 13 + exp, 9 + exp and 5 + exp vector instructions per pair against 27 + exp, 13 + exp, 13 + exp of the as-coded form.  The fit is the
+// as-coded one (same Gram, same right_vector); what the mode gives up is the reference's rounding noise in the hot evaluation -- measured on the
+// reference's own experiments: GP relative L2 moves by <= 8e-6, ScaSML by <= 3e-5 (profiles/r04_eval_rounding_study.txt).
+template <int GEOM, int FORM, bool BDY>
+__device__ __forceinline__ void compat_epilogue_fact(const float *rows_lds, const f32x16 &lam, const f32x16 &G, int half, const CompatPoint &p,
+                                                     const CompatConsts &c, float &au, float &at, float &ad, float &al) {
+    const float4 *cb = reinterpret_cast<const float4 *>(__builtin_assume_aligned(rows_lds + 4 * 8 * half, 16));   // row = (r&3) + 8 (r>>2) + 4 half
+    // which float4 of a row's eight constants this case reads: al domain both, al boundary and ys the first, xs the second
+    constexpr int Q0 = GEOM == 2 ? 1 : 0;
+    constexpr int NQ = (GEOM == 0 && !BDY) ? 2 : 1;
+    float4 q[2][NQ];
+    auto fetch = [&](int r, float4 (&dst)[NQ]) {
+        const int row = (r & 3) + 8 * (r >> 2);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) dst[i] = cb[row * 2 + Q0 + i];
+    };
+    fetch(0, q[0]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int cur = r & 1, nxt = cur ^ 1;
+        if (r + 1 < 16) fetch(r + 1, q[nxt]);
+        __builtin_amdgcn_sched_barrier(0);
+        const float kap = __builtin_amdgcn_exp2f(lam[r]);
+        if constexpr (GEOM == 0) {
+            const float vsy = q[cur][0].x, vty = q[cur][0].y, c0 = q[cur][0].z;
+            if constexpr (BDY) {                                    // boundary rows: c0 only
+                const float F = c0 * kap;
+                au += F;
+                if constexpr (FORM == 0) at = fmaf(-(p.tx - vty), F, at);
+                if constexpr (FORM != 1) ad = fmaf(-(p.sx - vsy), F, ad);
+            } else {
+                const float cL = q[cur][0].w, ct = q[cur][1].x, cS = q[cur][1].y;
+                const float pp = p.tx - vty, ss = p.sx - vsy;       // a r_t, a S
+                const float E = fmaf(ct, pp, fmaf(cS, ss, c0));
+                au = fmaf(kap, E, au);
+                if constexpr (FORM != 1) ad = fmaf(kap, fmaf(-ss, E, q[cur][1].w), ad);
+                if constexpr (FORM == 0) {
+                    at = fmaf(kap, fmaf(-pp, E, q[cur][1].z), at);
+                    const float g0 = G[r];
+                    al = fmaf(cL * kap, fmaf(g0, g0 - c.c4, -c.c10), al);
+                }
+            }
+        } else if constexpr (GEOM == 1) {       // lap_y rows, coefficient cL (domain tiles only)
+            const float vsy1 = q[cur][0].x, vay0 = q[cur][0].y, vwy1 = q[cur][0].z, cL = q[cur][0].w;
+            const float v = cL * kap;
+            if constexpr (FORM == 1) {
+                au = fmaf(v, G[r], au);
+            } else {
+                const float w = v * G[r];
+                au += w;
+                ad = fmaf(-(p.sx - vsy1), w, fmaf(v, p.wxb - vwy1, ad));
+                if constexpr (FORM == 0) at = fmaf(-(p.tx - vay0), w, at);
+            }
+        } else {                                // lap_x rows (full form only); boundary rows have ct = cS = 0: e0 = c0, cSw = 0
+            const float ct = q[cur][0].x, cS = q[cur][0].y, e0 = q[cur][0].z, cSw = q[cur][0].w;
+            if constexpr (BDY) {
+                al = fmaf(kap * G[r], e0, al);
+            } else {
+                const float E2 = fmaf(ct, p.ax0, fmaf(cS, p.sx2, e0));
+                const float t = fmaf(cS, p.wxa, -cSw);
+                al = fmaf(kap, fmaf(G[r], E2, -t), al);
+            }
+        }
+    }
+}
+
 // Stage block, in floats (scasml_gp_compat_pack_mfma): KS*256 planes | 256 Q fragment | 256 row constants (32 x 8) = (KS + 2) KiB
 constexpr int kStageTail = 256 + 256;
 
-template <int KS, int BPC, bool R16>
+template <int KS, int BPC, bool R16, int PLANES>
 __global__ __launch_bounds__(256, BPC) void gp_eval_compat_mfma_kernel(const GpCompatArgs g) {
+    static_assert(PLANES == 2 || !R16, "the as-coded form keeps both point planes");
     // three slots: stage s is read while s + 1 has landed or lands and s + 2 is issued into the slot stage s - 1 was read from, which
     // every wave left before the barrier that ended step s - 1
 #ifndef SCASML_COMPAT_NSLOT
@@ -320,7 +399,8 @@ __global__ __launch_bounds__(256, BPC) void gp_eval_compat_mfma_kernel(const GpC
     const float qs = 0.5f * 1.44269504088896341f / g.a, k1 = -qs;
     const float hh = (float)g.d / (float)kHutch;
     const float ha2 = hh * g.a * g.a;
-    s16x8 xb[2][KS];
+    s16x8 xb[PLANES][KS];
+    float acc0 = 0.0f;          // PLANES == 1: the low part of the |x|^2 column, which the dropped plane would have carried
     CompatPoint pt;
     Frag qa[1], qb[1];          // B fragments of the Q products: components i_j + 1 (al, xs) and i_j (ys)
     {
@@ -359,7 +439,7 @@ __global__ __launch_bounds__(256, BPC) void gp_eval_compat_mfma_kernel(const GpC
                 Frag fh, fl;
                 make_planes(t, fh, fl);
                 xb[0][s] = fh.v;
-                xb[1][s] = fl.v;
+                if constexpr (PLANES == 2) xb[1][s] = fl.v;
             }
         }
         pn += __shfl_xor(pn, 32);
@@ -371,7 +451,8 @@ __global__ __launch_bounds__(256, BPC) void gp_eval_compat_mfma_kernel(const GpC
             Frag fh, fl;
             make_planes(tlast, fh, fl);
             xb[0][KS - 1] = fh.v;
-            xb[1][KS - 1] = fl.v;
+            if constexpr (PLANES == 2) xb[1][KS - 1] = fl.v;
+            else acc0 = k1 * g.a * g.a * pn - (float)(_Float16)(k1 * g.a * g.a * pn);   // both halves: every row of this lane's column
         }
         pt.sx = g.a * (ps - ptime);           // the row sum includes t
         pt.tx = g.a * ptime;
@@ -429,7 +510,7 @@ __global__ __launch_bounds__(256, BPC) void gp_eval_compat_mfma_kernel(const GpC
         if (s_now + AHEAD < n_stages) stage(s_now + AHEAD);
         const float *base = lds + slot * STAGE;
         if (region & 1) {
-            compat_mfma_lam<KS>(reinterpret_cast<const float4 *>(base), xb, acc, lane);
+            compat_mfma_lam<KS, PLANES>(reinterpret_cast<const float4 *>(base), xb, acc, lane, acc0);
             if constexpr (NEEDG) {
                 Frag aq;
                 aq.f = reinterpret_cast<const float4 *>(base + KS * 256)[lane];
@@ -438,7 +519,10 @@ __global__ __launch_bounds__(256, BPC) void gp_eval_compat_mfma_kernel(const GpC
                 accG = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq.h, GEOM == 1 ? qb[0].h : qa[0].h, accG, 0, 0, 0);
             }
         }
-        if (region & 2) compat_epilogue<GEOM, FORM, BDY, R16>(base + (KS + 1) * 256, acc, accG, half, pt, cc, au, at, ad, al);
+        if (region & 2) {
+            if constexpr (R16) compat_epilogue<GEOM, FORM, BDY, true>(base + (KS + 1) * 256, acc, accG, half, pt, cc, au, at, ad, al);
+            else compat_epilogue_fact<GEOM, FORM, BDY>(base + (KS + 1) * 256, acc, accG, half, pt, cc, au, at, ad, al);
+        }
         rendezvous(s_now + AHEAD < n_stages);
         ++s_now;
     };
@@ -545,6 +629,8 @@ __global__ void gp_compat_pack_mfma_kernel(int d, float a, const float *x_dom, i
             rc[3] = cL;
             rc[4] = ct;
             rc[5] = cS;
+            rc[6] = a * ct;
+            rc[7] = a * (float)d * cS;
         } else if (g == 1) {
             rc[0] = a * (sy - y(0) + y(d));
             rc[1] = a * y(0);
@@ -557,21 +643,24 @@ __global__ void gp_compat_pack_mfma_kernel(int d, float a, const float *x_dom, i
             rc[3] = c0;
             rc[4] = ct;
             rc[5] = cS;
+            rc[6] = fmaf(-cS, rc[0], fmaf(-ct, rc[1], c0));
+            rc[7] = cS * rc[2];
         }
     }
 }
 
-template <int KS, bool R16>
+template <int KS, bool R16, int PLANES>
 static int launch_compat(const GpCompatArgs &g, hipStream_t s) {
-    // registers: 8 KS for the point planes + ~90 for accumulators, Q fragments, row constants and temporaries
-    constexpr int REGS = 8 * KS + 90;
-    constexpr int BPC = REGS <= 128 ? 4 : (REGS <= 168 ? 3 : 2);
+    // registers: 4 KS per point plane + ~90 for accumulators, Q fragments, row constants and temporaries
+    constexpr int REGS = 4 * PLANES * KS + 90;
+    constexpr size_t lds_bytes = SCASML_COMPAT_NSLOT * (size_t)(KS * 256 + kStageTail) * sizeof(float);
+    constexpr int BPC_REGS = REGS <= 128 ? 4 : (REGS <= 168 ? 3 : 2), BPC_LDS = (int)(160 * 1024 / lds_bytes);
+    constexpr int BPC = BPC_REGS < BPC_LDS ? BPC_REGS : BPC_LDS;
     const int64_t waves = (g.n_inf + 31) / 32;
     const int64_t blocks = (waves + 3) / 4;
     if (blocks > 0x7FFFFFFF) return fail(SCASML_ERR_UNSUPPORTED, "gp_eval_compat_sites: too many points");
-    constexpr size_t lds_bytes = SCASML_COMPAT_NSLOT * (size_t)(KS * 256 + kStageTail) * sizeof(float);
     static_assert(lds_bytes * BPC <= 160 * 1024, "LDS slots exceed 160 KiB");
-    auto kern = gp_eval_compat_mfma_kernel<KS, BPC, R16>;
+    auto kern = gp_eval_compat_mfma_kernel<KS, BPC, R16, PLANES>;
     if (lds_bytes > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
             return fail(SCASML_ERR_HIP, "gp_eval_compat_sites: cannot reserve %zu bytes of LDS", lds_bytes);
@@ -580,11 +669,11 @@ static int launch_compat(const GpCompatArgs &g, hipStream_t s) {
     return check_launch("gp_eval_compat_sites launch");
 }
 
-template <bool R16>
+template <bool R16, int PLANES>
 static int launch_compat_ks(const GpCompatArgs &g, hipStream_t s) {
     switch (g.kp / 16) {
 #define SCASML_CASE(K) \
-    case K: return launch_compat<K, R16>(g, s);
+    case K: return launch_compat<K, R16, PLANES>(g, s);
         SCASML_CASE(1) SCASML_CASE(2) SCASML_CASE(3) SCASML_CASE(4) SCASML_CASE(5) SCASML_CASE(6) SCASML_CASE(7) SCASML_CASE(8)
         SCASML_CASE(9) SCASML_CASE(10) SCASML_CASE(11) SCASML_CASE(12) SCASML_CASE(13) SCASML_CASE(14) SCASML_CASE(15) SCASML_CASE(16)
 #undef SCASML_CASE
@@ -657,5 +746,9 @@ extern "C" int scasml_gp_eval_compat_sites(int32_t d, float a, float sigma_eq, f
     g.site_kinds = site_kinds;
     g.rows_per_site = rows_per_site;
     hipStream_t s = (hipStream_t)stream;
-    return (round16 & 1) ? launch_compat_ks<true>(g, s) : launch_compat_ks<false>(g, s);
+    if (round16 & 1) {
+        if (round16 & 4) return fail(SCASML_ERR_ARG, "gp_eval_compat_sites: round16 bit 2 (one point plane) is the geometry mode's option, not the as-coded form's");
+        return launch_compat_ks<true, 2>(g, s);
+    }
+    return (round16 & 4) ? launch_compat_ks<false, 1>(g, s) : launch_compat_ks<false, 2>(g, s);
 }

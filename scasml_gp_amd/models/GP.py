@@ -21,6 +21,11 @@ Two surrogates (``compat``):
   reference's are -- and in float64 (csrc/gp_compat.hip, ``compat_eval = "float64"``) otherwise; Gram, gradient and the CPU
   statement (oracle/gp_compat.py) are float64.  ``laplacian_idx`` may be the five indices or the name of the Threefry counter
   layout ("original" / "partitionable") with which the reference's own draw is recomputed (scasml_gp_amd/threefry.py).
+* ``"reference-geometry"`` (opt-in): the SAME fit (Gram, K_p, right_vector of ``"reference"``) evaluated on the hot path without the float16
+  rounding of every kernel entry, which lets the four sums factor per pair geometry (13 + 9 + 5 vector instructions per pair instead of
+  27 + 13 + 13), and with the evaluation point's coordinates entering the x.y products as ONE float16 plane (half the MFMAs).  On the
+  reference's own experiments (d = 20 .. 80) GP relative L2 moves by <= 1e-5 and ScaSML by <= 3e-5 against ``"reference"``
+  (profiles/r04_eval_rounding_study.txt); u_hat and eps_PDE still leave as float16 values (:671, 769).
 Remaining deviations in both: Newton start at 0 instead of 1e-3*N(0,1) from PRNGKey(0) (:501); Cholesky instead of
 the SVD factor, so the float16 rounding of L itself (:266) has no counterpart (no measurable effect).
 """
@@ -45,8 +50,12 @@ class GP(object):
         reference's logged errors, "original" is jax < 0.5).  compat=None: the operators the reference documents."""
         if compat == "exact":
             compat = None
+        # "reference-geometry": the fit of "reference", the hot evaluation without the per-entry float16 roundings (module docstring)
+        self.eval_geometry = compat == "reference-geometry"
+        if self.eval_geometry:
+            compat = "reference"
         if compat not in (None, "reference"):
-            raise ValueError("compat must be 'reference' or None")
+            raise ValueError("compat must be 'reference', 'reference-geometry' or None")
         if compat == "reference" and equation.n_input - 1 < 5:
             raise ValueError("compat='reference' draws five distinct Hutchinson indices from d = %d < 5 coordinates (the reference's "
                              "random.choice(..., replace=False) fails there too); use compat=None" % (equation.n_input - 1))
@@ -78,6 +87,10 @@ class GP(object):
         # compat="reference" evaluation kernel: "mfma" (matrix cores; needs float16-exact collocation points, else float64 is
         # used) or "float64" (one wavefront per point, rounding decided exactly as the NumPy statement decides it)
         self.compat_eval = os.environ.get("SCASML_GP_COMPAT_EVAL", "mfma")
+        # round16 argument of the compat evaluation: bit 0 = every kernel entry rounded to float16 (:43, 55-179), bit 1 = u_hat and eps_PDE
+        # leave as float16 values (:671, 769), bit 2 = one float16 plane of the evaluation point in x.y (matrix-core kernel, with bit 0 off).
+        # 3 is the reference's code; 6 is compat="reference-geometry"
+        self.eval_round16 = int(os.environ.get("SCASML_GP_EVAL_ROUND16", "6" if self.eval_geometry else "3"))
         self.profile = False            # bench.py: HIP-event time of every training stage into self.stage_ms
         self.stage_ms = {}
 
@@ -96,11 +109,17 @@ class GP(object):
 
     # ------------------------------------------------------------------ device helpers
     def _points_device(self, x):
-        """(n, d+1) numpy / torch -> (n, kp) float32 CUDA rows (X, t, zero pad)."""
+        """(n, d+1) numpy / torch -> (n, kp) float32 CUDA rows (X, t, zero pad).  The largest |coordinate| of a host array is noted on the
+        host (self._host_bound) so that the evaluation need not read it back from the device."""
         torch = _lib.require_gpu()
         was_numpy = not isinstance(x, torch.Tensor)
-        xt = torch.from_numpy(np.ascontiguousarray(np.asarray(x), dtype=np.float32)).cuda() if was_numpy \
-            else x.to(device="cuda", dtype=torch.float32)
+        self._host_bound = None
+        if was_numpy:
+            arr = np.ascontiguousarray(np.asarray(x), dtype=np.float32)
+            self._host_bound = float(np.abs(arr).max()) if arr.size else 0.0
+            xt = torch.from_numpy(arr).cuda()
+        else:
+            xt = x.to(device="cuda", dtype=torch.float32)
         if xt.dim() != 2 or xt.shape[1] != self.d + 1:
             raise ValueError("points must have shape (n, %d), got %s" % (self.d + 1, tuple(xt.shape)))
         kp = int(_lib.load().scasml_point_stride(self.d))
@@ -134,12 +153,13 @@ class GP(object):
         return m
 
     def _eval_device(self, pts):
-        """Caller-supplied points: their coordinate bound is measured (one reduction + host read) so that far-out rows fall
-        back to the bf16 x 3 arithmetic instead of overflowing the fp16 planes."""
+        """Caller-supplied points: their coordinate bound (taken on the host for host arrays; one reduction + read for device tensors) lets
+        far-out rows fall back to the bf16 x 3 arithmetic instead of overflowing the fp16 planes."""
         torch = _lib.require_gpu()
         out = torch.empty((pts.shape[0], 4), dtype=torch.float32, device="cuda")
         fp16_planes = (int(self.eval_split) == 22 and self.compat is None) or (self.compat == "reference" and self.compat_eval == "mfma")
-        xb = float(pts.abs().max()) if pts.shape[0] and fp16_planes else 0.0
+        hb, self._host_bound = getattr(self, "_host_bound", None), None
+        xb = (hb if hb is not None else float(pts.abs().max())) if pts.shape[0] and fp16_planes else 0.0
         self._eval_rows(pts, pts.shape[0], 0, None, out, x_bound=max(xb, 2.0) if xb > 0 else 0.0)
         return out
 
@@ -155,14 +175,14 @@ class GP(object):
             if self.compat_eval == "mfma" and self._compat_model is not None and 0.7213 * a * xb * xb * (self.d + 1) <= 3.0e4:
                 _lib.check(lib.scasml_gp_eval_compat_sites(
                     self.d, a, float(self.equation.sigma()), float(self.equation.mu()), int(self.equation.eq_id), _lib.ptr(self._compat_model),
-                    self.N_domain, self.N_boundary, self.laplacian_idx.ctypes.data_as(C.c_void_p), 3, float(x_bound), _lib.ptr(pts), n_rows,
+                    self.N_domain, self.N_boundary, self.laplacian_idx.ctypes.data_as(C.c_void_p), int(self.eval_round16), float(x_bound), _lib.ptr(pts), n_rows,
                     rows_per_site if kinds is not None else 0, _lib.ptr(kinds) if kinds is not None else None, _lib.ptr(out4), None,
                     _lib.stream_ptr()), "gp_eval_compat_sites")
                 return
             N = self.N_domain + self.N_boundary
             _lib.check(lib.scasml_gp_eval_compat(self.d, a, float(self.equation.sigma()),
                                                  float(self.equation.mu()), int(self.equation.eq_id), _lib.ptr(self._colloc_t), self.N_domain, self.N_boundary, N, _lib.ptr(self._rv_dev),
-                                                 self.laplacian_idx.ctypes.data_as(C.c_void_p), 3, _lib.ptr(pts), n_rows,
+                                                 self.laplacian_idx.ctypes.data_as(C.c_void_p), int(self.eval_round16) & 3, _lib.ptr(pts), n_rows,
                                                  pts.shape[1], _lib.ptr(out4), None, _lib.stream_ptr()), "gp_eval_compat")
             return
         model = self._device_model(x_bound)

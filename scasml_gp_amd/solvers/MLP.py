@@ -7,7 +7,9 @@ class MLP:
     '''Multilevel Picard Iteration for high dimensional semilinear PDE (solvers/MLP.py:5-25)'''
     _variant = "quad"
 
-    def __init__(self, equation, seed=0, compat_crn=False, compat_f16=False, compat_rng=None):
+    def __init__(self, equation, seed=0, compat_crn=False, compat_f16=False, compat_rng=None, reference_mode=False):
+        """reference_mode=True: what the reference's solver object computes -- its random stream under its key schedule
+        (compat_rng="jax") and its solver-level float16 casts (compat_f16) -- in one switch."""
         self.equation = equation
         self.sigma = equation.sigma
         self.mu = equation.mu
@@ -18,7 +20,8 @@ class MLP:
         self.n_output = equation.n_output
         self.evaluation_counter = 0
         self.key = seed                      # Philox seed; replaces random.PRNGKey(0) (:25)
-        self._engine = PicardEngine(equation, self._variant, gp=None, seed=seed, compat_crn=compat_crn, compat_f16=compat_f16, compat_rng=compat_rng)
+        self._engine = PicardEngine(equation, self._variant, gp=None, seed=seed, compat_crn=compat_crn, compat_f16=compat_f16, compat_rng=compat_rng,
+                                    reference_mode=reference_mode)
 
     def f(self, x_t, u, z):
         return self.equation.f(x_t, u, z)                         # :27-41

@@ -6,7 +6,9 @@ class MLP_full_history:
     '''Full-history multilevel Picard: one uniformly random time per sample, M^n / M^(n-l) samples.'''
     _variant = "fh"
 
-    def __init__(self, equation, seed=0, compat_crn=False, compat_f16=False, compat_rng=None):
+    def __init__(self, equation, seed=0, compat_crn=False, compat_f16=False, compat_rng=None, reference_mode=False):
+        """reference_mode=True: the reference's random stream (every draw from the one key of MLP_full_history.py:92-93) and its
+        solver-level float16 casts, in one switch."""
         self.equation = equation
         self.sigma = equation.sigma
         self.mu = equation.mu
@@ -16,7 +18,8 @@ class MLP_full_history:
         self.n_input = equation.n_input
         self.n_output = equation.n_output
         self.evaluation_counter = 0
-        self._engine = PicardEngine(equation, self._variant, gp=None, seed=seed, compat_crn=compat_crn, compat_f16=compat_f16, compat_rng=compat_rng)
+        self._engine = PicardEngine(equation, self._variant, gp=None, seed=seed, compat_crn=compat_crn, compat_f16=compat_f16, compat_rng=compat_rng,
+                                    reference_mode=reference_mode)
 
     def f(self, x_t, u, z):
         return self.equation.f(x_t, u, z)

@@ -7,7 +7,9 @@ class ScaSML:
     '''Multilevel Picard Iteration calibrated GP for high dimensional semilinear PDE'''
     _variant = "quad"
 
-    def __init__(self, equation, GP, seed=0, compat_crn=False, compat_f16=False, compat_rng=None):
+    def __init__(self, equation, GP, seed=0, compat_crn=False, compat_f16=False, compat_rng=None, reference_mode=False):
+        """reference_mode=True: the reference's random stream under its key schedule (compat_rng="jax") and its solver-level float16
+        casts (compat_f16) in one switch; with the default GP (compat="reference") that is the reference's ScaSML."""
         self.equation = equation
         self.sigma = equation.sigma
         self.mu = equation.mu
@@ -19,7 +21,8 @@ class ScaSML:
         self.GP = GP
         self.evaluation_counter = 0
         self.key = seed
-        self._engine = PicardEngine(equation, self._variant, gp=GP, seed=seed, compat_crn=compat_crn, compat_f16=compat_f16, compat_rng=compat_rng)
+        self._engine = PicardEngine(equation, self._variant, gp=GP, seed=seed, compat_crn=compat_crn, compat_f16=compat_f16, compat_rng=compat_rng,
+                                    reference_mode=reference_mode)
 
     def __setattr__(self, name, value):
         object.__setattr__(self, name, value)

@@ -11,15 +11,20 @@ POINT_BUFFER_BYTES = 24 << 30
 
 
 def _as_device(x_t, torch):
-    """-> (float32 contiguous CUDA tensor, was_numpy)."""
+    """-> (float32 contiguous CUDA tensor, was_numpy, largest |coordinate| or None).  The bound of a host array is taken on the host
+    before the upload; a device tensor's is the caller's business (PicardEngine._root_bound caches it per tensor version)."""
     if isinstance(x_t, torch.Tensor):
-        return x_t.to(device="cuda", dtype=torch.float32).contiguous(), False
+        return x_t.to(device="cuda", dtype=torch.float32).contiguous(), False, None
     arr = np.ascontiguousarray(np.asarray(x_t), dtype=np.float32)
-    return torch.from_numpy(arr).cuda(), True
+    return torch.from_numpy(arr).cuda(), True, (float(np.abs(arr).max()) if arr.size else 0.0)
 
 
 class PicardEngine:
-    def __init__(self, equation, variant, gp=None, seed=0, compat_crn=False, compat_f16=False, compat_rng=None):
+    def __init__(self, equation, variant, gp=None, seed=0, compat_crn=False, compat_f16=False, compat_rng=None, reference_mode=False):
+        if reference_mode:
+            # ONE switch for "what the reference's solver objects compute": its random stream under its key schedule and its solver-level
+            # float16 casts (the surrogate's half of it is GP(compat="reference"), the default)
+            compat_rng, compat_f16 = "jax", True
         if getattr(equation, "eq_id", None) is None:
             raise NotImplementedError("no HIP kernels for equation %s (eq_id unset)" % type(equation).__name__)
         self.equation = equation
@@ -31,7 +36,7 @@ class PicardEngine:
         # the reference's solver-level float16 casts (g, f, every uz_solve return): SCASML_RNG_COMPAT_F16 in include/scasml_hip.h
         self.compat_f16 = bool(compat_f16)
         # compat_rng="jax": the reference's own normals -- jax.random.normal(float16) under its key schedule (SCASML_RNG_JAX_STREAM in
-        # include/scasml_hip.h; quadrature solvers, n <= 3).  The state below is the solver's ``self.key`` of solvers/MLP.py:25, 220: it
+        # include/scasml_hip.h; unsharded solves).  The state below is the solver's ``self.key`` of solvers/MLP.py:25, 220: it
         # starts at PRNGKey(0) and every uz_solve advances it by the sub-keys that call consumes.
         if compat_rng not in (None, "jax"):
             raise ValueError("compat_rng must be None or 'jax'")
@@ -45,10 +50,11 @@ class PicardEngine:
         self._kinds = {}
         self._owners = {}
         self._work = {}               # point / GP-value buffers, kept across calls (4.9 GB at the headline shape)
+        self._bound_cache = None      # (data_ptr, numel, version) -> largest |coordinate| of a device tensor of roots
 
     def __getstate__(self):               # deep-copyable (tests/ComputingBudget.py:138): drop caches and events
         st = dict(self.__dict__)
-        st["_plans"], st["_events"], st["_kinds"], st["_owners"], st["_work"] = {}, [], {}, {}, {}
+        st["_plans"], st["_events"], st["_kinds"], st["_owners"], st["_work"], st["_bound_cache"] = {}, [], {}, {}, {}, None
         return st
 
     def _timed(self, name, fn):
@@ -130,7 +136,7 @@ class PicardEngine:
         """-> (uz (B, 1+d), u_hat (B,) or None) as torch CUDA tensors, plus was_numpy."""
         torch = _lib.require_gpu()
         lib = _lib.load()
-        x, was_numpy = _as_device(x_t, torch)
+        x, was_numpy, x_max = _as_device(x_t, torch)
         d = self.equation.n_input - 1
         if x.dim() != 2 or x.shape[1] != d + 1:
             raise ValueError("x_t must have shape (batch, %d), got %s" % (d + 1, tuple(x.shape)))
@@ -142,11 +148,13 @@ class PicardEngine:
                                    % (float(self.gp.T), float(self.equation.T)))
         flags = (_lib.RNG_COMPAT_CRN if self.compat_crn else 0) | (_lib.RNG_COMPAT_F16 if self.compat_f16 else 0)
         owner = self.unit_owners(n, par, world)[1].data_ptr() if world > 1 and n > 0 else None
-        jax_keys = None
+        jax_keys, jax_next = None, None
         if self.compat_rng == "jax" and n > 0:
             if world != 1:
                 raise NotImplementedError("compat_rng='jax' with Monte-Carlo sample sharding")
-            keys = self._jax_keys(plan)
+            if n > _lib.MAX_LEVEL:             # refuse before the key words are computed: a refused solve must not move the solver's key
+                raise _lib.ScasmlError("picard_tree: level n=%d outside 1..%d" % (n, _lib.MAX_LEVEL))
+            keys, jax_next = self._jax_keys(plan)
             jax_keys = keys.data_ptr()
             flags |= _lib.RNG_JAX_STREAM
         rng = _lib.Rng(self.seed, self.calls if stream_id is None else stream_id, root0, rank, world, flags, 0, owner, jax_keys)
@@ -157,6 +165,7 @@ class PicardEngine:
         if self.gp is None:
             _lib.check(self._timed("picard_mlp", lambda: lib.scasml_picard_tree(
                 C.byref(prob), C.byref(plan), _lib.MODE_MLP, _lib.ptr(x), B, 0, rng, None, None, _lib.ptr(out), None, s)), "picard_tree")
+            self._jax_commit(jax_next, stream_id)
             return out, None, was_numpy
         uhat = torch.empty((B,), dtype=torch.float32, device="cuda")
         ppr = int(lib.scasml_points_per_root(C.byref(plan)))
@@ -168,8 +177,9 @@ class PicardEngine:
         pts, vals = self._buffers(stride * ppr, kp)   # rows of un-owned units and padding rows are never written: their (finite,
         # stale) content is evaluated or skipped by the GP kernel and never read back by ACCUMULATE
         kinds = self.site_kinds(n, par, rank, world) if n > 0 else None
-        # one reduction over the roots per solve: roots outside the training cube widen the bound instead of silently breaking it
-        x_bound = self.path_bound(float(x.abs().max()) if B else None, plan)
+        # roots outside the training cube widen the bound instead of silently breaking it (host arrays: measured before the upload;
+        # device tensors: one reduction per tensor version, not per solve)
+        x_bound = self.path_bound(self._root_bound(x, x_max) if B else None, plan)
         for b0 in range(0, B, chunk):
             nb = min(chunk, B - b0)
             rng_c = _lib.Rng(rng.seed, rng.stream, root0 + b0, rank, world, flags, 0, owner, jax_keys)
@@ -186,17 +196,34 @@ class PicardEngine:
             else:                          # n == 0: zeros (ScaSML.py:217-219); u_hat still needed by u_solve
                 out[b0:b0 + nb].zero_()
                 uhat[b0:b0 + nb] = self.gp._predict_device(xc)[:, 0]
+        self._jax_commit(jax_next, stream_id)
         return out, uhat, was_numpy
 
+    def _root_bound(self, x, x_max):
+        """Largest |coordinate| of the roots: given for host arrays; for a device tensor read once per (storage, version)."""
+        if x_max is not None:
+            return x_max
+        key = (x.data_ptr(), x.numel(), x._version)
+        if self._bound_cache is None or self._bound_cache[0] != key:
+            self._bound_cache = (key, float(x.abs().max()))
+        return self._bound_cache[1]
+
     def _jax_keys(self, plan):
-        """Device words [terminal key | the sub-keys this solve draws from the solver's stateful key]; advances that key."""
+        """Device words [terminal key | the sub-keys this solve draws from the solver's stateful key] and the key state AFTER the solve,
+        which the caller commits (_jax_commit) once every launch of the solve has been accepted."""
         from .. import threefry
         torch = _lib.require_gpu()
         q = [[int(plan.term[level][l].q) for l in range(level)] for level in range(plan.n + 1)]
-        words, self.jax_key = threefry.solver_key_words(q, plan.n, self.jax_key, quadrature=self.variant == "quad")
-        self.jax_splits += len(words) - 1
+        words, key_after = threefry.solver_key_words(q, plan.n, self.jax_key, quadrature=self.variant == "quad")
         self._work["jax_keys"] = torch.from_numpy(words.view(np.int32).reshape(-1).copy()).cuda()
-        return self._work["jax_keys"]
+        return self._work["jax_keys"], (key_after, len(words) - 1)
+
+    def _jax_commit(self, jax_next, stream_id):
+        """Advance the solver's key (``self.key`` of solvers/MLP.py:220) by what the finished solve drew.  A solve that raised has not moved
+        it; a replay of an earlier call (explicit ``stream_id``) reads the current key and does not move it either -- as it leaves the Philox
+        call counter alone."""
+        if jax_next is not None and stream_id is None:
+            self.jax_key, self.jax_splits = jax_next[0], self.jax_splits + jax_next[1]
 
     def _buffers(self, rows, kp):
         """The site-major point buffer and its GP values: owned by the engine and reused by later calls of the same
@@ -211,9 +238,12 @@ class PicardEngine:
         return self._work["pts"][:rows], self._work["vals"][:rows]
 
     def finalize_partials(self, summed):
-        """Clip all-reduced partial sums of a sample-sharded solve (MLP.py:272-274)."""
+        """Clip all-reduced partial sums of a sample-sharded solve and, under compat_f16, apply the root call's ``.astype(float16)``
+        (MLP.py:272-274, ScaSML.py:282-284, MLP_full_history.py:178-180; ScaSML_full_history.py:196-199 does not cast): the kernel leaves
+        both to the reduction's end when the root call is sharded."""
         lib = _lib.load()
-        _lib.check(lib.scasml_clip(_lib.ptr(summed), summed.numel(), self.problem().clip, _lib.stream_ptr()), "clip")
+        round16 = 1 if (self.compat_f16 and not (self.variant == "fh" and self.gp is not None)) else 0
+        _lib.check(lib.scasml_clip_round16(_lib.ptr(summed), summed.numel(), self.problem().clip, round16, _lib.stream_ptr()), "clip")
         return summed
 
     def evaluation_increment(self, n, par):

@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_struct_layouts_and_version(lib):
-    assert lib.scasml_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.scasml_abi_version() == _lib.ABI_VERSION == 5
     for which, st in enumerate((_lib.Problem, _lib.Rng, _lib.Term, _lib.Plan, _lib.GpModel)):
         assert lib.scasml_sizeof(which) == C.sizeof(st)
     assert C.sizeof(_lib.Plan) < 3900          # travels by value in the kernarg segment (4 KiB)

@@ -146,6 +146,82 @@ def test_what_a_site_consumes_does_not_depend_on_the_form_its_workgroup_ran():
             assert np.array_equal(part32[sl, 1], full32[sl, 1])
 
 
+@pytest.mark.parametrize("d,idx,nd,nb", [CASES[0], CASES[2], CASES[3]])
+def test_geometry_mode_factored_sums_in_every_site_form(d, idx, nd, nb):
+    """compat="reference-geometry" (round16 bit 0 off): the factored epilogue, per site form.  Every form's outputs against the float64
+    statement without entry rounding, and what a site consumes is the same number in whichever form its workgroup ran -- to float32
+    accuracy of the sums (the forms order their additions differently), not bitwise as in the as-coded mode."""
+    gp, ogp, _ = _setup(d, idx, nd, nb, seed=21, round16=False)
+    rows = 128
+    kinds = [0, 1, 3, 4, 0, 4, 1]
+    X = _test_points(d, rows * len(kinds), seed=22, spread=0.7)
+    mag = _magnitudes(ogp, X)
+    dt, div, lp = ogp.pde_parts(X)
+    u = ogp.predict(X)[:, 0]
+    for bits in (0, 4):                                   # two point planes / one
+        # one plane: the point enters x.y rounded to float16: |delta Lambda| <= 1.45 a 2^-12 sum_k |x_k y_k| per pair, relative in kappa
+        a = 1.0 / float(gp.sigma) ** 2
+        ycol = np.concatenate([ogp.x_t_domain, ogp.x_t_boundary])
+        loose = 0.0 if bits == 0 else 1.0 * a * 2.0 ** -12 * float((np.abs(X).astype(np.float64) @ np.abs(ycol).T).max())
+        tol = 2e-5 + loose
+        part, _ = _raw(gp, X, round16=bits, kinds=kinds, rows_per_site=rows)
+        full, lap = _raw(gp, X, round16=bits)
+        assert np.all(np.abs(full[:, 0] - u) <= tol * mag["I"])
+        assert np.all(np.abs(full[:, 3] - dt[:, 0]) <= tol * mag["dt"])
+        assert np.all(np.abs(full[:, 1] - div[:, 0]) <= tol * mag["div"])
+        assert np.all(np.abs(lap - lp[:, 0]) <= tol * mag["lap"])
+        for s_, k in enumerate(kinds):
+            sl = slice(s_ * rows, (s_ + 1) * rows)
+            assert np.all(np.abs(part[sl, 0] - u[sl]) <= tol * mag["I"][sl]), (bits, k)
+            if k in (0, 4):
+                assert np.all(np.abs(part[sl, 1] - div[sl, 0]) <= tol * mag["div"][sl]), (bits, k)
+            if k == 0:
+                assert np.all(np.abs(part[sl, 3] - dt[sl, 0]) <= tol * mag["dt"][sl])
+    # one plane is an approximation of the stated size, not a different function: against two planes
+    two, _ = _raw(gp, X, round16=0)
+    one, _ = _raw(gp, X, round16=4)
+    assert np.all(np.abs(one[:, 0] - two[:, 0]) <= loose * mag["I"] + 1e-6)
+    assert np.abs(one[:, 0] - two[:, 0]).max() > 0.0
+    # the as-coded form refuses the one-plane option
+    from scasml_gp_amd import _lib
+    with pytest.raises(_lib.ScasmlError):
+        _raw(gp, X[:32], round16=5)
+
+
+def test_reference_geometry_surrogate_follows_the_reference_surrogate():
+    """GP(compat="reference-geometry"): the fit of compat="reference" bit for bit; predictions and PDE residual within the rounding noise the
+    as-coded evaluation carries (a float16 ulp of single terms), and a ScaSML solve on it within 1e-4 in relative L2 of the as-coded one."""
+    from oracle.equation import sample_points
+    from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
+    from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
+    from scasml_gp_amd.solvers.ScaSML import ScaSML
+    d = 40
+    eq = Grad_Dependent_Nonlinear(d + 1)
+    state = np.random.get_state()
+    np.random.seed(7)
+    dom, bdy = eq.generate_data(400, 80)
+    xt = np.concatenate(eq.generate_test_data(500, 100))
+    np.random.set_state(state)
+    ref = GP_Grad_Dependent_Nonlinear(eq)
+    geo = GP_Grad_Dependent_Nonlinear(eq, compat="reference-geometry")
+    assert geo.compat == "reference" and geo.eval_geometry and geo.eval_round16 == 6 and ref.eval_round16 == 3
+    ref.GPsolver(dom, bdy)
+    geo.GPsolver(dom, bdy)
+    assert np.array_equal(ref.right_vector, geo.right_vector)
+    exact = np.asarray(eq.exact_solution(xt), dtype=np.float64)
+    rel = lambda v: float(np.linalg.norm(np.asarray(v, dtype=np.float64) - exact) / np.linalg.norm(exact))
+    pr, pg = ref.predict(xt).astype(np.float64), geo.predict(xt).astype(np.float64)
+    assert np.abs(pr - pg).max() <= 8 * 2.0 ** -11 and abs(rel(pr) - rel(pg)) <= 1e-4
+    er, eg = ref.compute_PDE_loss(xt).astype(np.float64), geo.compute_PDE_loss(xt).astype(np.float64)
+    assert np.abs(er - eg).max() <= 0.02 * np.abs(er).max()
+    sr = ScaSML(eq, ref, seed=3).u_solve(2, 2, xt)
+    sg = ScaSML(eq, geo, seed=3).u_solve(2, 2, xt)
+    assert abs(rel(sr) - rel(sg)) <= 1e-4, (rel(sr), rel(sg))
+    # a state saved from one loads into the other: the fit is the same object
+    geo2 = GP_Grad_Dependent_Nonlinear(eq, compat="reference-geometry").load_state_dict(ref.state_dict())
+    assert np.array_equal(geo2.predict(xt), geo.predict(xt))
+
+
 @pytest.mark.parametrize("d,idx,nd,nb", [(20, [11, 17, 12, 6, 4], 80, 20), (7, [5, 0, 3, 6, 2], 40, 9)])
 def test_compat_gradient_is_the_gradient_of_the_as_coded_surrogate(d, idx, nd, nb):
     gp, ogp, _ = _setup(d, idx, nd, nb, seed=11)
