@@ -371,6 +371,10 @@ int scasml_gp_eval_compat_sites(int32_t d, float a, float sigma_eq, float mu_eq,
 #define SCASML_DIST_BLOCK 256
 int scasml_gp_gram_rows(int32_t d, double a, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy,
                         int64_t row0, int32_t nrows, int64_t ncols, double *out, int64_t ld, void *stream);
+/* The same rows of the as-coded Gram (scasml_gp_gram_compat; models/GP.py:182-258 with the shifted Hutchinson blocks and float16 entries):
+ * bit-identical to the rows of the full matrix, so a block-row distributed fit builds the reference's estimator too. */
+int scasml_gp_gram_compat_rows(int32_t d, double a, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy, const int32_t *idx_h,
+                               int32_t round16, int64_t row0, int32_t nrows, int64_t ncols, double *out, int64_t ld, void *stream);
 int scasml_gemm_nt_sub(double *C, int64_t ldc, int64_t rows, int64_t cols, const double *A, int64_t lda, const double *B,
                        int64_t ldb, int64_t K, int64_t tri_row0, int64_t tri_stride, int64_t tri_col0, void *stream);
 int scasml_trsm_right_lt(const double *L, int64_t ldl, int64_t nb, double *X, int64_t ldx, int64_t rows, void *stream);

@@ -34,8 +34,11 @@ the shifted kernels in tests/test_oracle_gp_compat.py):
     lap_x div_y kappa      = -d/5 sum_i (2 a^2 r_i + a^2 S - a^3 S r_i^2) kappa   [xs]
     lap_x lap_y kappa      = (d/5)^2 ((sum_i g_i)^2 + sum_i (2 a^2 - 4 a^3 r_i^2)) kappa   [al, r_i = r_{i+1}]
 and the Laplacian-free blocks are those of oracle/gp.py.  Arithmetic inside an entry is float64
-with ONE rounding to float16 at the end (the reference evaluates the whole expression in float16;
-XLA's float16 evaluation order is not pinned, so intermediate roundings are not modelled).
+with ONE rounding to float16 at the end.  That is what JAX computes on float64 rows (every tree point below a solver's root call).
+On float16 rows -- the collocation points, the harness's test points -- the reference's kernels are float16 arithmetic
+throughout (``self.sigma`` is weakly typed), and its first-order blocks are reverse-mode autodiff THROUGH that arithmetic;
+``f16_graph=True`` follows that op sequence for kappa and the four first-order blocks (``_f16_first_order``; models/GP.py:41-85).
+The second-order and Hutchinson blocks (autodiff of autodiff) keep one rounding per entry.
 """
 import numpy as np
 
@@ -62,8 +65,11 @@ class OracleGPCompat(OracleGP):
 
     MC = 5                                            # models/GP.py:30
 
-    def __init__(self, eq, idx, round16=True, round_factor=True, round_out=None):
+    def __init__(self, eq, idx, round16=True, round_factor=True, round_out=None, f16_graph=False):
         super().__init__(eq)
+        # f16_graph: on float16 rows evaluate kappa and the first-order blocks through the reference's float16 op sequence (module docstring).
+        # Off by default: the product rounds each entry once, and HIP <-> oracle parity is stated in that arithmetic.
+        self.f16_graph = bool(f16_graph) and bool(round16)
         self.round_factor = bool(round_factor) and bool(round16)
         # predict / compute_PDE_loss / compute_gradient return .astype(float16) (models/GP.py:671, 687, 769)
         self.round_out = bool(round16) if round_out is None else bool(round_out)
@@ -95,9 +101,46 @@ class OracleGPCompat(OracleGP):
         ri = X[:, cols][:, None, :] - Y[:, cols][None, :, :]
         return kap, S, rD, ri
 
+    # ---------------------------------------------------------------- float16 op sequence of kappa and its first derivatives
+    def _f16_first_order(self, opx, opy, X, Y):
+        """kappa = exp(-sum((x - y)**2) / (2 sigma**2)).astype(float16) (models/GP.py:41-43) on float16 rows: every operation rounds to
+        float16 (jnp.sum accumulates in float32 and rounds once; exp and the division are float32 operations on float16 operands,
+        rounded); 2 sigma**2 is a weakly typed scalar, i.e. float16(d / 8).  grad(kappa) (:55-57, 65-67) is reverse mode through the same
+        graph: cotangent 1 -> exp: kappa16 -> division: t1 = float16(kappa16 / c16) -> negation -> broadcast over the sum -> square:
+        float16(-t1 * (2 r_k)) -> the subtraction: +/-.  dt_* picks component d (:59-63, 69-73); div_* is the float16 sum (float32
+        accumulation) of the d spatial components, each already rounded (:75-85)."""
+        F16, F32 = np.float16, np.float32
+        d = self.d
+        X16, Y16 = np.asarray(X).astype(F16), np.asarray(Y).astype(F16)
+        c16 = F16(2.0 * float(self.s2))
+        out = np.empty((X16.shape[0], Y16.shape[0]))
+        sign = 1.0 if opx != "I" else -1.0                 # g below is d/dx; d/dy = -d/dx exactly (a negation of float16 values)
+        op = opx if opx != "I" else opy
+        for i0 in range(0, X16.shape[0], 128):
+            r = X16[i0:i0 + 128, None, :] - Y16[None, :, :]                       # float16 subtraction
+            sq = r * r                                                             # float16 product
+            S = sq.astype(F32).sum(axis=2, dtype=F32).astype(F16)
+            q = ((-S).astype(F32) / F32(c16)).astype(F16)
+            kap = np.exp(q.astype(np.float64)).astype(F32).astype(F16)
+            if op == "I":
+                out[i0:i0 + 128] = kap.astype(np.float64)
+                continue
+            t1 = (kap.astype(F32) / F32(c16)).astype(F16)
+            if op == "dt":
+                g = ((-t1).astype(F32) * (F16(2.0) * r[:, :, d]).astype(F32)).astype(F16)
+            else:                                          # "div": float16 sum of the d rounded spatial components
+                gk = ((-t1)[:, :, None].astype(F32) * (F16(2.0) * r[:, :, :d]).astype(F32)).astype(F16)
+                g = gk.astype(F32).sum(axis=2, dtype=F32).astype(F16)
+            out[i0:i0 + 128] = sign * g.astype(np.float64)
+        return out
+
     def block(self, opx, opy, X, Y):
         a, d = self.a, self.d
         key = (opx, opy)
+        if self.f16_graph and key in (("I", "I"), ("dt", "I"), ("I", "dt"), ("div", "I"), ("I", "div")):
+            Xa, Ya = np.asarray(X, dtype=np.float64), np.asarray(Y, dtype=np.float64)
+            if np.array_equal(Xa, f16(Xa)) and np.array_equal(Ya, f16(Ya)):
+                return self._f16_first_order(opx, opy, Xa, Ya)
         if "lap" not in key:
             return self._r(super().block(opx, opy, X, Y))
         h = d / float(self.MC)

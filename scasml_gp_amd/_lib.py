@@ -99,6 +99,8 @@ SIGNATURES = {
                                               C.c_int32, C.c_float, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "scasml_gp_gram_rows": (C.c_int, [C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int64,
                                       C.c_void_p, C.c_int64, C.c_void_p]),
+    "scasml_gp_gram_compat_rows": (C.c_int, [C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64,
+                                             C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "scasml_gemm_nt_sub": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
                                      C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
     "scasml_gp_newton_jv": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),

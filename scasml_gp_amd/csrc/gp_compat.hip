@@ -150,6 +150,29 @@ __global__ void gp_gram_compat_kernel(int d, double a, const float *x_dom, int n
     }
 }
 
+// Rows of the same matrix for the block-row distributed fit (scasml_gp_gram_compat_rows; BASELINE configs[4]): the feature rows of ONE
+// operator `ox` at the points [i_lo, i_lo + n_i) against every collocation point j, columns < ncols only (the distributed factor stores
+// the lower triangle).  Same per-pair arithmetic as gp_gram_compat_kernel (pair_geometry + compat_blocks): the rows are bit-identical.
+__global__ void gp_gram_compat_rows_kernel(int d, double a, const float *x_dom, int n_dom, const float *x_bdy, int n_bdy, CompatIdx ix, int r16,
+                                           int ox, int i_lo, int n_i, int64_t ncols, double *out, int64_t ld) {
+    const int N = n_dom + n_bdy;
+    const int ii = blockIdx.y * blockDim.y + threadIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ii >= n_i || j >= N || (int64_t)j >= ncols) return;       // column j of the u block is this pair's smallest column
+    const int i = i_lo + ii;
+    const float *xi = i < n_dom ? x_dom + (int64_t)i * (d + 1) : x_bdy + (int64_t)(i - n_dom) * (d + 1);
+    const float *yj = j < n_dom ? x_dom + (int64_t)j * (d + 1) : x_bdy + (int64_t)(j - n_dom) * (d + 1);
+    PairGeom g;
+    pair_geometry(d, a, ix, [&](int k) { return (double)xi[k]; }, [&](int k) { return (double)yj[k]; }, g);
+    double P[4][4];
+    compat_blocks(d, a, g, r16, P);
+    const int nops_j = j < n_dom ? 4 : 1;
+    for (int oy = 0; oy < nops_j; ++oy) {
+        const int64_t col = oy == 0 ? j : (int64_t)N + (int64_t)(oy - 1) * n_dom + j;
+        if (col < ncols) out[(int64_t)ii * ld + col] = P[ox][oy];
+    }
+}
+
 // diagonal of K + nugget I rounded to float16 (kernel_phi_phi_perturb.astype(float16), models/GP.py:268): the entries of K are
 // float16 values already, so only the diagonal moves
 __global__ void round16_diag_kernel(double *A, int64_t M, int64_t lda, double nugget) {
@@ -345,6 +368,43 @@ extern "C" int scasml_gp_gram_compat(int32_t d, double a, const float *x_dom, in
     hipLaunchKernelGGL(gp_gram_compat_kernel, dim3((N + 15) / 16, (N + 15) / 16), dim3(16, 16), 0, (hipStream_t)stream, d, a,
                        x_dom, n_dom, x_bdy, n_bdy, ix, round16, K);
     return check_launch("gp_gram_compat launch");
+}
+
+extern "C" int scasml_gp_gram_compat_rows(int32_t d, double a, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy,
+                                          const int32_t *idx_h, int32_t round16, int64_t row0, int32_t nrows, int64_t ncols, double *out, int64_t ld,
+                                          void *stream) {
+    if (!x_dom || !out || (n_bdy > 0 && !x_bdy)) return fail(SCASML_ERR_ARG, "gp_gram_compat_rows: null argument");
+    const int64_t M = 4 * (int64_t)n_dom + n_bdy;
+    if (d < kMC || n_dom < 1 || n_bdy < 0 || row0 < 0 || nrows < 0 || row0 + nrows > M || ncols < 0 || ncols > M || ld < ncols)
+        return fail(SCASML_ERR_ARG, "gp_gram_compat_rows: bad sizes (d >= %d needed)", kMC);
+    CompatIdx ix;
+    if (int rc = check_idx(idx_h, d, ix, "gp_gram_compat_rows")) return rc;
+    if (nrows == 0 || ncols == 0) return 0;
+    const int N = n_dom + n_bdy;
+    int64_t r = row0;
+    const int64_t r_end = row0 + nrows;
+    while (r < r_end) {                         // one launch per operator segment of the row range (as scasml_gp_gram_rows)
+        int ox, i_lo;
+        int64_t seg_end;
+        if (r < N) {
+            ox = 0;
+            i_lo = (int)r;
+            seg_end = N;
+        } else {
+            const int64_t q = r - N;
+            ox = 1 + (int)(q / n_dom);
+            i_lo = (int)(q % n_dom);
+            seg_end = (int64_t)N + (int64_t)ox * n_dom;
+        }
+        const int64_t stop = seg_end < r_end ? seg_end : r_end;
+        const int n_i = (int)(stop - r);
+        const unsigned gy = (unsigned)((n_i + 15) / 16);
+        if (gy > 65535) return fail(SCASML_ERR_UNSUPPORTED, "gp_gram_compat_rows: too many rows per call");
+        hipLaunchKernelGGL(gp_gram_compat_rows_kernel, dim3((N + 15) / 16, gy), dim3(16, 16), 0, (hipStream_t)stream, d, a, x_dom, n_dom, x_bdy, n_bdy,
+                           ix, round16, ox, i_lo, n_i, ncols, out + (r - row0) * ld, ld);
+        r = stop;
+    }
+    return check_launch("gp_gram_compat_rows launch");
 }
 
 extern "C" int scasml_round16_diag(double *A, int64_t M, int64_t lda, double nugget, void *stream) {

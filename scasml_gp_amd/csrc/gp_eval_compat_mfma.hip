@@ -255,7 +255,9 @@ __device__ __forceinline__ void compat_epilogue_fact(const float *rows_lds, cons
     for (int r = 0; r < 16; ++r) {
         const int cur = r & 1, nxt = cur ^ 1;
         if (r + 1 < 16) fetch(r + 1, q[nxt]);
+        #ifndef SCASML_FACT_NOSCHED
         __builtin_amdgcn_sched_barrier(0);
+#endif
         const float kap = __builtin_amdgcn_exp2f(lam[r]);
         if constexpr (GEOM == 0) {
             const float vsy = q[cur][0].x, vty = q[cur][0].y, c0 = q[cur][0].z;
@@ -655,7 +657,18 @@ static int launch_compat(const GpCompatArgs &g, hipStream_t s) {
     constexpr int REGS = 4 * PLANES * KS + 90;
     constexpr size_t lds_bytes = SCASML_COMPAT_NSLOT * (size_t)(KS * 256 + kStageTail) * sizeof(float);
     constexpr int BPC_REGS = REGS <= 128 ? 4 : (REGS <= 168 ? 3 : 2), BPC_LDS = (int)(160 * 1024 / lds_bytes);
+#if defined(SCASML_FACT_BPC) || defined(SCASML_R16_BPC)      // development: occupancy A/B
+#ifndef SCASML_FACT_BPC
+#define SCASML_FACT_BPC BPC_REGS
+#endif
+#ifndef SCASML_R16_BPC
+#define SCASML_R16_BPC BPC_REGS
+#endif
+    constexpr int BPC_DEV = R16 ? SCASML_R16_BPC : SCASML_FACT_BPC;
+    constexpr int BPC = BPC_DEV < BPC_LDS ? BPC_DEV : BPC_LDS;
+#else
     constexpr int BPC = BPC_REGS < BPC_LDS ? BPC_REGS : BPC_LDS;
+#endif
     const int64_t waves = (g.n_inf + 31) / 32;
     const int64_t blocks = (waves + 3) / 4;
     if (blocks > 0x7FFFFFFF) return fail(SCASML_ERR_UNSUPPORTED, "gp_eval_compat_sites: too many points");

@@ -100,8 +100,13 @@ def owned_blocks(nblk, rank, world):
 class DistCholesky:
     """K(phi, phi) + nugget I, block-row distributed: build(), factor(), solve(b)."""
 
-    def __init__(self, d, a, x_dom, x_bdy, nugget, comm=None):
+    def __init__(self, d, a, x_dom, x_bdy, nugget, comm=None, compat_idx=None, round_diag=False):
+        """compat_idx: the five Hutchinson indices -> the Gram AS CODED by the reference (shifted blocks, float16 entries:
+        scasml_gp_gram_compat_rows); round_diag: the diagonal of K + nugget I rounded to float16 as well, i.e. the matrix
+        kernel_phi_phi_perturb.astype(float16) of models/GP.py:268 that the right_vector solve of :599 uses."""
         torch = _lib.require_gpu()
+        self.compat_idx = None if compat_idx is None else np.ascontiguousarray(np.asarray(compat_idx, dtype=np.int32))
+        self.round_diag = bool(round_diag)
         self.lib = _lib.load()
         self.comm = comm or Comm()
         self.d, self.a, self.nugget = int(d), float(a), float(nugget)
@@ -138,11 +143,19 @@ class DistCholesky:
             row0 = i * BLK
             nrows = max(0, min(BLK, self.M - row0))
             ncols = min((i + 1) * BLK, self.M)
-            _lib.check(lib.scasml_gp_gram_rows(self.d, self.a, _lib.ptr(self.xd), self.n_dom, _lib.ptr(self.xb), self.n_bdy, row0, nrows,
-                                               ncols, self._ptr(self.R, slot * BLK, 0, self.Mp), self.Mp, s), "gp_gram_rows")
+            if self.compat_idx is not None:
+                _lib.check(lib.scasml_gp_gram_compat_rows(self.d, self.a, _lib.ptr(self.xd), self.n_dom, _lib.ptr(self.xb), self.n_bdy,
+                                                          self.compat_idx.ctypes.data_as(C.c_void_p), 1, row0, nrows, ncols,
+                                                          self._ptr(self.R, slot * BLK, 0, self.Mp), self.Mp, s), "gp_gram_compat_rows")
+            else:
+                _lib.check(lib.scasml_gp_gram_rows(self.d, self.a, _lib.ptr(self.xd), self.n_dom, _lib.ptr(self.xb), self.n_bdy, row0, nrows,
+                                                   ncols, self._ptr(self.R, slot * BLK, 0, self.Mp), self.Mp, s), "gp_gram_rows")
             blk = self.R[slot * BLK:(slot + 1) * BLK, row0:row0 + BLK]
             dg = blk.diagonal()
-            dg[:nrows] += self.nugget                     # K + nugget I (models/GP.py:260-267)
+            if self.round_diag and nrows > 0:             # float16(K + nugget I): the entries are float16 already, the diagonal moves (:268)
+                _lib.check(lib.scasml_round16_diag(self._ptr(self.R, slot * BLK, row0, self.Mp), nrows, self.Mp, self.nugget, s), "round16_diag")
+            elif not self.round_diag:
+                dg[:nrows] += self.nugget                 # K + nugget I (models/GP.py:260-267)
             dg[nrows:] = 1.0                              # identity padding beyond M
         return self
 
@@ -303,8 +316,10 @@ class DistributedGP:
     right_vector (replicated, M doubles) and can hand it to GP.load_right_vector for the (root-sharded) evaluation."""
 
     def __init__(self, gp, comm=None):
-        if getattr(gp, "compat", None) is not None:
-            raise NotImplementedError("the distributed fit builds the documented operators (scasml_gp_gram_rows): construct the GP with compat=None")
+        """gp.compat == "reference" (the default GP): the fit builds the Gram as coded by the reference (scasml_gp_gram_compat_rows), factors it
+        for the Newton iteration, then -- as models/GP.py:268, 599, 719 -- rounds z4 and the diagonal of K + nugget I to float16 and solves the
+        rounded matrix for right_vector with a second distributed factorisation: the estimator of every other configuration.
+        gp.compat is None: the documented operators (scasml_gp_gram_rows)."""
         self.gp = gp
         self.comm = comm or Comm()
         self.cg_iterations = []
@@ -315,7 +330,8 @@ class DistributedGP:
         lib, s = _lib.load(), _lib.stream_ptr()
         gp = self.gp
         eq_id, d, sig, mu = int(gp.equation.eq_id), int(gp.d), float(gp.equation.sigma()), float(gp.equation.mu())
-        ch = DistCholesky(d, 1.0 / float(gp.sigma) ** 2, x_t_domain, x_t_boundary, gp.nugget, self.comm).build().factor()
+        compat_idx = gp.laplacian_idx if getattr(gp, "compat", None) == "reference" else None
+        ch = DistCholesky(d, 1.0 / float(gp.sigma) ** 2, x_t_domain, x_t_boundary, gp.nugget, self.comm, compat_idx=compat_idx).build().factor()
         self.chol = ch
         N, Nb, M = ch.n_dom, ch.n_bdy, ch.M
         bdy_g = torch.as_tensor(np.asarray(gp.bdy_g(np.asarray(x_t_boundary)), dtype=np.float64), device="cuda").contiguous()
@@ -391,6 +407,17 @@ class DistributedGP:
         gp.grad_norms = self.grad_norms
         gp._sol = sol
         rv = Ab                                                         # right_vector = K_p^-1 z at the final sol (:593-600)
+        if compat_idx is not None:
+            # z4 = time_der_rep(sol).astype(float16) (:719); right_vector = solve(float16(K_p), z) (:268, 599): a second factorisation, of the
+            # matrix with the float16-rounded diagonal, in the memory of the first
+            _lib.check(lib.scasml_round16(C.c_void_p(b.data_ptr() + 8 * (2 * N + Nb)), N, s), "round16")
+            ch.R = None
+            ch.diag = [None] * ch.nblk
+            torch.cuda.empty_cache()
+            ch2 = DistCholesky(d, 1.0 / float(gp.sigma) ** 2, x_t_domain, x_t_boundary, gp.nugget, self.comm, compat_idx=compat_idx,
+                               round_diag=True).build().factor()
+            rv = ch2.solve(b)
+            self.chol = ch2
         gp.N_domain, gp.N_boundary, gp.phi_dim = N, Nb, M
         gp.load_right_vector(x_t_domain, x_t_boundary, rv.cpu().numpy())
         return gp

@@ -86,6 +86,32 @@ def test_gram_rows_tile_kernel_equals_the_rows_of_the_full_gram(row0, nrows, nco
     assert bool((out[:, ncols:] == -7.0).all())                     # nothing beyond the requested columns is touched
 
 
+@pytest.mark.parametrize("row0,nrows,ncols", [(0, 630, 630), (100, 300, 400), (170, 20, 190), (329, 257, 586), (480, 150, 37), (629, 1, 630)])
+def test_compat_gram_rows_equal_the_rows_of_the_as_coded_gram(row0, nrows, ncols):
+    """scasml_gp_gram_compat_rows against the same rows of scasml_gp_gram_compat (shifted Hutchinson blocks, float16 entries): bit-identical,
+    for ranges that start and end inside, and straddle, the operator blocks."""
+    import ctypes as C
+    import torch
+    from scasml_gp_amd import _lib
+    lib = _lib.load()
+    d, nd, nb = 20, 150, 30
+    eq, dom, bdy = _problem(d, nd, nb)
+    xd = torch.from_numpy(np.ascontiguousarray(dom, dtype=np.float32)).cuda()
+    xb = torch.from_numpy(np.ascontiguousarray(bdy, dtype=np.float32)).cuda()
+    M = 4 * nd + nb
+    a = 1.0 / (0.25 ** 2 * d)
+    idx = np.asarray([11, 17, 12, 6, 4], dtype=np.int32)
+    K = torch.empty((M, M), dtype=torch.float64, device="cuda")
+    _lib.check(lib.scasml_gp_gram_compat(d, a, _lib.ptr(xd), nd, _lib.ptr(xb), nb, idx.ctypes.data_as(C.c_void_p), 1, _lib.ptr(K), _lib.stream_ptr()), "gp_gram_compat")
+    ld = ncols + 5
+    out = torch.full((nrows, ld), -7.0, dtype=torch.float64, device="cuda")
+    _lib.check(lib.scasml_gp_gram_compat_rows(d, a, _lib.ptr(xd), nd, _lib.ptr(xb), nb, idx.ctypes.data_as(C.c_void_p), 1, row0, nrows, ncols,
+                                              _lib.ptr(out), ld, _lib.stream_ptr()), "gp_gram_compat_rows")
+    assert torch.equal(out[:, :ncols], K[row0:row0 + nrows, :ncols])
+    assert bool((out[:, ncols:] == -7.0).all())
+    assert bool((K.half().double() == K).all())                     # the entries are float16 values (models/GP.py:43, 55-179)
+
+
 def _worker(rank, world, port, case, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch
@@ -112,6 +138,20 @@ def _worker(rank, world, port, case, q):
             _lib.check(lib.scasml_trsm_lower(_lib.ptr(gp._L_pad), Mp32, _lib.ptr(ref), 1, 1, _lib.stream_ptr()), "trsm")
             err = float((x - ref[:ch.M, 0]).abs().max() / ref.abs().max())
             q.put((rank, rel, err, ch.memory_bytes(), ch.comm.bytes_moved))
+        elif case == "fit_compat":
+            d, nd, nb = 20, 1600, 601                                # M = 7001, 28 block rows over 2 ranks
+            eq, dom, bdy = _problem(d, nd, nb)
+            one = GP_Grad_Dependent_Nonlinear(eq)                     # the default: the reference's as-coded surrogate
+            one.GPsolver(dom, bdy, GN_steps=20)
+            gp = GP_Grad_Dependent_Nonlinear(eq)
+            fit = DistributedGP(gp, Comm())
+            fit.fit(dom, bdy, GN_steps=20)
+            assert gp.compat == "reference" and fit.chol.round_diag and fit.chol.compat_idx is not None
+            rv_err = float(np.abs(gp.right_vector - one.right_vector).max() / np.abs(one.right_vector).max())
+            X = np.concatenate(eq.generate_test_data(200, 40))
+            pred_err = float(np.abs(gp.predict(X).astype(np.float64) - one.predict(X).astype(np.float64)).max())
+            q.put((rank, rv_err, pred_err, len(gp.loss_history) - len(one.loss_history),
+                   float(abs(gp.loss_history[-1] - one.loss_history[-1]) / one.loss_history[-1]), max(fit.cg_iterations)))
         elif case == "indefinite":
             d, nd, nb = 20, 150, 30                                  # M = 630, 3 block rows over 2 ranks: the LAST one belongs to rank 0
             eq, dom, bdy = _problem(d, nd, nb)
@@ -173,6 +213,16 @@ def test_three_ranks_newton_cg_fit_matches_the_single_gpu_fit():
     for rank, rv_err, pred_err, dsteps, dloss, cg_max in res:
         assert rv_err <= 1e-6 and pred_err <= 2e-5 and dsteps == 0 and dloss <= 1e-9, res
         assert cg_max <= 150, res
+
+
+def test_two_ranks_fit_the_as_coded_surrogate_to_the_single_gpu_fit():
+    """configs[4] must run the estimator every other configuration runs.  Two ranks build the Gram AS CODED by the reference
+    block row by block row (float16 entries, shifted Hutchinson blocks), run the matrix-free Newton on its factor, then round z4 and the diagonal of
+    K + nugget I to float16 and solve the rounded matrix with a second distributed factorisation (models/GP.py:268, 599, 719): right_vector of the
+    single-GPU compat="reference" fit to 1e-6 at M = 7001; predictions (float16 values) within an ulp."""
+    res = _run(2, "fit_compat", 900)
+    for rank, rv_err, pred_err, dsteps, dloss, cg_max in res:
+        assert rv_err <= 1e-6 and pred_err <= 2.0 ** -10 and dsteps == 0 and dloss <= 1e-8, res
 
 
 def test_a_failed_pivot_on_one_rank_raises_on_every_rank():

@@ -58,6 +58,59 @@ def test_the_reference_test_set_is_reproduced_bit_for_bit(d):
     assert dom.dtype == np.float16 and np.abs(bdy[:, :-1].astype(np.float64)).max(axis=1).min() == 0.5     # one coordinate on a face
 
 
+@pytest.mark.parametrize("d", [40, 60, 80])
+def test_oracle_gp_reproduces_the_logged_single_run_at_every_dimension(d):
+    """The GP half of the oracle pinned on the CPU at every dimension the reference ran (d = 20 below, with the ten test
+    sets): one fit of oracle/gp_compat.py on the reference's training set, its SimpleUniform test set, GP relative L2 and L1 max / mean of
+    <d>d/SimpleUniform/SimpleUniform.log:4, 9.  Measured differences of the relative L2: -1.05e-4, -1.3e-5, +4.4e-5 at d = 40, 60, 80."""
+    from oracle.equation import GradDependentNonlinear, deepxde_points, logistic_wave_f16
+    from oracle.gp_compat import OracleGPCompat
+    from scasml_gp_amd.threefry import reference_laplacian_idx
+    np.random.seed(1234)
+    dom, bdy = deepxde_points(d, 1000, 200)
+    xt = np.concatenate(deepxde_points(d, 1000, 200))
+    gp = OracleGPCompat(GradDependentNonlinear(d + 1), reference_laplacian_idx(d, "partitionable"))
+    gp.GPsolver(dom.astype(np.float64), bdy.astype(np.float64), GN_steps=20)
+    ex = logistic_wave_f16(xt).astype(np.float64)[:, 0]
+    err = np.abs(gp.predict(xt.astype(np.float64))[:, 0] - ex)
+    head = simple_head(d)
+    assert abs(np.linalg.norm(err) / np.linalg.norm(ex) - head["GP rel L2, rho=2"]) <= 1.3e-4
+    assert abs(err.mean() - head["GP L1, rho=2"]["mean"]) <= 1e-3 * head["GP L1, rho=2"]["mean"]
+    assert abs(err.max() - head["GP L1, rho=2"]["max"]) <= 5e-3 * head["GP L1, rho=2"]["max"]
+
+
+def test_oracle_float16_graph_of_kappa_and_first_order_blocks_at_d20():
+    """On float16 rows the reference's kernels are float16 arithmetic throughout and its first-order blocks reverse-mode autodiff through it
+    (models/GP.py:41-85); OracleGPCompat(f16_graph=True) follows that op sequence for kappa, dt_x/dt_y kappa and div_x/div_y kappa (9 of the 25
+    Gram blocks, 4 of the 5 feature rows of predict).  GP relative L2 against SimpleUniform.log:4: +3.65e-5 with one rounding per entry,
+    -1.5e-5 with the graph (bound 5e-5: VERDICT r3 item 4); L1 max 0.35596 -> 0.35547 against the logged 0.35449."""
+    from oracle.equation import GradDependentNonlinear, deepxde_points, logistic_wave_f16
+    from oracle.gp_compat import OracleGPCompat
+    from scasml_gp_amd.threefry import reference_laplacian_idx
+    d = 20
+    np.random.seed(1234)
+    dom, bdy = deepxde_points(d, 1000, 200)
+    xt = np.concatenate(deepxde_points(d, 1000, 200))
+    gp = OracleGPCompat(GradDependentNonlinear(d + 1), reference_laplacian_idx(d, "partitionable"), f16_graph=True)
+    gp.GPsolver(dom.astype(np.float64), bdy.astype(np.float64), GN_steps=20)
+    ex = logistic_wave_f16(xt).astype(np.float64)[:, 0]
+    err = np.abs(gp.predict(xt.astype(np.float64))[:, 0] - ex)
+    head = simple_head(d)
+    assert abs(np.linalg.norm(err) / np.linalg.norm(ex) - head["GP rel L2, rho=2"]) <= 5e-5
+    assert abs(err.max() - head["GP L1, rho=2"]["max"]) <= 1.2e-3
+    # the graph differs from one-rounding-per-entry where it should: the first-order blocks on float16 rows, by a few float16 ulps; and not elsewhere
+    one = OracleGPCompat(GradDependentNonlinear(d + 1), reference_laplacian_idx(d, "partitionable"))
+    X, Y = dom[:64].astype(np.float64), dom[64:192].astype(np.float64)
+    for key in (("I", "I"), ("dt", "I"), ("I", "dt"), ("div", "I"), ("I", "div")):
+        a, b = gp.block(key[0], key[1], X, Y), one.block(key[0], key[1], X, Y)
+        assert np.array_equal(a.astype(np.float16).astype(np.float64), a)
+        assert np.abs(a - b).max() <= (2.0 ** -8 if "div" in key else 2.0 ** -9) * np.abs(b).max() and (a != b).any(), key
+    assert np.array_equal(gp.block("I", "dt", X, Y), -gp.block("dt", "I", X, Y))
+    assert np.array_equal(gp.block("lap", "I", X, Y), one.block("lap", "I", X, Y))
+    Xf = X + 1e-4                                                      # not float16 rows: one rounding per entry IS what JAX computes
+    assert np.array_equal(gp.block("I", "I", Xf, Y), one.block("I", "I", Xf, Y))
+
+
 def test_oracle_gp_reproduces_the_logged_errors_at_d20():
     """RepeatedExperiment.py:143-207 with the oracle (NumPy float64 statement of the as-coded surrogate): one fit on the reference's
     training set, its ten test sets; mean / std / range of the GP's relative L2, mean L1 and mean squared error against
@@ -75,7 +128,7 @@ def test_oracle_gp_reproduces_the_logged_errors_at_d20():
     xt = np.concatenate(deepxde_points(d, 1000, 200))                    # SimpleUniform: the stream continues
     ex = logistic_wave_f16(xt).astype(np.float64)[:, 0]
     err = np.abs(gp.predict(xt.astype(np.float64))[:, 0] - ex)
-    assert abs(np.linalg.norm(err) / np.linalg.norm(ex) - simple_head(d)["GP rel L2, rho=2"]) <= 1.5e-4
+    assert abs(np.linalg.norm(err) / np.linalg.norm(ex) - simple_head(d)["GP rel L2, rho=2"]) <= 5e-5     # measured +3.65e-5
     # the other Threefry counter layout (jax < 0.5) draws other indices and misses the same log by 1.4 %: 16 sigma of that mean
     assert reference_laplacian_idx(d, "original").tolist() != idx.tolist()
     rel, l1, l2 = [], [], []
