@@ -447,7 +447,7 @@ def main():
     n_inf = B * ppr
     flops = n_inf * (2.0 * n_colloc * (d + 1) + 10.0 * m_feat)     # 2 N_inf N (d+1) + 10 N_inf M
     gp_ms = kernel_ms.get("gp_eval")
-    traffic, traffic_source, issue = None, None, None
+    traffic, traffic_source, issue, vector_roof = None, None, None, None
     # HBM bytes and issue-slot counters per launch come from separate rocprofv3 --pmc passes of this same command, condensed
     # by profiles/summarize.py (they cannot be collected inside this process): NOT measured in this run, labelled so, and quoted
     # only if they were taken on the SAME kernel source (sha1 of the files the kernel is built from)
@@ -455,7 +455,7 @@ def main():
     for prof in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gp_eval_pmc.json")), reverse=True):
         try:
             pj = json.load(open(prof))
-            if gp is not None and pj.get("n_inf") == n_inf and pj.get("d") == d and pj.get("source_sha1") == gp_sha:
+            if gp is not None and pj.get("n_inf") == n_inf and pj.get("d") == d and pj.get("source_sha1") == gp_sha and pj.get("mode", "reference") == args.compat:
                 traffic = pj.get("hbm_bytes_per_launch")
                 traffic_source = "%s (separate rocprofv3 --pmc passes of this command on this kernel source; FETCH_SIZE doubled per MI355X_MICROARCH.md)" % os.path.relpath(prof, ROOT)
                 if pj.get("valu_active_frac") is not None:
@@ -463,9 +463,27 @@ def main():
                              "coexec_frac_of_mfma_busy": round(pj["coexec_frac_of_mfma_busy"], 3),
                              "cycles_per_valu_instruction": round(pj["cycles_per_valu_instruction"], 2),
                              "effective_clock_ghz": round(pj.get("effective_clock_ghz", 0.0), 3),
-                             "source": os.path.relpath(prof, ROOT), "note": "vector time and matrix time ADD on this chip (ablation and instruction-level "
-                             "microbenchmarks: profiles/r03_compat_eval_experiments.txt, DESIGN.md 4.4): the launch is t_vector + t_matrix, the "
-                             "counters' busy fractions overlap only in issue; `frac` is of the matrix roof alone"}
+                             "source": os.path.relpath(prof, ROOT), "note": "vector time and matrix time ADD in this kernel (ablations and instruction-level "
+                             "microbenchmarks: profiles/r03_compat_eval_experiments.txt, r04_ubench_hetero.txt, DESIGN.md 4.4): the launch is t_vector + t_matrix, "
+                             "the counters' busy fractions overlap only in issue; `frac` is of the matrix roof alone, `vector` states the other term"}
+                    cnt = pj.get("counters_avg_per_launch", {})
+                    if cnt.get("SQ_INSTS_VALU") and pj.get("effective_clock_ghz"):
+                        # the binding roof: vector wave-instructions per SIMD x the issue cost of THIS instruction mix with >= 3 waves
+                        # per SIMD (tools/ubench_hetero.hip, vector-only rows: 2.02 cycles for plain float32, 3.12 for the as-coded epilogue's mix
+                        # of plain / float16-conversion / exp instructions, 2.6 for the factored epilogue's plain + exp mix) / the clock the chip held
+                        mix = 3.12 if args.compat == "reference" else 2.6
+                        clk = pj["effective_clock_ghz"] * 1e9
+                        per_simd = cnt["SQ_INSTS_VALU"] / 1024.0
+                        t_v = per_simd * mix / clk * 1e3
+                        t_m = cnt.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 1024.0 / clk * 1e3
+                        vector_roof = {"valu_wave_instructions_per_launch": cnt["SQ_INSTS_VALU"], "per_pair": round(cnt["SQ_INSTS_VALU"] * 64.0 / (n_inf * float((n_colloc + 31) // 32 * 32)), 2),
+                                       "issue_cycles_per_instruction_of_this_mix": mix, "clock_ghz": round(pj["effective_clock_ghz"], 3),
+                                       "vector_ms": round(t_v, 2), "vector_ms_at_2_cycles_per_instruction": round(per_simd * 2.0 / clk * 1e3, 2),
+                                       "matrix_ms": round(t_m, 2), "sum_model_ms": round(t_v + t_m, 2), "profiled_launch_ms": round(pj["avg_ms_kernel_trace"], 2),
+                                       "frac_of_sum_model": round((t_v + t_m) / pj["avg_ms_kernel_trace"], 3),
+                                       "source": os.path.relpath(prof, ROOT) + " + profiles/r04_ubench_hetero.txt",
+                                       "note": "a MFMA-only wave beside vector-only waves on one SIMD starves the vector waves (one instruction per 16 cycles each), and "
+                                               "waves that interleave both pay ~8 issue cycles per MFMA only in a uniform stream: the kernel's launch time is the sum"}
                 break
         except Exception:
             continue
@@ -507,7 +525,7 @@ def main():
                                    "not rounded: factored sums)" % (planes, "" if planes == 1 else "s")) if geometry else
                                   "gp_eval_compat_mfma_kernel (as-coded surrogate: 3 shifted geometries x 2 fp16 planes, float16 entries)",
                         "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                        "traffic": traffic, "traffic_source": traffic_source, "valu_issue": issue, "avg_launch_ms": round(gp_ms, 4),
+                        "traffic": traffic, "traffic_source": traffic_source, "valu_issue": issue, "vector": vector_roof, "avg_launch_ms": round(gp_ms, 4),
                         "flops_per_launch": flops, "mfma_issued_tflops": round(issued, 1), "mfma_issued_frac": round(issued / peak, 4),
                         "as_coded": {"flops_per_launch": flops_ac, "achieved": round(ach_ac, 3), "frac": round(ach_ac / peak, 4),
                                      "note": "algorithmic flops of the surrogate the reference's code builds: 3 x.y products per pair where eps_PDE is "

@@ -6,6 +6,8 @@
 * <tag>_kernel_stats.csv        rocprofv3 --kernel-trace --stats summary, verbatim
 * <tag>_kernel_by_grid.txt      the same trace grouped by (kernel, grid) so that the bench-size
                                 launches are not averaged with the small setup / harness launches
+  (extra key=value arguments are copied into the summary: n_inf=... d=... mode=reference|reference-geometry|none -- bench.py quotes the
+   summary of the surrogate it runs; out=<name> replaces <tag>_gp_eval_pmc.json / <tag>_picard_pmc.json by <name>_...)
 * <tag>_gp_eval_pmc.json        PMC counters of the bench-size gp_eval launch.  HBM bytes follow
                                 MI355X_MICROARCH.md "HBM": bytes = 2*FETCH_SIZE*1024 (gfx950 reports
                                 half of a wide coalesced read) + WRITE_SIZE*1024, separate passes.
@@ -73,7 +75,8 @@ def main():
                 out["cycles_per_valu_instruction"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / c["SQ_INSTS_VALU"] if "SQ_INSTS_VALU" in c else None
             if "SQ_VALU_MFMA_COEXEC_CYCLES" in c:
                 out["coexec_frac_of_mfma_busy"] = c["SQ_VALU_MFMA_COEXEC_CYCLES"] / c["SQ_VALU_MFMA_BUSY_CYCLES"]
-        json.dump(out, open(os.path.join(HERE, tag + "_gp_eval_pmc.json"), "w"), indent=1)
+        out_tag = out.pop("out", tag)
+        json.dump(out, open(os.path.join(HERE, out_tag + "_gp_eval_pmc.json"), "w"), indent=1)
         print(json.dumps(out, indent=1))
         # the two Picard-tree passes of the same step (bench-size launches = the largest grid of each kernel)
         pic = {}
@@ -93,7 +96,7 @@ def main():
             ent["counters_avg_per_launch"] = cnt
             pic[name] = ent
         pic["source_sha1"] = bench.kernel_source_sha1(bench.PICARD_SOURCES)
-        json.dump(pic, open(os.path.join(HERE, tag + "_picard_pmc.json"), "w"), indent=1)
+        json.dump(pic, open(os.path.join(HERE, out_tag + "_picard_pmc.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -100,12 +100,20 @@ template <int KS, int PLANES>
 __device__ __forceinline__ void compat_mfma_lam(const float4 *lds_a, const s16x8 (&xb)[PLANES][KS], f32x16 &acc, int lane, float acc0) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = acc0;
-    Frag a[2];
-    a[0].f = lds_a[lane];
+    // two planes: ONE fragment register set, read step by step (the other waves of the SIMD cover the LDS latency): with the row constants
+    // of the epilogue read the same way the as-coded kernel fits 128 registers at KS = 7, i.e. a fourth wave per SIMD (19.6 -> 19.2 ms;
+    // 134 registers and three waves with only the registers saved: 19.7)
+    constexpr int NA = PLANES == 2 ? 1 : 2;
+    Frag a[NA];
+    if constexpr (NA == 2) a[0].f = lds_a[lane];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-        const int cur = s & 1, nxt = cur ^ 1;
-        if (s + 1 < KS) a[nxt].f = lds_a[(s + 1) * 64 + lane];
+        const int cur = NA == 2 ? (s & 1) : 0, nxt = cur ^ 1;
+        if constexpr (NA == 2) {
+            if (s + 1 < KS) a[nxt].f = lds_a[(s + 1) * 64 + lane];
+        } else {
+            a[0].f = lds_a[s * 64 + lane];
+        }
         Frag b0;
         b0.v = xb[0][s];
         if constexpr (PLANES == 2) {
@@ -136,17 +144,16 @@ __device__ __forceinline__ void compat_epilogue(const float *rows_lds, const f32
                                                 const CompatConsts &c, float &au, float &at, float &ad, float &al) {
     const float4 *cb = reinterpret_cast<const float4 *>(__builtin_assume_aligned(rows_lds + 4 * 8 * half, 16));   // row = (r&3) + 8 (r>>2) + 4 half
     constexpr int NQ = (BDY || GEOM == 1) ? 1 : 2;
-    float4 q[2][NQ];
+    float4 q[1][NQ];
     auto fetch = [&](int r, float4 (&dst)[NQ]) {
         const int row = (r & 3) + 8 * (r >> 2);
 #pragma unroll
         for (int i = 0; i < NQ; ++i) dst[i] = cb[row * 2 + i];
     };
-    fetch(0, q[0]);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int cur = r & 1, nxt = cur ^ 1;
-        if (r + 1 < 16) fetch(r + 1, q[nxt]);
+        const int cur = 0;
+        fetch(r, q[0]);             // read where used, not one row ahead: eight registers fewer (see compat_mfma_lam)
         __builtin_amdgcn_sched_barrier(0);
         const float kap = pin(__builtin_amdgcn_exp2f(lam[r]));
         if constexpr (GEOM == 0) {
@@ -653,22 +660,12 @@ __global__ void gp_compat_pack_mfma_kernel(int d, float a, const float *x_dom, i
 
 template <int KS, bool R16, int PLANES>
 static int launch_compat(const GpCompatArgs &g, hipStream_t s) {
-    // registers: 4 KS per point plane + ~90 for accumulators, Q fragments, row constants and temporaries
-    constexpr int REGS = 4 * PLANES * KS + 90;
+    // registers: 4 KS per point plane + ~72 (as-coded, reads not run ahead) / ~90 (geometry mode) for accumulators, Q fragments, row
+    // constants and temporaries
+    constexpr int REGS = 4 * PLANES * KS + (R16 ? 72 : 90);
     constexpr size_t lds_bytes = SCASML_COMPAT_NSLOT * (size_t)(KS * 256 + kStageTail) * sizeof(float);
-    constexpr int BPC_REGS = REGS <= 128 ? 4 : (REGS <= 168 ? 3 : 2), BPC_LDS = (int)(160 * 1024 / lds_bytes);
-#if defined(SCASML_FACT_BPC) || defined(SCASML_R16_BPC)      // development: occupancy A/B
-#ifndef SCASML_FACT_BPC
-#define SCASML_FACT_BPC BPC_REGS
-#endif
-#ifndef SCASML_R16_BPC
-#define SCASML_R16_BPC BPC_REGS
-#endif
-    constexpr int BPC_DEV = R16 ? SCASML_R16_BPC : SCASML_FACT_BPC;
-    constexpr int BPC = BPC_DEV < BPC_LDS ? BPC_DEV : BPC_LDS;
-#else
+    constexpr int BPC_REGS = REGS <= 128 ? 4 : (REGS <= 164 ? 3 : 2), BPC_LDS = (int)(160 * 1024 / lds_bytes);
     constexpr int BPC = BPC_REGS < BPC_LDS ? BPC_REGS : BPC_LDS;
-#endif
     const int64_t waves = (g.n_inf + 31) / 32;
     const int64_t blocks = (waves + 3) / 4;
     if (blocks > 0x7FFFFFFF) return fail(SCASML_ERR_UNSUPPORTED, "gp_eval_compat_sites: too many points");

@@ -122,6 +122,14 @@ __device__ __forceinline__ float jax_uniform_f16(uint32_t k0, uint32_t k1, uint6
     return (float)(__builtin_bit_cast(_Float16, hb) - (_Float16)1.0f);
 }
 
+// ACCUMULATE's read-ahead of terminal rows (kAhead samples); empty in the other modes
+template <bool ON>
+struct PrefetchQueue {
+    float4 XT[kAhead], gp[kAhead];
+};
+template <>
+struct PrefetchQueue<false> {};
+
 template <int VAR, int MODE, int EQ, bool JAX = false>
 struct Walker {
     const TreeArgs &a;
@@ -337,14 +345,18 @@ struct Walker {
             // ACCUMULATE reads the stored X_T back: the rows of the next kAhead samples are requested before this one is
             // consumed (one dependent HBM round trip per sample otherwise; the pass is bound by the bytes it keeps in flight)
             const bool readback = MODE == SCASML_MODE_ACCUMULATE && vol >= kReadbackMinVol;
-            float4 XTq[kAhead], gpq[kAhead];
+            // (the queue exists in ACCUMULATE only: as plain arrays in every mode they survived as a dead 36-byte stack object of the MLP and
+            // GENERATE kernels from level 3 on -- private segment enabled for nothing, profiles/r03_kernel_by_grid.txt)
+            PrefetchQueue<MODE == SCASML_MODE_ACCUMULATE> pq;
+            if constexpr (MODE == SCASML_MODE_ACCUMULATE) {
 #pragma unroll
-            for (int p = 0; p < kAhead; ++p) {
-                XTq[p] = f4(0.0f);
-                gpq[p] = f4(0.0f);
-                if (MODE == SCASML_MODE_ACCUMULATE && !(TOP && a.world > 1) && p < mg) {
-                    if (readback) XTq[p] = load_point(base + (uint32_t)p);
-                    gpq[p] = gp_at(base + (uint32_t)p);
+                for (int p = 0; p < kAhead; ++p) {
+                    pq.XT[p] = f4(0.0f);
+                    pq.gp[p] = f4(0.0f);
+                    if (!(TOP && a.world > 1) && p < mg) {
+                        if (readback) pq.XT[p] = load_point(base + (uint32_t)p);
+                        pq.gp[p] = gp_at(base + (uint32_t)p);
+                    }
                 }
             }
             for (int m = 0; m < mg; ++m) {                       // MLP.py:175-202
@@ -352,16 +364,16 @@ struct Walker {
                 float4 nrm, XT, gpv = f4(0.0f);
                 if constexpr (MODE == SCASML_MODE_ACCUMULATE) {
                     if (!(TOP && a.world > 1)) {                 // un-sharded: software-pipelined reads
-                        XT = XTq[0];
-                        gpv = gpq[0];
+                        XT = pq.XT[0];
+                        gpv = pq.gp[0];
 #pragma unroll
                         for (int p = 0; p + 1 < kAhead; ++p) {
-                            XTq[p] = XTq[p + 1];
-                            gpq[p] = gpq[p + 1];
+                            pq.XT[p] = pq.XT[p + 1];
+                            pq.gp[p] = pq.gp[p + 1];
                         }
                         if (m + kAhead < mg) {
-                            if (readback) XTq[kAhead - 1] = load_point(site + kAhead);
-                            gpq[kAhead - 1] = gp_at(site + kAhead);
+                            if (readback) pq.XT[kAhead - 1] = load_point(site + kAhead);
+                            pq.gp[kAhead - 1] = gp_at(site + kAhead);
                         }
                     } else {
                         if (!owned(TOP)) continue;
