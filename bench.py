@@ -470,8 +470,8 @@ def main():
                     if cnt.get("SQ_INSTS_VALU") and pj.get("effective_clock_ghz"):
                         # the binding roof: vector wave-instructions per SIMD x the issue cost of THIS instruction mix with >= 3 waves
                         # per SIMD (tools/ubench_hetero.hip, vector-only rows: 2.02 cycles for plain float32, 3.12 for the as-coded epilogue's mix
-                        # of plain / float16-conversion / exp instructions, 2.6 for the factored epilogue's plain + exp mix) / the clock the chip held
-                        mix = 3.12 if args.compat == "reference" else 2.6
+                        # of plain / float16-conversion / exp instructions; the factored epilogue's 19 plain + 3 exp (8.3 cycles) per 22: 2.9) / the clock the chip held
+                        mix = 3.12 if args.compat == "reference" else 2.9
                         clk = pj["effective_clock_ghz"] * 1e9
                         per_simd = cnt["SQ_INSTS_VALU"] / 1024.0
                         t_v = per_simd * mix / clk * 1e3

@@ -401,7 +401,10 @@ class GP(object):
             raise ValueError("state is for n_input=%d, this GP has n_input=%d" % (int(state["n_input"]), self.n_input))
         if str(state.get("compat", "")) != (self.compat or "") or (
                 self.compat and not np.array_equal(np.asarray(state["laplacian_idx"]), self.laplacian_idx)):
-            raise ValueError("state was trained with compat=%r, laplacian_idx=%s" % (str(state.get("compat", "")), state.get("laplacian_idx")))
+            trained = str(state.get("compat", ""))
+            raise ValueError("state was trained with compat=%r, laplacian_idx=%s: construct the GP with compat=%s%s to load it" % (
+                trained, state.get("laplacian_idx"), repr(trained) if trained else "None",
+                (", laplacian_idx=%s" % np.asarray(state["laplacian_idx"]).tolist()) if trained else ""))
         self.nugget = float(state["nugget"])
         if "T" in state and float(state["T"]) != float(self.T):
             raise ValueError("state was trained with terminal time T = %g, this GP's equation has T = %g" % (float(state["T"]), float(self.T)))

@@ -98,6 +98,30 @@ def test_sample_sharding_partials_sum_to_the_unsharded_result():
     assert torch.allclose(summed, full, atol=1e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("variant,n,par", [("quad", 3, 3), ("fh", 3, 3)])
+def test_sample_sharded_solve_applies_the_root_calls_float16_cast_after_the_reduction(variant, n, par):
+    """under compat_f16 a sharded root call leaves clip AND .astype(float16) (MLP.py:272-274, MLP_full_history.py:178-180) to the end
+    of the all-reduce; finalize_partials applies both, so the sharded estimator returns float16 values as the unsharded one does."""
+    import torch
+    from scasml_gp_amd.solvers._picard import PicardEngine
+    from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
+    eq = Grad_Dependent_Nonlinear(21)
+    eq.geometry()
+    xt = _points(20, 32, 8)
+    eng = PicardEngine(eq, variant, seed=4, compat_f16=True)
+    full, _, _ = eng.solve(n, par, xt, stream_id=0)
+    assert torch.equal(full.half().float(), full)                       # the unsharded root call returns float16 values
+    parts = [eng.solve(n, par, xt, rank=r, world=3, stream_id=0)[0] for r in range(3)]
+    raw = parts[0] + parts[1] + parts[2]
+    assert not torch.equal(raw.half().float(), raw)                     # partial sums are not rounded
+    summed = eng.finalize_partials(raw.clone())
+    assert torch.equal(summed.half().float(), summed)
+    # the same numbers up to the order of the float32 additions, i.e. at most one float16 ulp where a sum lands next to a rounding boundary
+    assert float((summed - full).abs().max()) <= 2.0 ** -10 * float(full.abs().max()) and float((summed != full).float().mean()) < 0.02
+    plain = PicardEngine(eq, variant, seed=4).finalize_partials(raw.clone())
+    assert not torch.equal(plain.half().float(), plain)                 # without compat_f16: clip only
+
+
 def test_maximum_dimension_and_single_root():
     hip, ora = _solvers(252, "quad", seed=5)
     xt = _points(252, 4, 9)[:1]
