@@ -34,8 +34,9 @@ def build_library(force=False, verbose=False):
         o = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            # plan_host.cpp is plain C++ (host only): no offload flag, so nothing in it can depend on HIP
-            flags = FLAGS if src.endswith(".hip") else [f for f in FLAGS if not f.startswith("--offload-arch")]
+            # plan_host.cpp is plain C++ (host only): compiled AS C++ (-x c++: hipcc would otherwise treat a .cpp as HIP) without an offload
+            # architecture, so nothing in it can depend on HIP -- the same file builds with g++ under the sanitizers (tests/test_host_sanitizers.py)
+            flags = FLAGS if src.endswith(".hip") else [f for f in FLAGS if not f.startswith("--offload-arch")] + ["-x", "c++"]
             jobs.append([hipcc] + flags + ["-c", s, "-o", o])
 
     def run(cmd):
