@@ -74,6 +74,7 @@ __global__ void debug_normals_kernel(uint32_t k0, uint32_t k1, uint32_t stream, 
 }
 
 __global__ void debug_jax_normals_kernel(uint32_t k0, uint32_t k1, uint64_t index0, int64_t count, float *out) {
+    jax_table_to_lds();             // the path the tree kernels take: the tabulated transform
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) out[i] = jax_normal_f16(k0, k1, index0 + (uint64_t)i);
 }

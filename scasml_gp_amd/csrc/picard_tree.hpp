@@ -63,7 +63,7 @@ constexpr int kAhead = SCASML_ACC_AHEAD;
 // element with row-major index i of a draw under key (k0, k1) = low 16 bits of y0 ^ y1, (y0, y1) = Threefry-2x32-20(key, (i >> 32, i));
 // bits >> 6 | 0x3C00 is a float16 in [1, 2); minus 1, times 2, plus nextafter(-1, 0), clamped below (each a float16 operation);
 // sqrt(2) * erf_inv in float32 (XLA's ErfInv32) rounded to float16 before the float16 product.  One Threefry per normal: this is the
-// parity mode, ~7x the integer work of the Philox stream.
+// parity mode, ~7x the integer work of the Philox stream.  The transform itself depends on ten bits only and is tabulated per workgroup.
 __device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
 __device__ __forceinline__ uint32_t threefry_bits16(uint32_t k0, uint32_t k1, uint64_t index) {
     const uint32_t ks[3] = {k0, k1, k0 ^ k1 ^ 0x1BD11BDAu};
@@ -81,8 +81,10 @@ __device__ __forceinline__ uint32_t threefry_bits16(uint32_t k0, uint32_t k1, ui
     }
     return (x0 ^ x1) & 0xFFFFu;
 }
-__device__ __forceinline__ float jax_normal_f16(uint32_t k0, uint32_t k1, uint64_t index) {
-    const unsigned short hb = (unsigned short)((threefry_bits16(k0, k1, index) >> 6) | 0x3C00u);
+// the float16 transform of the draw's TEN live bits (the float16 uniform has a 10-bit mantissa): a function of 1024 inputs, which the tree kernels
+// tabulate once per workgroup (jax_table_to_lds) instead of evaluating log1p, a square root and a polynomial per normal
+__device__ __forceinline__ float jax_normal_of_bits10(uint32_t b10) {
+    const unsigned short hb = (unsigned short)(b10 | 0x3C00u);
     const _Float16 lo = (_Float16)-0.99951171875f;                      // nextafter(float16(-1), 0)
     _Float16 u = __builtin_bit_cast(_Float16, hb) - (_Float16)1.0f;
     u = u * (_Float16)2.0f + lo;                                        // (1 - lo) rounds to 2 in float16; both operations are exact or rounded once
@@ -115,6 +117,20 @@ __device__ __forceinline__ float jax_normal_f16(uint32_t k0, uint32_t k1, uint64
     }
     const _Float16 e = (_Float16)(p * x);
     return (float)((_Float16)1.4140625f * e);                           // float16(sqrt(2)) * float16(erf_inv): a float16 product
+}
+constexpr int kJaxTableRows = 1024;
+__device__ __forceinline__ float *jax_table_lds() {
+    __shared__ float t[kJaxTableRows];
+    return t;
+}
+// every thread of the workgroup, before any return: the 1024 possible normals of jax.random.normal(float16), 4 KB of LDS
+__device__ __forceinline__ void jax_table_to_lds() {
+    float *t = jax_table_lds();
+    for (int i = threadIdx.x; i < kJaxTableRows; i += blockDim.x) t[i] = jax_normal_of_bits10((uint32_t)i);
+    __syncthreads();
+}
+__device__ __forceinline__ float jax_normal_f16(uint32_t k0, uint32_t k1, uint64_t index) {
+    return jax_table_lds()[threefry_bits16(k0, k1, index) >> 6];
 }
 // jax.random.uniform(key, shape, float16): one of the 1024 values k / 1024 (0 included)
 __device__ __forceinline__ float jax_uniform_f16(uint32_t k0, uint32_t k1, uint64_t index) {
@@ -433,7 +449,8 @@ struct Walker {
 // deeper levels then spill inside their loops; 6 and 8 are slower.  No hint.)
 template <int VAR, int MODE, int N, int EQ, bool JAX = false>
 __global__ __launch_bounds__(256) void picard_tree_kernel(const TreeArgs a) {
-    normal_table_to_lds();   // every thread, before any return below
+    if constexpr (JAX) jax_table_to_lds();   // every thread, before any return below: the reference's stream needs its own 4 KB table only
+    else normal_table_to_lds();
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * (blockDim.x >> 6)) + (threadIdx.x >> 6);
     int64_t local;
