@@ -79,7 +79,7 @@ typedef struct {
  * uz_solve returns clip(...).astype(float16) (solvers/MLP.py:274, ScaSML.py:284, MLP_full_history.py:180; ScaSML_full_history.py:199
  * does not cast), so a child's (u, z) is a float16 value before the parent's f sees it.  Sample-sharded partial sums (world > 1) are
  * left unrounded: the cast follows the clip, which follows the all-reduce (scasml_clip_round16).
- * JAX_STREAM (every level 1..SCASML_MAX_LEVEL, no sample sharding) replaces the Philox stream by the REFERENCE's own normals (and, full history, uniform times) --
+ * JAX_STREAM (every level 1..SCASML_MAX_LEVEL; with sample sharding every rank passes the same key words) replaces the Philox stream by the REFERENCE's own normals (and, full history, uniform times) --
  * jax.random.normal(key, shape, float16) under jax_threefry_partitionable, each element addressed by the row-major index it has in the
  * reference's batch-vectorised draw (one Threefry-2x32 per normal) -- under the keys in scasml_rng.jax_keys; seed / stream are ignored.
  * With it a solve on the reference's test set lands on the numbers its runs logged (tests/test_gpu_jax_stream.py). */

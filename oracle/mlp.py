@@ -122,8 +122,6 @@ class PicardOracle:
         self.sites_executed = 0
         jx = None
         if self.jax_stream:
-            if world != 1:
-                raise NotImplementedError("jax_stream: unsharded solves only")
             jx = (self.jax_splits, np.arange(B, dtype=np.uint64))
             if self.variant == "quad":               # the full-history solvers draw everything from the one terminal key
                 self.jax_splits += self._jax_splits_in_call(n)

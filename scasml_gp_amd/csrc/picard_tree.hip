@@ -136,7 +136,6 @@ extern "C" int scasml_picard_tree(const scasml_problem *prob, const scasml_plan 
     a.f16 = (rng.flags & SCASML_RNG_COMPAT_F16) ? 1 : 0;
     a.jk = (rng.flags & SCASML_RNG_JAX_STREAM) ? rng.jax_keys : nullptr;
     if ((rng.flags & SCASML_RNG_JAX_STREAM) && !rng.jax_keys) return fail(SCASML_ERR_ARG, "picard_tree: SCASML_RNG_JAX_STREAM needs scasml_rng.jax_keys");
-    if (a.jk && rng.world != 1) return fail(SCASML_ERR_UNSUPPORTED, "picard_tree: SCASML_RNG_JAX_STREAM with sample sharding");
     a.d = prob->d;
     a.kp = scasml_point_stride(prob->d);
     a.G = ceil_pow2(a.kp / 4);

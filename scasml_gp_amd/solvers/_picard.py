@@ -150,8 +150,8 @@ class PicardEngine:
         owner = self.unit_owners(n, par, world)[1].data_ptr() if world > 1 and n > 0 else None
         jax_keys, jax_next = None, None
         if self.compat_rng == "jax" and n > 0:
-            if world != 1:
-                raise NotImplementedError("compat_rng='jax' with Monte-Carlo sample sharding")
+            # (sample sharding: a draw is addressed by the index it has in the reference's flattened batch, which does not depend on who owns
+            # the sample; every rank derives the same key words and advances its key state alike)
             if n > _lib.MAX_LEVEL:             # refuse before the key words are computed: a refused solve must not move the solver's key
                 raise _lib.ScasmlError("picard_tree: level n=%d outside 1..%d" % (n, _lib.MAX_LEVEL))
             keys, jax_next = self._jax_keys(plan)

@@ -168,6 +168,35 @@ def _small_surrogates(d, nd, nb, seed):
     return eq, gp, oeq, ogp, xt
 
 
+@pytest.mark.parametrize("variant,n,par", [("quad", 3, 3), ("fh", 3, 3)])
+def test_sample_sharded_solves_on_the_reference_stream(variant, n, par):
+    """The Monte-Carlo units of the root call dealt over three ranks, on the reference's stream: a draw is addressed by its index in the reference's
+    flattened batch, whoever owns the sample, so the ranks' partial sums add up to the unsharded estimator (and each equals the oracle's partial)."""
+    import torch
+    from oracle.equation import GradDependentNonlinear, sample_points
+    from oracle.mlp import PicardOracle
+    from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
+    from scasml_gp_amd.solvers._picard import PicardEngine
+    d = 20
+    eq = Grad_Dependent_Nonlinear(d + 1)
+    eq.geometry()
+    xt = np.concatenate(sample_points(np.random.default_rng(5), d, 32, 8)).astype(np.float16).astype(np.float32)
+    eng = PicardEngine(eq, variant, reference_mode=True)
+    key0 = eng.jax_key
+    parts = [eng.solve(n, par, xt, rank=r, world=3, stream_id=0)[0] for r in range(3)]        # replays: the key stays where it is
+    assert eng.jax_key == key0
+    summed = eng.finalize_partials((parts[0] + parts[1] + parts[2]).clone())
+    full, _, _ = eng.solve(n, par, xt)
+    assert eng.jax_key != key0 or variant == "fh"                                               # the quadrature solve moved the key
+    assert float((summed - full).abs().max()) <= 2.0 ** -10 * float(full.abs().max()) and float((summed != full).float().mean()) < 0.02
+    owner = eng.unit_owners(n, par, 3)[0]
+    for r in range(3):
+        ora = PicardOracle(GradDependentNonlinear(d + 1), variant, jax_stream=True, compat_f16=True)
+        want = ora.uz_solve(n, par, xt, rank=r, world=3, owner=owner)
+        ok = np.isfinite(want).all(axis=1)
+        assert np.allclose(parts[r].cpu().numpy()[ok], want[ok], atol=2e-4, rtol=2e-3), r
+
+
 @pytest.mark.parametrize("n,M,d", [(4, 3, 20), (5, 2, 10), (3, 3, 40)])
 def test_full_history_mlp_at_levels_up_to_five_on_the_reference_stream(n, M, d):
     """BASELINE configs[3] is the full-history recursion at n = 4: every draw of every call from the ONE key of MLP_full_history.py:92-93, 99,
