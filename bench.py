@@ -530,10 +530,15 @@ def main():
                         "as_coded": {"flops_per_launch": flops_ac, "achieved": round(ach_ac, 3), "frac": round(ach_ac / peak, 4),
                                      "note": "algorithmic flops of the surrogate the reference's code builds: 3 x.y products per pair where eps_PDE is "
                                              "consumed (%d of %d sites), 2 elsewhere" % (int((kinds == 0).sum()), len(kinds))},
-                        "note": "achieved = algorithmic flops of SURVEY 8(d) (2 N_inf N (d+1) + 10 N_inf M: ONE x.y product per pair); the as-coded "
-                                "surrogate needs three (aligned, y shifted, x shifted) in two fp16 planes each, and 13 separately float16-rounded "
-                                "entries per pair in the epilogue (~50 vector instructions + 3 exp against 14 + 1 for the documented operators): "
-                                "the launch time is vector time plus matrix time, which do not overlap on this chip (valu_issue; DESIGN.md 4.4)"}
+                        "note": ("achieved = algorithmic flops of SURVEY 8(d) (2 N_inf N (d+1) + 10 N_inf M: ONE x.y product per pair); the geometry mode keeps the "
+                                 "as-coded surrogate's three shifted x.y products (one fp16 plane of the point each) and drops the float16 rounding of the 13 "
+                                 "entries per pair, so that the four sums factor per geometry (13 + 9 + 5 vector instructions + 3 exp per pair against ~50 + 3); "
+                                 "DESIGN.md 4.5") if geometry else
+                                ("achieved = algorithmic flops of SURVEY 8(d) (2 N_inf N (d+1) + 10 N_inf M: ONE x.y product per pair); the as-coded "
+                                 "surrogate needs three (aligned, y shifted, x shifted) in two fp16 planes each, and 13 separately float16-rounded "
+                                 "entries per pair in the epilogue (~50 vector instructions + 3 exp against 14 + 1 for the documented operators): "
+                                 "the launch time is vector time plus matrix time: the chip's clock follows the MFMA density, so every instruction of either kind is paid "
+                                 "for in time (valu_issue, vector; DESIGN.md 4.4)")}
         else:
             split = int(gp.eval_split)
             products = {0: 1, 2: 3, 3: 6, 22: 2 if getattr(gp, "_colloc_is_f16", False) else 3}[split]

@@ -361,8 +361,8 @@ struct Walker {
             // ACCUMULATE reads the stored X_T back: the rows of the next kAhead samples are requested before this one is
             // consumed (one dependent HBM round trip per sample otherwise; the pass is bound by the bytes it keeps in flight)
             const bool readback = MODE == SCASML_MODE_ACCUMULATE && vol >= kReadbackMinVol;
-            // (the queue exists in ACCUMULATE only: as plain arrays in every mode they survived as a dead 36-byte stack object of the MLP and
-            // GENERATE kernels from level 3 on -- private segment enabled for nothing, profiles/r03_kernel_by_grid.txt)
+            // (the queue exists in ACCUMULATE only.  The 36 bytes of scratch rocprof reports for the level-3 / level-4 MLP and GENERATE kernels are
+            // not these arrays but the stack slot of six spilled SGPRs -- v_writelane / v_readlane, no scratch instruction: DESIGN.md 4.1)
             PrefetchQueue<MODE == SCASML_MODE_ACCUMULATE> pq;
             if constexpr (MODE == SCASML_MODE_ACCUMULATE) {
 #pragma unroll
