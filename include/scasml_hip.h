@@ -347,7 +347,14 @@ int scasml_gp_gradient_compat(int32_t d, double a, const double *colloc_t, int32
  *   scasml_gp_compat_pack_mfma     per (tile, geometry): fp16 A fragments of the shifted rows, the Hutchinson fragment, 8 row constants
  *   scasml_gp_eval_compat_sites    out4 / lap as scasml_gp_eval_compat; rows_per_site / site_kinds as scasml_gp_eval_sites
  *                                  (site_kinds may be NULL: every row gets everything).  A 128-row workgroup runs the geometries
- *                                  its sites need: all three where eps_PDE is consumed, two where only u_hat (and div) are. */
+ *                                  its sites need: all three where eps_PDE is consumed, two where only u_hat (and div) are.
+ *                                  round16 here: bit 0 = every entry rounded to float16 (the reference's code, models/GP.py:43, 55-179);
+ *                                  bit 1 = u_hat and eps_PDE leave as float16 values (:671, 769); with bit 0 OFF the kernel runs the
+ *                                  GEOMETRY mode -- the same sixteen entries in the same three geometries, not rounded, so that the four
+ *                                  sums factor per geometry (GP(compat="reference-geometry"); 1.5x faster, relative L2 of the solvers
+ *                                  within 3e-5 of the as-coded mode on the reference's experiments) -- and bit 2 then lets the evaluation
+ *                                  point enter x.y as ONE float16 plane (kappa moves by <= 3.5e-5 relative; half the MFMAs).  3 = the
+ *                                  reference's code, 6 = the geometry mode as GP uses it; bit 2 with bit 0 is refused. */
 int64_t scasml_gp_compat_model_floats(int32_t d, int32_t n_pad);
 int scasml_gp_compat_pack_mfma(int32_t d, float a, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy,
                                const double *rv, const int32_t *idx_h, float *model_out, void *stream);

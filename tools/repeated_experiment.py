@@ -59,13 +59,14 @@ def run_case(d, train_seed, idx, reps, compat, rng=None):
     from scasml_gp_amd.solvers.ScaSML_full_history import ScaSML_full_history
     np.random.seed(train_seed)                                   # experiment_run.py:32 (1234)
     eq = Grad_Dependent_Nonlinear(d + 1)
-    gp = GP_Grad_Dependent_Nonlinear(eq, compat="reference", laplacian_idx=idx) if compat else GP_Grad_Dependent_Nonlinear(eq, compat=None)
+    gp = GP_Grad_Dependent_Nonlinear(eq, compat=compat if isinstance(compat, str) else "reference", laplacian_idx=idx) if compat \
+        else GP_Grad_Dependent_Nonlinear(eq, compat=None)
     dom, bdy = eq.generate_data(1000, 200)
     t0 = time.time()
     gp.GPsolver(dom, bdy, GN_steps=20)
     torch.cuda.synchronize()
     t_fit = time.time() - t0
-    kw = {"compat_crn": compat, "compat_f16": compat}        # the reference's key reuse and its solver-level float16 casts
+    kw = {"compat_crn": bool(compat), "compat_f16": bool(compat)}        # the reference's key reuse and its solver-level float16 casts
     kq = dict(kw, compat_rng=rng)                             # --rng jax: the solvers on the reference's own normals, uniform times and key schedule
     solvers = {"MLP": MLP(eq, **kq), "ScaSML": ScaSML(eq, gp, **kq),
                "MLP_fh": MLP_full_history(eq, **kq), "ScaSML_fh": ScaSML_full_history(eq, gp, **kq)}
@@ -95,7 +96,7 @@ def run_case(d, train_seed, idx, reps, compat, rng=None):
             acc[k].append(mq[k])
         for k in ("MLP_fh", "ScaSML_fh"):
             acc[k].append(mf[k])
-    row = {"d": d, "train_seed": train_seed, "compat": "reference" if compat else None, "rng": rng or "philox", "idx": None if idx is None else [int(i) for i in idx],
+    row = {"d": d, "train_seed": train_seed, "compat": (compat if isinstance(compat, str) else "reference") if compat else None, "rng": rng or "philox", "idx": None if idx is None else [int(i) for i in idx],
            "gp_fit_s": round(t_fit, 2), "valid_points_min": [int(min(v[0] for v in valid)), int(min(v[1] for v in valid))]}
     for name in NAMES:
         a = np.asarray(acc[name])
@@ -110,7 +111,7 @@ def run_case(d, train_seed, idx, reps, compat, rng=None):
 LOGGED_SIMPLE = {20: (0.1466, 0.1604, 0.0701), 40: (0.1810, 0.2059, 0.0932), 60: (0.2401, 0.2521, 0.1356), 80: (0.2660, 0.2709, 0.1609)}
 
 
-def run_simple_uniform(d, idx, seed=1234, rng=None):
+def run_simple_uniform(d, idx, seed=1234, rng=None, compat="reference"):
     """tests/SimpleUniform.py:46-136: ONE generator stream -- np.random.seed(1234) (experiment_run.py:32), the training set, then
     the test set without reseeding."""
     from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
@@ -119,7 +120,7 @@ def run_simple_uniform(d, idx, seed=1234, rng=None):
     from scasml_gp_amd.solvers.ScaSML import ScaSML
     np.random.seed(seed)
     eq = Grad_Dependent_Nonlinear(d + 1)
-    gp = GP_Grad_Dependent_Nonlinear(eq, compat="reference", laplacian_idx=idx)
+    gp = GP_Grad_Dependent_Nonlinear(eq, compat=compat, laplacian_idx=idx)
     dom, bdy = eq.generate_data(1000, 200)
     gp.GPsolver(dom, bdy)                                   # SimpleUniform.py:81 (GN_steps default 20)
     xt = np.concatenate(eq.generate_test_data(1000, 200), axis=0)
@@ -140,7 +141,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dims", type=int, nargs="+", default=[20, 40, 60, 80])
     ap.add_argument("--reps", type=int, default=10)
-    ap.add_argument("--compat", choices=["reference"], default=None)
+    ap.add_argument("--compat", choices=["reference", "reference-geometry"], default=None,
+                    help="reference: the as-coded surrogate; reference-geometry: the same fit evaluated without the per-entry float16 roundings")
     ap.add_argument("--idx-sets", type=int, default=8, help="random Hutchinson index sets per training set (--compat reference)")
     ap.add_argument("--train-seeds", type=int, nargs="+", default=[1234])
     ap.add_argument("--idx-mode", choices=["random", "original", "partitionable"], default="random",
@@ -155,19 +157,19 @@ def main():
         from scasml_gp_amd.threefry import reference_laplacian_idx
         for d in args.dims:
             idx = reference_laplacian_idx(d, args.idx_mode) if args.idx_mode != "random" else np.random.default_rng(1000).choice(d, 5, replace=False)
-            print(json.dumps(run_simple_uniform(d, idx, rng=None if args.rng == "philox" else args.rng)), flush=True)
+            print(json.dumps(run_simple_uniform(d, idx, rng=None if args.rng == "philox" else args.rng, compat=args.compat or "reference")), flush=True)
     summary = []
     for d in args.dims:
         rows = []
         for ts in args.train_seeds:
             if args.compat and args.idx_mode != "random":
                 from scasml_gp_amd.threefry import reference_laplacian_idx
-                rows.append(run_case(d, ts, reference_laplacian_idx(d, args.idx_mode), args.reps, True, rng=None if args.rng == "philox" else args.rng))
+                rows.append(run_case(d, ts, reference_laplacian_idx(d, args.idx_mode), args.reps, args.compat, rng=None if args.rng == "philox" else args.rng))
                 print(json.dumps(rows[-1]), flush=True)
             elif args.compat:
                 rng = np.random.default_rng(1000 + ts)
                 for _ in range(args.idx_sets):
-                    rows.append(run_case(d, ts, rng.choice(d, 5, replace=False), args.reps, True, rng=None if args.rng == "philox" else args.rng))
+                    rows.append(run_case(d, ts, rng.choice(d, 5, replace=False), args.reps, args.compat, rng=None if args.rng == "philox" else args.rng))
                     print(json.dumps(rows[-1]), flush=True)
             else:
                 rows.append(run_case(d, ts, None, args.reps, False))
