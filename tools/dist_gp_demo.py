@@ -4,6 +4,7 @@
 GPsolver on the same data.  Prints one JSON line per rank 0.
 
     python tools/dist_gp_demo.py --ranks 2 --d 250 --n-dom 8333 --n-bdy 1667      # M = 34 999: BASELINE configs[4], staged
+    python tools/dist_gp_demo.py --compat none ...                                 # the documented operators instead of the as-coded surrogate
 """
 import argparse
 import json
@@ -29,14 +30,20 @@ def worker(rank, world, port, args, q):
     np.random.seed(1234)
     dom, bdy = eq.generate_data(args.n_dom, args.n_bdy)
     xt = np.concatenate(eq.generate_test_data(500, 100))
-    out = {"ranks": world, "d": args.d, "collocation": "%d+%d" % (args.n_dom, args.n_bdy)}
+    compat = None if args.compat == "none" else "reference"
+    out = {"ranks": world, "d": args.d, "collocation": "%d+%d" % (args.n_dom, args.n_bdy), "surrogate": "as coded (compat='reference')" if compat else "documented operators"}
+    say = lambda msg: print("[rank %d, %.0f s] %s" % (rank, time.perf_counter() - t_start, msg), file=sys.stderr, flush=True) if rank == 0 else None
+    t_start = time.perf_counter()
+    probe = GP_Grad_Dependent_Nonlinear(eq, compat=compat)
     cm = Comm()
     # stage timings of the distributed factorisation alone
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    ch = DistCholesky(args.d, 1.0 / (0.25 ** 2 * args.d), dom, bdy, 1e-2, cm).build()
+    ch = DistCholesky(args.d, 1.0 / (0.25 ** 2 * args.d), dom, bdy, 1e-2, cm, compat_idx=probe.laplacian_idx).build()
     torch.cuda.synchronize(); t1 = time.perf_counter()
+    say("Gram rows built")
     ch.factor()
     torch.cuda.synchronize(); t2 = time.perf_counter()
+    say("factored")
     b = torch.from_numpy(np.random.default_rng(0).standard_normal(ch.M)).cuda()
     ch.solve(b)
     torch.cuda.synchronize(); t3 = time.perf_counter()
@@ -47,18 +54,20 @@ def worker(rank, world, port, args, q):
                solve_s=round(t3 - t2, 3), matvec_s=round(t4 - t3, 3), collective_gb_per_rank=round(cm.bytes_moved / 1e9, 2))
     del ch
     torch.cuda.empty_cache()
-    gp = GP_Grad_Dependent_Nonlinear(eq, compat=None)
+    gp = GP_Grad_Dependent_Nonlinear(eq, compat=compat)
     fit = DistributedGP(gp, Comm())
     torch.cuda.synchronize(); t0 = time.perf_counter()
+    say("distributed fit starts")
     fit.fit(dom, bdy, GN_steps=20)
     torch.cuda.synchronize(); t1 = time.perf_counter()
+    say("distributed fit done")
     out.update(fit_s=round(t1 - t0, 2), newton_steps=len(gp.loss_history) - 1, cg_products=fit.cg_iterations,
                loss=[float("%.6g" % v) for v in gp.loss_history], grad_norm_last=gp.grad_norms[-1])
     pred = gp.predict(xt)
     exact = eq.exact_solution(xt)
     out["gp_rel_l2"] = round(float(np.linalg.norm(pred - exact) / np.linalg.norm(exact)), 4)
     if rank == 0 and not args.no_single:
-        one = GP_Grad_Dependent_Nonlinear(eq, compat=None)
+        one = GP_Grad_Dependent_Nonlinear(eq, compat=compat)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         one.GPsolver(dom, bdy, GN_steps=20)
         torch.cuda.synchronize(); t1 = time.perf_counter()
@@ -78,6 +87,9 @@ def main():
     ap.add_argument("--n-dom", type=int, default=8333)
     ap.add_argument("--n-bdy", type=int, default=1667)
     ap.add_argument("--no-single", action="store_true")
+    ap.add_argument("--compat", choices=["reference", "none"], default="reference",
+                    help="reference (default): the as-coded surrogate -- Gram rows of scasml_gp_gram_compat_rows, the float16-rounded matrix solved by a second "
+                         "distributed factorisation; none: the documented operators")
     args = ap.parse_args()
     import socket
     import torch.multiprocessing as mp
