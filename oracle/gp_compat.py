@@ -104,15 +104,20 @@ class OracleGPCompat(OracleGP):
     # ---------------------------------------------------------------- float16 op sequence of kappa and its first derivatives
     def _f16_first_order(self, opx, opy, X, Y):
         """kappa = exp(-sum((x - y)**2) / (2 sigma**2)).astype(float16) (models/GP.py:41-43) on float16 rows: every operation rounds to
-        float16 (jnp.sum accumulates in float32 and rounds once; exp and the division are float32 operations on float16 operands,
-        rounded); 2 sigma**2 is a weakly typed scalar, i.e. float16(d / 8).  grad(kappa) (:55-57, 65-67) is reverse mode through the same
-        graph: cotangent 1 -> exp: kappa16 -> division: t1 = float16(kappa16 / c16) -> negation -> broadcast over the sum -> square:
-        float16(-t1 * (2 r_k)) -> the subtraction: +/-.  dt_* picks component d (:59-63, 69-73); div_* is the float16 sum (float32
-        accumulation) of the d spatial components, each already rounded (:75-85)."""
+        float16 (jnp.sum accumulates in float32 and rounds once; exp is a float32 operation on a float16 operand, rounded); 2 sigma**2 is a
+        weakly typed scalar, i.e. the float16 constant c16 = float16(d / 8), and the division by a constant reaches the device as a
+        MULTIPLICATION by the constant's reciprocal, float16(1 / c16) (XLA's algebraic simplifier: A / Const => A * (1 / Const)).  The logs
+        decide between the two readings: GP relative L2 minus SimpleUniform.log:4 at d = 20 / 40 / 60 / 80 is +1.3e-5 / -1.6e-6 / -1.6e-5 /
+        -2.5e-5 with the reciprocal and -1.5e-5 / -6.2e-5 / +8.6e-5 / -1.0e-5 with a true division (one rounding per entry: +3.65e-5 / -1.05e-4
+        / -1.3e-5 / +4.4e-5; tests/studies/f16_graph_study.py).  grad(kappa) (:55-57, 65-67) is reverse mode through the same graph: cotangent
+        1 -> exp: kappa16 -> division: t1 = float16(kappa16 * inv16) -> negation -> broadcast over the sum -> square: float16(-t1 * (2 r_k))
+        -> the subtraction: +/-.  dt_* picks component d (:59-63, 69-73); div_* is the float16 sum (float32 accumulation) of the d spatial
+        components, each already rounded (:75-85)."""
         F16, F32 = np.float16, np.float32
         d = self.d
         X16, Y16 = np.asarray(X).astype(F16), np.asarray(Y).astype(F16)
         c16 = F16(2.0 * float(self.s2))
+        inv16 = F16(F32(1.0) / F32(c16))                   # the folded constant 1 / c16, a float16 value
         out = np.empty((X16.shape[0], Y16.shape[0]))
         sign = 1.0 if opx != "I" else -1.0                 # g below is d/dx; d/dy = -d/dx exactly (a negation of float16 values)
         op = opx if opx != "I" else opy
@@ -120,12 +125,12 @@ class OracleGPCompat(OracleGP):
             r = X16[i0:i0 + 128, None, :] - Y16[None, :, :]                       # float16 subtraction
             sq = r * r                                                             # float16 product
             S = sq.astype(F32).sum(axis=2, dtype=F32).astype(F16)
-            q = ((-S).astype(F32) / F32(c16)).astype(F16)
+            q = ((-S).astype(F32) * F32(inv16)).astype(F16)
             kap = np.exp(q.astype(np.float64)).astype(F32).astype(F16)
             if op == "I":
                 out[i0:i0 + 128] = kap.astype(np.float64)
                 continue
-            t1 = (kap.astype(F32) / F32(c16)).astype(F16)
+            t1 = (kap.astype(F32) * F32(inv16)).astype(F16)
             if op == "dt":
                 g = ((-t1).astype(F32) * (F16(2.0) * r[:, :, d]).astype(F32)).astype(F16)
             else:                                          # "div": float16 sum of the d rounded spatial components
