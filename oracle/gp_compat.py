@@ -37,8 +37,12 @@ and the Laplacian-free blocks are those of oracle/gp.py.  Arithmetic inside an e
 with ONE rounding to float16 at the end.  That is what JAX computes on float64 rows (every tree point below a solver's root call).
 On float16 rows -- the collocation points, the harness's test points -- the reference's kernels are float16 arithmetic
 throughout (``self.sigma`` is weakly typed), and its first-order blocks are reverse-mode autodiff THROUGH that arithmetic;
-``f16_graph=True`` follows that op sequence for kappa and the four first-order blocks (``_f16_first_order``; models/GP.py:41-85).
-The second-order and Hutchinson blocks (autodiff of autodiff) keep one rounding per entry.
+``f16_graph=1`` (or True) follows that op sequence for kappa and the four first-order blocks (``_f16_first_order``; models/GP.py:41-85),
+``f16_graph=2`` also for the four dt / div second-order blocks (``_f16_second_order``: reverse mode over reverse mode, :107-139) -- the level the
+logs support best: GP relative L2 within 1.7e-5 of SimpleUniform.log:4 at all four dimensions (2.9e-6, 5.8e-6 at d = 20, 40).  ``f16_graph=3``
+adds lap_y kappa and lap_x kappa (``_f16_hutchinson``); the logs do not decide for it (relative L2 1.2e-5 .. 3.2e-5 away, but three of the four
+logged L1 maxima to <= 1 float16 ulp, two exactly), so it stays exploratory.  The third- and fourth-order Hutchinson blocks keep one rounding
+per entry at every level.
 """
 import numpy as np
 
@@ -67,9 +71,9 @@ class OracleGPCompat(OracleGP):
 
     def __init__(self, eq, idx, round16=True, round_factor=True, round_out=None, f16_graph=False):
         super().__init__(eq)
-        # f16_graph: on float16 rows evaluate kappa and the first-order blocks through the reference's float16 op sequence (module docstring).
+        # f16_graph (0, 1 = True, 2, 3): on float16 rows evaluate kappa and derivative blocks through the reference's float16 op sequence (module docstring).
         # Off by default: the product rounds each entry once, and HIP <-> oracle parity is stated in that arithmetic.
-        self.f16_graph = bool(f16_graph) and bool(round16)
+        self.f16_graph = (int(f16_graph) if f16_graph else 0) if round16 else 0      # 1 / True: kappa + first order; 2: + the dt / div second-order blocks
         self.round_factor = bool(round_factor) and bool(round16)
         # predict / compute_PDE_loss / compute_gradient return .astype(float16) (models/GP.py:671, 687, 769)
         self.round_out = bool(round16) if round_out is None else bool(round_out)
@@ -139,6 +143,70 @@ class OracleGPCompat(OracleGP):
             out[i0:i0 + 128] = sign * g.astype(np.float64)
         return out
 
+    def _f16_second_order(self, opx, opy, X, Y):
+        """dt_x/div_x composed with dt_y/div_y on float16 rows (models/GP.py:107-117, 129-139): ``grad(h, argnums=1)`` of the first-order
+        function h = dt_x kappa (component d of grad_x kappa) or div_x kappa (the float16 sum of its d spatial components) -- reverse mode
+        through the BACKWARD graph of ``_f16_first_order``, every operation again a float16 operation.  With t1 = float16(kappa16 inv16),
+        m_k = 2 r_k (exact), the cotangent of h reaches S as
+            gS = float16(float16(float16(w inv16) kappa16) inv16),   w = m_d (dt_x)  or  sum_{k<d} m_k (div_x; float32 accumulation assumed),
+        and  grad_y h [k] = -float16(-2 t1 [k is differentiated directly: k = d for dt_x, k < d for div_x] + float16(gS m_k)); dt_y picks
+        component d, div_y is the float16 sum (float32 accumulation) of the d spatial components."""
+        F16, F32 = np.float16, np.float32
+        d = self.d
+        X16, Y16 = np.asarray(X).astype(F16), np.asarray(Y).astype(F16)
+        c16 = F16(2.0 * float(self.s2))
+        inv16 = F32(F16(F32(1.0) / F32(c16)))
+        mul = lambda a, b: (a.astype(F32) * (b.astype(F32) if hasattr(b, "astype") else b)).astype(F16)
+        out = np.empty((X16.shape[0], Y16.shape[0]))
+        for i0 in range(0, X16.shape[0], 128):
+            r = X16[i0:i0 + 128, None, :] - Y16[None, :, :]
+            S = (r * r).astype(F32).sum(axis=2, dtype=F32).astype(F16)
+            q = ((-S).astype(F32) * inv16).astype(F16)
+            kap = np.exp(q.astype(np.float64)).astype(F32).astype(F16)
+            t1 = (kap.astype(F32) * inv16).astype(F16)
+            m = F16(2.0) * r                                                     # exact
+            w = m[:, :, d] if opx == "dt" else m[:, :, :d].astype(F32).sum(axis=2, dtype=F32).astype(F16)
+            gS = mul(mul(mul(w, inv16), kap), inv16)
+            two_t1 = F16(2.0) * t1
+            if opy == "dt":
+                b = mul(gS, m[:, :, d])
+                g = (two_t1.astype(F32) - b.astype(F32)).astype(F16) if opx == "dt" else -b
+            else:
+                bk = mul(gS[:, :, None], m[:, :, :d])
+                gk = (two_t1[:, :, None].astype(F32) - bk.astype(F32)).astype(F16) if opx == "div" else -bk
+                g = gk.astype(F32).sum(axis=2, dtype=F32).astype(F16)
+            out[i0:i0 + 128] = g.astype(np.float64)
+        return out
+
+    def _f16_hutchinson(self, opx, opy, X, Y):
+        """lap_y kappa and lap_x kappa on float16 rows (models/GP.py:28-39, 87-105): the mean over the five drawn indices of the Hessian diagonal
+        of kappa in the SHIFTED argument, times d -- each diagonal entry reverse mode over reverse mode through kappa's float16 graph (as
+        ``_f16_second_order`` with both derivatives along component i):  H_i = float16(float16(gS_i m_i) - 2 t1),  gS_i = float16(float16(
+        float16(m_i inv16) kappa16) inv16); jnp.mean accumulates in float32 and rounds once; the product with the weakly typed d is float16."""
+        F16, F32 = np.float16, np.float32
+        d = self.d
+        X16, Y16 = np.asarray(X).astype(F16), np.asarray(Y).astype(F16)
+        if opx == "lap":
+            X16 = np.roll(X16, -1, axis=1)                                        # geometry xs: r = x' - y
+        else:
+            Y16 = np.roll(Y16, -1, axis=1)                                        # geometry ys: r = x - y'
+        c16 = F16(2.0 * float(self.s2))
+        inv16 = F32(F16(F32(1.0) / F32(c16)))
+        mul = lambda a, b: (a.astype(F32) * (b.astype(F32) if hasattr(b, "astype") else b)).astype(F16)
+        out = np.empty((X16.shape[0], Y16.shape[0]))
+        for i0 in range(0, X16.shape[0], 128):
+            r = X16[i0:i0 + 128, None, :] - Y16[None, :, :]
+            S = (r * r).astype(F32).sum(axis=2, dtype=F32).astype(F16)
+            q = ((-S).astype(F32) * inv16).astype(F16)
+            kap = np.exp(q.astype(np.float64)).astype(F32).astype(F16)
+            t1 = (kap.astype(F32) * inv16).astype(F16)
+            mi = F16(2.0) * r[:, :, self.idx]                                    # (n, m, 5), exact
+            gS = mul(mul(mul(mi, inv16), kap[:, :, None]), inv16)
+            H = (mul(gS, mi).astype(F32) - (F16(2.0) * t1)[:, :, None].astype(F32)).astype(F16)
+            mean = (H.astype(F32).sum(axis=2, dtype=F32) / F32(self.MC)).astype(F16)
+            out[i0:i0 + 128] = (mean.astype(F32) * F32(d)).astype(F16).astype(np.float64)
+        return out
+
     def block(self, opx, opy, X, Y):
         a, d = self.a, self.d
         key = (opx, opy)
@@ -146,6 +214,14 @@ class OracleGPCompat(OracleGP):
             Xa, Ya = np.asarray(X, dtype=np.float64), np.asarray(Y, dtype=np.float64)
             if np.array_equal(Xa, f16(Xa)) and np.array_equal(Ya, f16(Ya)):
                 return self._f16_first_order(opx, opy, Xa, Ya)
+        if self.f16_graph == 2 and key in (("dt", "dt"), ("dt", "div"), ("div", "dt"), ("div", "div")):
+            Xa, Ya = np.asarray(X, dtype=np.float64), np.asarray(Y, dtype=np.float64)
+            if np.array_equal(Xa, f16(Xa)) and np.array_equal(Ya, f16(Ya)):
+                return self._f16_second_order(opx, opy, Xa, Ya)
+        if self.f16_graph == 3 and key in (("I", "lap"), ("lap", "I"), ("dt", "dt"), ("dt", "div"), ("div", "dt"), ("div", "div")):
+            Xa, Ya = np.asarray(X, dtype=np.float64), np.asarray(Y, dtype=np.float64)
+            if np.array_equal(Xa, f16(Xa)) and np.array_equal(Ya, f16(Ya)):
+                return self._f16_hutchinson(opx, opy, Xa, Ya) if "lap" in key else self._f16_second_order(opx, opy, Xa, Ya)
         if "lap" not in key:
             return self._r(super().block(opx, opy, X, Y))
         h = d / float(self.MC)

@@ -2,6 +2,8 @@
 weakly typed constant, or the multiplication by the folded reciprocal that XLA's algebraic simplifier emits for a division by a constant?
 GP relative L2 of oracle/gp_compat.py (f16_graph=True) against results/**/SimpleUniform.log:4 at d = 20, 40, 60, 80.  About three minutes.
     python tests/studies/f16_graph_study.py
+(The study below is level 1 -- kappa and the first-order blocks; levels 2 and 3 of OracleGPCompat(f16_graph=...) were measured the same way:
+ -2.9e-6 / +5.8e-6 / -1.5e-5 / -1.7e-5 and +1.3e-5 / -1.9e-5 / -3.2e-5 / -1.2e-5.)
 Result (round 4): reciprocal +1.3e-5 / -1.6e-6 / -1.6e-5 / -2.5e-5; division -1.5e-5 / -6.2e-5 / +8.6e-5 / -1.0e-5; L1 max with the reciprocal
 0.354980 / 0.400879 / 0.383301 / 0.361328 against the logged 0.354492 / 0.400391 / 0.383545 / 0.361328."""
 import sys, os, time, json

@@ -80,24 +80,25 @@ def test_oracle_gp_reproduces_the_logged_single_run_at_every_dimension(d):
 
 
 @pytest.mark.parametrize("d", [20, 40])
-def test_oracle_float16_graph_of_kappa_and_first_order_blocks(d):
+def test_oracle_float16_graph_of_kappa_first_and_second_order_blocks(d):
     """On float16 rows the reference's kernels are float16 arithmetic throughout and its first-order blocks reverse-mode autodiff through it
-    (models/GP.py:41-85); OracleGPCompat(f16_graph=True) follows that op sequence for kappa, dt_x/dt_y kappa and div_x/div_y kappa (9 of the 25
-    Gram blocks, 4 of the 5 feature rows of predict), the division by 2 sigma^2 as XLA emits it (a multiplication by the folded reciprocal).  GP
-    relative L2 against SimpleUniform.log:4: +3.65e-5 / -1.05e-4 with one rounding per entry, +1.3e-5 / -1.6e-6 with the graph at d = 20 / 40
-    (-1.6e-5, -2.5e-5 at d = 60, 80: tests/studies/f16_graph_study.py); bound 2e-5 (VERDICT r3 item 4 asked for 5e-5 at d = 20)."""
+    (models/GP.py:41-85), its dt / div second-order blocks reverse mode over reverse mode (:107-139); OracleGPCompat(f16_graph=2) follows that op
+    sequence for the nine Laplacian-free operator pairs (16 of the 25 Gram blocks, 4 of the 5 feature rows of predict), the division by 2 sigma^2
+    as XLA emits it (a multiplication by the folded reciprocal).  GP relative L2 against SimpleUniform.log:4: +3.65e-5 / -1.05e-4 with one
+    rounding per entry, -2.9e-6 / +5.8e-6 with the graph at d = 20 / 40 (-1.5e-5, -1.7e-5 at d = 60, 80: tests/studies/f16_graph_study.py);
+    bound 1e-5 (VERDICT r3 item 4 asked for 5e-5 at d = 20)."""
     from oracle.equation import GradDependentNonlinear, deepxde_points, logistic_wave_f16
     from oracle.gp_compat import OracleGPCompat
     from scasml_gp_amd.threefry import reference_laplacian_idx
     np.random.seed(1234)
     dom, bdy = deepxde_points(d, 1000, 200)
     xt = np.concatenate(deepxde_points(d, 1000, 200))
-    gp = OracleGPCompat(GradDependentNonlinear(d + 1), reference_laplacian_idx(d, "partitionable"), f16_graph=True)
+    gp = OracleGPCompat(GradDependentNonlinear(d + 1), reference_laplacian_idx(d, "partitionable"), f16_graph=2)
     gp.GPsolver(dom.astype(np.float64), bdy.astype(np.float64), GN_steps=20)
     ex = logistic_wave_f16(xt).astype(np.float64)[:, 0]
     err = np.abs(gp.predict(xt.astype(np.float64))[:, 0] - ex)
     head = simple_head(d)
-    assert abs(np.linalg.norm(err) / np.linalg.norm(ex) - head["GP rel L2, rho=2"]) <= 2e-5
+    assert abs(np.linalg.norm(err) / np.linalg.norm(ex) - head["GP rel L2, rho=2"]) <= 1e-5
     assert abs(err.max() - head["GP L1, rho=2"]["max"]) <= 3 * 2.0 ** -12        # two float16 ulps of 0.35 .. 0.40
     assert abs(err.mean() - head["GP L1, rho=2"]["mean"]) <= 3e-4 * head["GP L1, rho=2"]["mean"]
     if d != 20:
@@ -105,10 +106,10 @@ def test_oracle_float16_graph_of_kappa_and_first_order_blocks(d):
     # the graph differs from one-rounding-per-entry where it should: the first-order blocks on float16 rows, by a few float16 ulps; and not elsewhere
     one = OracleGPCompat(GradDependentNonlinear(d + 1), reference_laplacian_idx(d, "partitionable"))
     X, Y = dom[:64].astype(np.float64), dom[64:192].astype(np.float64)
-    for key in (("I", "I"), ("dt", "I"), ("I", "dt"), ("div", "I"), ("I", "div")):
+    for key in (("I", "I"), ("dt", "I"), ("I", "dt"), ("div", "I"), ("I", "div"), ("dt", "dt"), ("dt", "div"), ("div", "dt"), ("div", "div")):
         a, b = gp.block(key[0], key[1], X, Y), one.block(key[0], key[1], X, Y)
         assert np.array_equal(a.astype(np.float16).astype(np.float64), a)
-        assert np.abs(a - b).max() <= (2.0 ** -7 if "div" in key else 2.0 ** -8) * np.abs(b).max() and (a != b).any(), key
+        assert np.abs(a - b).max() <= 2.0 ** -7 * np.abs(b).max() and (a != b).any(), key
     assert np.array_equal(gp.block("I", "dt", X, Y), -gp.block("dt", "I", X, Y))
     assert np.array_equal(gp.block("lap", "I", X, Y), one.block("lap", "I", X, Y))
     Xf = X + 1e-4                                                      # not float16 rows: one rounding per entry IS what JAX computes
