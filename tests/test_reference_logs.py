@@ -79,7 +79,7 @@ def test_oracle_gp_reproduces_the_logged_single_run_at_every_dimension(d):
     assert abs(err.max() - head["GP L1, rho=2"]["max"]) <= 5e-3 * head["GP L1, rho=2"]["max"]
 
 
-@pytest.mark.parametrize("d", [20, 40])
+@pytest.mark.parametrize("d", [20])          # d = 40 (+5.8e-6) and 60, 80 are in tests/studies/f16_graph_study.py: 40 s of CPU each
 def test_oracle_float16_graph_of_kappa_first_and_second_order_blocks(d):
     """On float16 rows the reference's kernels are float16 arithmetic throughout and its first-order blocks reverse-mode autodiff through it
     (models/GP.py:41-85), its dt / div second-order blocks reverse mode over reverse mode (:107-139); OracleGPCompat(f16_graph=2) follows that op
