@@ -146,7 +146,7 @@ def test_what_a_site_consumes_does_not_depend_on_the_form_its_workgroup_ran():
             assert np.array_equal(part32[sl, 1], full32[sl, 1])
 
 
-@pytest.mark.parametrize("d,idx,nd,nb", [CASES[0], CASES[2], CASES[3]])
+@pytest.mark.parametrize("d,idx,nd,nb", CASES)
 def test_geometry_mode_factored_sums_in_every_site_form(d, idx, nd, nb):
     """compat="reference-geometry" (round16 bit 0 off): the factored epilogue, per site form.  Every form's outputs against the float64
     statement without entry rounding, and what a site consumes is the same number in whichever form its workgroup ran -- to float32
@@ -182,6 +182,11 @@ def test_geometry_mode_factored_sums_in_every_site_form(d, idx, nd, nb):
     one, _ = _raw(gp, X, round16=4)
     assert np.all(np.abs(one[:, 0] - two[:, 0]) <= loose * mag["I"] + 1e-6)
     assert np.abs(one[:, 0] - two[:, 0]).max() > 0.0
+    # ragged batches: a row's result does not depend on how many rows follow it (the last workgroup and wave are partly shadow rows)
+    for n_rows in (1, 33, 333):
+        part, lap_part = _raw(gp, X[:n_rows], round16=6)
+        whole, lap_whole = _raw(gp, X, round16=6)
+        assert np.array_equal(part, whole[:n_rows]) and np.array_equal(lap_part, lap_whole[:n_rows]), n_rows
     # the as-coded form refuses the one-plane option
     from scasml_gp_amd import _lib
     with pytest.raises(_lib.ScasmlError):
