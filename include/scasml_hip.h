@@ -311,7 +311,10 @@ int scasml_gp_newton_jtv(int32_t eq_id, int32_t d, double sigma, double mu, cons
  *   idx_h   : the five Hutchinson indices, HOST int32[5], distinct, 0 <= i < d.  The reference draws them with
  *             random.choice(PRNGKey(0), d, (5,), replace=False) -- JAX threefry, not reproducible without JAX -- so they are
  *             an argument.  Index i differentiates along component i of the SHIFTED vector (original coordinate i+1).
- *   round16 : bit 0 rounds every kernel entry to float16 (RNE) before it is stored / used; bit 1 (evaluation only) also returns
+ *   round16 : bit 2 (Gram, Gram rows and scasml_gp_eval_compat; the caller vouches that the collocation rows are float16 values) evaluates the nine
+ *             Laplacian-free operator pairs on float16 rows through the reference's float16 op sequence -- kappa in float16 arithmetic, its
+ *             derivative kernels reverse-mode autodiff through it (models/GP.py:41-85, 107-139) -- instead of one rounding per entry;
+ *             bit 0 rounds every kernel entry to float16 (RNE) before it is stored / used; bit 1 (evaluation only) also returns
  *             u_hat and eps_PDE as float16 values, as predict / compute_PDE_loss do (.astype(float16), models/GP.py:671, 769;
  *             eps_PDE is then formed from the rounded u_hat).
  * scasml_gp_gram_compat   K(phi, phi), same block order as scasml_gp_gram              (models/GP.py:182-258)

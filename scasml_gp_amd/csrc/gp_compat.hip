@@ -126,6 +126,66 @@ __device__ __forceinline__ void compat_blocks(int d, double a, const PairGeom &g
         for (int j = 0; j < 4; ++j) P[i][j] = round16(P[i][j], r16);
 }
 
+// ---- the reference's FLOAT16 ARITHMETIC on float16 rows (round16 bit 2; GP(f16_graph=True); oracle: OracleGPCompat(f16_graph=2)) ------------
+// On float16 rows (the collocation points, the harness's test points) kappa = exp(-sum((x - y)**2) / (2 sigma**2)) is float16 arithmetic
+// throughout -- self.sigma is weakly typed (models/GP.py:25, 41-43) -- and the derivative kernels are reverse-mode autodiff THROUGH it (:55-85;
+// the dt / div second-order blocks reverse over reverse, :107-139).  This restates that op sequence for the nine Laplacian-free operator pairs:
+//   r_k = f16(x_k - y_k); S = f16(sum_f32 f16(r_k^2)); q = f16(-S inv16); kappa16 = f16(exp(q)); t1 = f16(kappa16 inv16); m_k = 2 r_k
+//   d/dx_k kappa = f16(-t1 m_k);  div_x = f16(sum_f32 over k < d);  d/dy = -d/dx
+//   second order, h = dt_x or div_x of kappa, w = m_d or f16(sum_f32 m_k):  gS = f16(f16(f16(w inv16) kappa16) inv16),
+//   grad_y h [k] = -f16(-2 t1 [k differentiated directly] + f16(gS m_k));  dt_y picks k = d, div_y is the float16 sum over k < d.
+// inv16 = f16(1 / f16(2 sigma^2)): the division by the constant reaches the device as a multiplication by its folded reciprocal (XLA's
+// algebraic simplifier); the reference's logged GP errors decide for this reading (tests/studies/f16_graph_study.py).
+// The Hutchinson blocks keep one rounding per entry (compat_blocks).  Float32 accumulations run in index order.
+__device__ __forceinline__ _Float16 hmul(_Float16 a, _Float16 b) { return (_Float16)((float)a * (float)b); }   // exact product, one rounding
+
+template <class FX, class FY>
+__device__ __forceinline__ void f16_graph_blocks(int d, double a, FX x, FY y, double (&P)[4][4]) {
+    const _Float16 c16 = (_Float16)(2.0 / a);
+    const _Float16 inv16 = (_Float16)(1.0f / (float)c16);
+    float Sf = 0.0f;
+    for (int k = 0; k <= d; ++k) {
+        const _Float16 r = (_Float16)x(k) - (_Float16)y(k);
+        Sf += (float)(r * r);
+    }
+    const _Float16 S = (_Float16)Sf;
+    const _Float16 q = hmul(-S, inv16);
+    const _Float16 kap = (_Float16)(float)exp((double)q);
+    const _Float16 t1 = hmul(kap, inv16);
+    const _Float16 two_t1 = (_Float16)2.0f * t1;
+    float sum_m = 0.0f, sum_dx = 0.0f;
+    for (int k = 0; k < d; ++k) {
+        const _Float16 m = (_Float16)2.0f * ((_Float16)x(k) - (_Float16)y(k));
+        sum_m += (float)m;
+        sum_dx += (float)hmul(-t1, m);
+    }
+    const _Float16 m_d = (_Float16)2.0f * ((_Float16)x(d) - (_Float16)y(d));
+    const _Float16 dx_d = hmul(-t1, m_d), div_x = (_Float16)sum_dx;
+    auto to_S = [&](_Float16 w) { return hmul(hmul(hmul(w, inv16), kap), inv16); };
+    const _Float16 gS_dt = to_S(m_d), gS_div = to_S((_Float16)sum_m);
+    float s_dtdiv = 0.0f, s_divdiv = 0.0f;
+    for (int k = 0; k < d; ++k) {
+        const _Float16 m = (_Float16)2.0f * ((_Float16)x(k) - (_Float16)y(k));
+        s_dtdiv += (float)(-hmul(gS_dt, m));
+        s_divdiv += (float)(_Float16)((float)two_t1 - (float)hmul(gS_div, m));
+    }
+    P[0][0] = (double)kap;
+    P[2][0] = (double)dx_d;
+    P[0][2] = -(double)dx_d;
+    P[3][0] = (double)div_x;
+    P[0][3] = -(double)div_x;
+    P[2][2] = (double)(_Float16)((float)two_t1 - (float)hmul(gS_dt, m_d));
+    P[2][3] = (double)(_Float16)s_dtdiv;
+    P[3][2] = -(double)hmul(gS_div, m_d);
+    P[3][3] = (double)(_Float16)s_divdiv;
+}
+template <class FX>
+__device__ __forceinline__ bool row_is_f16(int d, FX x) {
+    bool ok = true;
+    for (int k = 0; k <= d; ++k) ok = ok && (double)(float)(_Float16)x(k) == (double)x(k);
+    return ok;
+}
+
 // ---------------------------------------------------------------------------------- Gram (models/GP.py:182-258)
 __global__ void gp_gram_compat_kernel(int d, double a, const float *x_dom, int n_dom, const float *x_bdy, int n_bdy,
                                       CompatIdx ix, int r16, double *K) {
@@ -139,7 +199,8 @@ __global__ void gp_gram_compat_kernel(int d, double a, const float *x_dom, int n
     PairGeom g;
     pair_geometry(d, a, ix, [&](int k) { return (double)xi[k]; }, [&](int k) { return (double)yj[k]; }, g);
     double P[4][4];
-    compat_blocks(d, a, g, r16, P);
+    compat_blocks(d, a, g, r16 & 1, P);
+    if (r16 & 4) f16_graph_blocks(d, a, [&](int k) { return xi[k]; }, [&](int k) { return yj[k]; }, P);   // the caller vouches for float16 rows
     const int nops_i = i < n_dom ? 4 : 1, nops_j = j < n_dom ? 4 : 1;
     for (int ox = 0; ox < nops_i; ++ox) {
         const int64_t row = ox == 0 ? i : (int64_t)n_dom + n_bdy + (int64_t)(ox - 1) * n_dom + i;
@@ -165,7 +226,8 @@ __global__ void gp_gram_compat_rows_kernel(int d, double a, const float *x_dom, 
     PairGeom g;
     pair_geometry(d, a, ix, [&](int k) { return (double)xi[k]; }, [&](int k) { return (double)yj[k]; }, g);
     double P[4][4];
-    compat_blocks(d, a, g, r16, P);
+    compat_blocks(d, a, g, r16 & 1, P);
+    if (r16 & 4) f16_graph_blocks(d, a, [&](int k) { return xi[k]; }, [&](int k) { return yj[k]; }, P);
     const int nops_j = j < n_dom ? 4 : 1;
     for (int oy = 0; oy < nops_j; ++oy) {
         const int64_t col = oy == 0 ? j : (int64_t)N + (int64_t)(oy - 1) * n_dom + j;
@@ -206,12 +268,16 @@ __global__ __launch_bounds__(256) void gp_eval_compat_kernel(int d, double a, do
     for (int k = lane; k < D; k += 64) xs[k] = (double)points[row * kp + k];
     __syncthreads();
     const int N = n_dom + n_bdy;
+    // round16 bit 2: on a float16 evaluation row (the collocation points are float16: the caller vouches) the Laplacian-free entries follow the
+    // reference's float16 op sequence (f16_graph_blocks)
+    const bool graph = (r16 & 4) && row_is_f16(d, [&](int k) { return xs[k]; });
     double acc[4] = {0.0, 0.0, 0.0, 0.0};   // I, lap, dt, div applied in x
     for (int j = lane; j < N; j += 64) {
         PairGeom g;
         pair_geometry(d, a, ix, [&](int k) { return xs[k]; }, [&](int k) { return colloc_t[(int64_t)k * ldc + j]; }, g);
         double P[4][4];
         compat_blocks(d, a, g, r16 & 1, P);
+        if (graph) f16_graph_blocks(d, a, [&](int k) { return xs[k]; }, [&](int k) { return colloc_t[(int64_t)k * ldc + j]; }, P);
         const double c0 = rv[j];
         double cL = 0.0, ct = 0.0, cS = 0.0;
         if (j < n_dom) {

@@ -100,13 +100,14 @@ def owned_blocks(nblk, rank, world):
 class DistCholesky:
     """K(phi, phi) + nugget I, block-row distributed: build(), factor(), solve(b)."""
 
-    def __init__(self, d, a, x_dom, x_bdy, nugget, comm=None, compat_idx=None, round_diag=False):
+    def __init__(self, d, a, x_dom, x_bdy, nugget, comm=None, compat_idx=None, round_diag=False, f16_graph=False):
         """compat_idx: the five Hutchinson indices -> the Gram AS CODED by the reference (shifted blocks, float16 entries:
         scasml_gp_gram_compat_rows); round_diag: the diagonal of K + nugget I rounded to float16 as well, i.e. the matrix
         kernel_phi_phi_perturb.astype(float16) of models/GP.py:268 that the right_vector solve of :599 uses."""
         torch = _lib.require_gpu()
         self.compat_idx = None if compat_idx is None else np.ascontiguousarray(np.asarray(compat_idx, dtype=np.int32))
         self.round_diag = bool(round_diag)
+        self.gram_bits = 1 | (4 if f16_graph else 0)       # scasml_gp_gram_compat_rows: bit 2 = the float16 op sequence on float16 rows (GP(f16_graph=True))
         self.lib = _lib.load()
         self.comm = comm or Comm()
         self.d, self.a, self.nugget = int(d), float(a), float(nugget)
@@ -145,7 +146,7 @@ class DistCholesky:
             ncols = min((i + 1) * BLK, self.M)
             if self.compat_idx is not None:
                 _lib.check(lib.scasml_gp_gram_compat_rows(self.d, self.a, _lib.ptr(self.xd), self.n_dom, _lib.ptr(self.xb), self.n_bdy,
-                                                          self.compat_idx.ctypes.data_as(C.c_void_p), 1, row0, nrows, ncols,
+                                                          self.compat_idx.ctypes.data_as(C.c_void_p), self.gram_bits, row0, nrows, ncols,
                                                           self._ptr(self.R, slot * BLK, 0, self.Mp), self.Mp, s), "gp_gram_compat_rows")
             else:
                 _lib.check(lib.scasml_gp_gram_rows(self.d, self.a, _lib.ptr(self.xd), self.n_dom, _lib.ptr(self.xb), self.n_bdy, row0, nrows,
@@ -331,7 +332,10 @@ class DistributedGP:
         gp = self.gp
         eq_id, d, sig, mu = int(gp.equation.eq_id), int(gp.d), float(gp.equation.sigma()), float(gp.equation.mu())
         compat_idx = gp.laplacian_idx if getattr(gp, "compat", None) == "reference" else None
-        ch = DistCholesky(d, 1.0 / float(gp.sigma) ** 2, x_t_domain, x_t_boundary, gp.nugget, self.comm, compat_idx=compat_idx).build().factor()
+        xd16, xb16 = np.asarray(x_t_domain, dtype=np.float32), np.asarray(x_t_boundary, dtype=np.float32)
+        graph = bool(getattr(gp, "f16_graph", False)) and compat_idx is not None and \
+            np.array_equal(xd16.astype(np.float16).astype(np.float32), xd16) and np.array_equal(xb16.astype(np.float16).astype(np.float32), xb16)
+        ch = DistCholesky(d, 1.0 / float(gp.sigma) ** 2, x_t_domain, x_t_boundary, gp.nugget, self.comm, compat_idx=compat_idx, f16_graph=graph).build().factor()
         self.chol = ch
         N, Nb, M = ch.n_dom, ch.n_bdy, ch.M
         bdy_g = torch.as_tensor(np.asarray(gp.bdy_g(np.asarray(x_t_boundary)), dtype=np.float64), device="cuda").contiguous()
@@ -415,7 +419,7 @@ class DistributedGP:
             ch.diag = [None] * ch.nblk
             torch.cuda.empty_cache()
             ch2 = DistCholesky(d, 1.0 / float(gp.sigma) ** 2, x_t_domain, x_t_boundary, gp.nugget, self.comm, compat_idx=compat_idx,
-                               round_diag=True).build().factor()
+                               round_diag=True, f16_graph=graph).build().factor()
             rv = ch2.solve(b)
             self.chol = ch2
         gp.N_domain, gp.N_boundary, gp.phi_dim = N, Nb, M

@@ -49,6 +49,9 @@ def metrics(sols, exact):
     return out
 
 
+F16_GRAPH = False      # --f16-graph: GP(f16_graph=True), the reference's float16 arithmetic on float16 rows (fit and predict)
+
+
 def run_case(d, train_seed, idx, reps, compat, rng=None):
     import torch
     from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
@@ -59,7 +62,7 @@ def run_case(d, train_seed, idx, reps, compat, rng=None):
     from scasml_gp_amd.solvers.ScaSML_full_history import ScaSML_full_history
     np.random.seed(train_seed)                                   # experiment_run.py:32 (1234)
     eq = Grad_Dependent_Nonlinear(d + 1)
-    gp = GP_Grad_Dependent_Nonlinear(eq, compat=compat if isinstance(compat, str) else "reference", laplacian_idx=idx) if compat \
+    gp = GP_Grad_Dependent_Nonlinear(eq, compat=compat if isinstance(compat, str) else "reference", laplacian_idx=idx, f16_graph=F16_GRAPH) if compat \
         else GP_Grad_Dependent_Nonlinear(eq, compat=None)
     dom, bdy = eq.generate_data(1000, 200)
     t0 = time.time()
@@ -120,7 +123,7 @@ def run_simple_uniform(d, idx, seed=1234, rng=None, compat="reference"):
     from scasml_gp_amd.solvers.ScaSML import ScaSML
     np.random.seed(seed)
     eq = Grad_Dependent_Nonlinear(d + 1)
-    gp = GP_Grad_Dependent_Nonlinear(eq, compat=compat, laplacian_idx=idx)
+    gp = GP_Grad_Dependent_Nonlinear(eq, compat=compat, laplacian_idx=idx, f16_graph=F16_GRAPH)
     dom, bdy = eq.generate_data(1000, 200)
     gp.GPsolver(dom, bdy)                                   # SimpleUniform.py:81 (GN_steps default 20)
     xt = np.concatenate(eq.generate_test_data(1000, 200), axis=0)
@@ -133,7 +136,7 @@ def run_simple_uniform(d, idx, seed=1234, rng=None, compat="reference"):
     pde = np.asarray(gp.compute_PDE_loss(xt), np.float64)                       # SimpleUniform.py:139-141, 412-414
     stats = lambda v: {"min": float(v.min()), "max": float(v.max()), "mean": float(v.mean()), "std": float(v.std())}
     return {"protocol": "SimpleUniform", "d": d, "seed": seed, "rng": rng or "philox", "idx": [int(i) for i in idx],
-            "rel_l2": {k: round(m[k][2], 6) for k in sols}, "logged": dict(zip(("GP", "MLP", "ScaSML"), LOGGED_SIMPLE.get(d, (None,) * 3))),
+            "rel_l2": {k: round(m[k][2], 8) for k in sols}, "f16_graph": F16_GRAPH, "logged": dict(zip(("GP", "MLP", "ScaSML"), LOGGED_SIMPLE.get(d, (None,) * 3))),
             "real_solution": float(np.linalg.norm(e) / np.sqrt(e.size)), "pde_loss": stats(pde), "gp_l1": stats(np.abs(diff)), "gp_l2": stats(diff ** 2)}
 
 
@@ -150,8 +153,11 @@ def main():
                          "Threefry counter layout (scasml_gp_amd/threefry.py)")
     ap.add_argument("--rng", choices=["philox", "jax"], default="philox",
                     help="jax: MLP and ScaSML draw the reference's own normals (jax.random.normal float16 under its key schedule, SCASML_RNG_JAX_STREAM)")
+    ap.add_argument("--f16-graph", action="store_true", help="GP(f16_graph=True): the reference's float16 op sequence on float16 rows (fit, predict, PDE residual)")
     ap.add_argument("--simple-uniform", action="store_true", help="also run tests/SimpleUniform.py's single-stream protocol (seed 1234)")
     args = ap.parse_args()
+    global F16_GRAPH
+    F16_GRAPH = bool(args.f16_graph)
 
     if args.simple_uniform:
         from scasml_gp_amd.threefry import reference_laplacian_idx
