@@ -179,6 +179,32 @@ __device__ __forceinline__ void f16_graph_blocks(int d, double a, FX x, FY y, do
     P[3][2] = -(double)hmul(gS_div, m_d);
     P[3][3] = (double)(_Float16)s_divdiv;
 }
+// (round16 bit 3, exploratory: lap_y kappa and lap_x kappa through the same float16 sequence -- the mean over the five drawn indices of the Hessian
+// diagonal of kappa in the SHIFTED argument, H_i = f16(f16(gS_i m_i) - 2 t1), gS_i from w = m_i; jnp.mean accumulates in float32 and rounds once,
+// the product with the weakly typed d is float16.  The logs do not decide for it: DESIGN.md section 2.)
+template <class FX, class FY>
+__device__ __forceinline__ double f16_graph_hutchinson(int d, double a, const CompatIdx &ix, FX x, FY y) {   // x, y: the geometry's rows, already shifted
+    const _Float16 c16 = (_Float16)(2.0 / a);
+    const _Float16 inv16 = (_Float16)(1.0f / (float)c16);
+    float Sf = 0.0f;
+    for (int k = 0; k <= d; ++k) {
+        const _Float16 r = (_Float16)x(k) - (_Float16)y(k);
+        Sf += (float)(r * r);
+    }
+    const _Float16 kap = (_Float16)(float)exp((double)hmul(-(_Float16)Sf, inv16));
+    const _Float16 t1 = hmul(kap, inv16), two_t1 = (_Float16)2.0f * t1;
+    float acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kMC; ++j) {
+        const int i = ix.i[j];
+        const _Float16 m = (_Float16)2.0f * ((_Float16)x(i) - (_Float16)y(i));
+        const _Float16 gS = hmul(hmul(hmul(m, inv16), kap), inv16);
+        acc += (float)(_Float16)((float)hmul(gS, m) - (float)two_t1);
+    }
+    const _Float16 mean = (_Float16)(acc / (float)kMC);
+    return (double)(_Float16)((float)mean * (float)d);
+}
+
 template <class FX>
 __device__ __forceinline__ bool row_is_f16(int d, FX x) {
     bool ok = true;
@@ -201,6 +227,11 @@ __global__ void gp_gram_compat_kernel(int d, double a, const float *x_dom, int n
     double P[4][4];
     compat_blocks(d, a, g, r16 & 1, P);
     if (r16 & 4) f16_graph_blocks(d, a, [&](int k) { return xi[k]; }, [&](int k) { return yj[k]; }, P);   // the caller vouches for float16 rows
+    if (r16 & 8) {
+        const int D = d + 1;
+        P[0][1] = f16_graph_hutchinson(d, a, ix, [&](int k) { return xi[k]; }, [&](int k) { return yj[(k + 1) % D]; });   // ys: r = x - y'
+        P[1][0] = f16_graph_hutchinson(d, a, ix, [&](int k) { return xi[(k + 1) % D]; }, [&](int k) { return yj[k]; });   // xs: r = x' - y
+    }
     const int nops_i = i < n_dom ? 4 : 1, nops_j = j < n_dom ? 4 : 1;
     for (int ox = 0; ox < nops_i; ++ox) {
         const int64_t row = ox == 0 ? i : (int64_t)n_dom + n_bdy + (int64_t)(ox - 1) * n_dom + i;
@@ -228,6 +259,11 @@ __global__ void gp_gram_compat_rows_kernel(int d, double a, const float *x_dom, 
     double P[4][4];
     compat_blocks(d, a, g, r16 & 1, P);
     if (r16 & 4) f16_graph_blocks(d, a, [&](int k) { return xi[k]; }, [&](int k) { return yj[k]; }, P);
+    if (r16 & 8) {
+        const int D = d + 1;
+        P[0][1] = f16_graph_hutchinson(d, a, ix, [&](int k) { return xi[k]; }, [&](int k) { return yj[(k + 1) % D]; });
+        P[1][0] = f16_graph_hutchinson(d, a, ix, [&](int k) { return xi[(k + 1) % D]; }, [&](int k) { return yj[k]; });
+    }
     const int nops_j = j < n_dom ? 4 : 1;
     for (int oy = 0; oy < nops_j; ++oy) {
         const int64_t col = oy == 0 ? j : (int64_t)N + (int64_t)(oy - 1) * n_dom + j;
@@ -278,6 +314,10 @@ __global__ __launch_bounds__(256) void gp_eval_compat_kernel(int d, double a, do
         double P[4][4];
         compat_blocks(d, a, g, r16 & 1, P);
         if (graph) f16_graph_blocks(d, a, [&](int k) { return xs[k]; }, [&](int k) { return colloc_t[(int64_t)k * ldc + j]; }, P);
+        if (graph && (r16 & 8)) {
+            P[0][1] = f16_graph_hutchinson(d, a, ix, [&](int k) { return xs[k]; }, [&](int k) { return colloc_t[(int64_t)((k + 1) % D) * ldc + j]; });
+            P[1][0] = f16_graph_hutchinson(d, a, ix, [&](int k) { return xs[(k + 1) % D]; }, [&](int k) { return colloc_t[(int64_t)k * ldc + j]; });
+        }
         const double c0 = rv[j];
         double cL = 0.0, ct = 0.0, cS = 0.0;
         if (j < n_dom) {

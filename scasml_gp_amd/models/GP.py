@@ -66,6 +66,7 @@ class GP(object):
         # one rounding per entry.  Brings the GP's relative L2 on the reference's experiments from <= 1e-4 to ~1e-5 of the logged numbers.  The
         # solvers' hot evaluation (float32 tree points) is unaffected.
         self.f16_graph = bool(f16_graph) and compat == "reference"
+        self._f16_extra = 8 if os.environ.get("SCASML_GP_F16_LEVEL") == "3" else 0     # exploratory: + the Hutchinson lap blocks (round16 bit 3)
         self.laplacian_idx = None
         if compat == "reference":
             if isinstance(laplacian_idx, str):                   # the reference's own draw, models/GP.py:35
@@ -173,7 +174,7 @@ class GP(object):
             N = self.N_domain + self.N_boundary
             _lib.check(_lib.load().scasml_gp_eval_compat(self.d, 1.0 / float(self.sigma) ** 2, float(self.equation.sigma()), float(self.equation.mu()),
                                                          int(self.equation.eq_id), _lib.ptr(self._colloc_t), self.N_domain, self.N_boundary, N,
-                                                         _lib.ptr(self._rv_dev), self.laplacian_idx.ctypes.data_as(C.c_void_p), (int(self.eval_round16) & 3) | 4,
+                                                         _lib.ptr(self._rv_dev), self.laplacian_idx.ctypes.data_as(C.c_void_p), (int(self.eval_round16) & 3) | 4 | self._f16_extra,
                                                          _lib.ptr(pts), pts.shape[0], pts.shape[1], _lib.ptr(out), None, _lib.stream_ptr()), "gp_eval_compat")
             return out
         xb = (hb if hb is not None else float(pts.abs().max())) if pts.shape[0] and fp16_planes else 0.0
@@ -228,7 +229,7 @@ class GP(object):
         K = torch.empty((M, M), dtype=torch.float64, device="cuda")
         if self.compat == "reference":
             colloc_f16 = bool((xd.half().float() == xd).all()) and bool((xb.half().float() == xb).all())
-            gram_bits = 1 | (4 if (self.f16_graph and colloc_f16) else 0)
+            gram_bits = 1 | ((4 | self._f16_extra) if (self.f16_graph and colloc_f16) else 0)
             self._stage("gram", lambda: _lib.check(lib.scasml_gp_gram_compat(
                 self.d, 1.0 / float(self.sigma) ** 2, _lib.ptr(xd), self.N_domain, _lib.ptr(xb), self.N_boundary,
                 self.laplacian_idx.ctypes.data_as(C.c_void_p), gram_bits, _lib.ptr(K), s), "gp_gram_compat"))
