@@ -201,8 +201,12 @@ __device__ __forceinline__ double f16_graph_hutchinson(int d, double a, const Co
         const _Float16 gS = hmul(hmul(hmul(m, inv16), kap), inv16);
         acc += (float)(_Float16)((float)hmul(gS, m) - (float)two_t1);
     }
+#ifdef SCASML_F16_HUTCH_FUSED      // development: mean * d without the intermediate float16 rounding
+    return (double)(_Float16)(acc / (float)kMC * (float)d);
+#else
     const _Float16 mean = (_Float16)(acc / (float)kMC);
     return (double)(_Float16)((float)mean * (float)d);
+#endif
 }
 
 template <class FX>
