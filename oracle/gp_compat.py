@@ -55,6 +55,16 @@ def f16(v):
         return np.asarray(v, dtype=np.float64).astype(np.float16).astype(np.float64)
 
 
+def _sum32(v):
+    """float32 sum over the last axis in INDEX ORDER (a running float32 accumulator, as a loop -- and the device kernel -- adds; NumPy's own
+    .sum is pairwise and lands on the other side of a float16 rounding boundary in ~0.3 % of the entries)."""
+    v = np.asarray(v, dtype=np.float32)
+    acc = np.zeros(v.shape[:-1], dtype=np.float32)
+    for k in range(v.shape[-1]):
+        acc = acc + v[..., k]
+    return acc
+
+
 def shift(P):
     """v' = (v_2, ..., v_d, t, v_1): models/GP.py:91-93 (concatenate((x_t[1:], x_t[0:1])))."""
     return np.roll(np.asarray(P, dtype=np.float64), -1, axis=1)
@@ -128,7 +138,7 @@ class OracleGPCompat(OracleGP):
         for i0 in range(0, X16.shape[0], 128):
             r = X16[i0:i0 + 128, None, :] - Y16[None, :, :]                       # float16 subtraction
             sq = r * r                                                             # float16 product
-            S = sq.astype(F32).sum(axis=2, dtype=F32).astype(F16)
+            S = _sum32(sq).astype(F16)
             q = ((-S).astype(F32) * F32(inv16)).astype(F16)
             kap = np.exp(q.astype(np.float64)).astype(F32).astype(F16)
             if op == "I":
@@ -139,7 +149,7 @@ class OracleGPCompat(OracleGP):
                 g = ((-t1).astype(F32) * (F16(2.0) * r[:, :, d]).astype(F32)).astype(F16)
             else:                                          # "div": float16 sum of the d rounded spatial components
                 gk = ((-t1)[:, :, None].astype(F32) * (F16(2.0) * r[:, :, :d]).astype(F32)).astype(F16)
-                g = gk.astype(F32).sum(axis=2, dtype=F32).astype(F16)
+                g = _sum32(gk).astype(F16)
             out[i0:i0 + 128] = sign * g.astype(np.float64)
         return out
 
@@ -160,12 +170,12 @@ class OracleGPCompat(OracleGP):
         out = np.empty((X16.shape[0], Y16.shape[0]))
         for i0 in range(0, X16.shape[0], 128):
             r = X16[i0:i0 + 128, None, :] - Y16[None, :, :]
-            S = (r * r).astype(F32).sum(axis=2, dtype=F32).astype(F16)
+            S = _sum32(r * r).astype(F16)
             q = ((-S).astype(F32) * inv16).astype(F16)
             kap = np.exp(q.astype(np.float64)).astype(F32).astype(F16)
             t1 = (kap.astype(F32) * inv16).astype(F16)
             m = F16(2.0) * r                                                     # exact
-            w = m[:, :, d] if opx == "dt" else m[:, :, :d].astype(F32).sum(axis=2, dtype=F32).astype(F16)
+            w = m[:, :, d] if opx == "dt" else _sum32(m[:, :, :d]).astype(F16)
             gS = mul(mul(mul(w, inv16), kap), inv16)
             two_t1 = F16(2.0) * t1
             if opy == "dt":
@@ -174,7 +184,7 @@ class OracleGPCompat(OracleGP):
             else:
                 bk = mul(gS[:, :, None], m[:, :, :d])
                 gk = (two_t1[:, :, None].astype(F32) - bk.astype(F32)).astype(F16) if opx == "div" else -bk
-                g = gk.astype(F32).sum(axis=2, dtype=F32).astype(F16)
+                g = _sum32(gk).astype(F16)
             out[i0:i0 + 128] = g.astype(np.float64)
         return out
 
@@ -196,14 +206,14 @@ class OracleGPCompat(OracleGP):
         out = np.empty((X16.shape[0], Y16.shape[0]))
         for i0 in range(0, X16.shape[0], 128):
             r = X16[i0:i0 + 128, None, :] - Y16[None, :, :]
-            S = (r * r).astype(F32).sum(axis=2, dtype=F32).astype(F16)
+            S = _sum32(r * r).astype(F16)
             q = ((-S).astype(F32) * inv16).astype(F16)
             kap = np.exp(q.astype(np.float64)).astype(F32).astype(F16)
             t1 = (kap.astype(F32) * inv16).astype(F16)
             mi = F16(2.0) * r[:, :, self.idx]                                    # (n, m, 5), exact
             gS = mul(mul(mul(mi, inv16), kap[:, :, None]), inv16)
             H = (mul(gS, mi).astype(F32) - (F16(2.0) * t1)[:, :, None].astype(F32)).astype(F16)
-            mean = (H.astype(F32).sum(axis=2, dtype=F32) / F32(self.MC)).astype(F16)
+            mean = (_sum32(H) / F32(self.MC)).astype(F16)
             out[i0:i0 + 128] = (mean.astype(F32) * F32(d)).astype(F16).astype(np.float64)
         return out
 
