@@ -45,10 +45,12 @@ def test_gram_on_float16_rows_follows_the_float16_op_sequence():
     ogp = OracleGPCompat(GradDependentNonlinear(d + 1), idx, f16_graph=2)
     want = ogp.kernel_phi_phi(dom.astype(np.float64), bdy.astype(np.float64))
     assert np.array_equal(got.astype(np.float16).astype(np.float64), got)        # float16 values
-    # float32 accumulations run in index order here and pairwise in NumPy: an entry can land on the other side of a float16 rounding boundary
+    # the same op sequence, float32 accumulations in index order on both sides: bit for bit (0 of 396 900 entries differed when this was written;
+    # a correctly rounded exp that lands exactly on a float16 tie is the one place the two could part)
     differs = got != want
-    assert differs.mean() < 3e-3, differs.mean()
-    assert np.all(np.abs(got - want)[differs] <= 2.0 ** -9 * np.abs(want)[differs] + 2.0 ** -24)
+    print("float16-graph Gram, device against oracle: %d of %d entries differ" % (int(differs.sum()), differs.size))
+    assert differs.sum() <= 2, int(differs.sum())
+    assert np.all(np.abs(got - want)[differs] <= 2.0 ** -10 * np.abs(want)[differs] + 2.0 ** -24)
     assert (got != plain).mean() > 0.2                                             # it IS another arithmetic than one rounding per entry
     # the Hutchinson blocks are untouched: rows / columns of the Laplacian features
     N = nd + nb
@@ -97,9 +99,10 @@ def test_fit_and_predict_in_the_reference_arithmetic_land_on_the_logged_gp_error
         rv_err = float(np.abs(gp.right_vector - ogp.right_vector).max() / np.abs(ogp.right_vector).max())
         pred = ogp.predict(xt.astype(np.float64))[:, 0]
         diff = np.abs(gp.predict(xt).astype(np.float64)[:, 0] - pred)
-        # right_vector = K_p^-1 z with cond(K_p) ~ 1e5: the few Gram entries that round the other way (float32 sums in another order) move it by 5e-3,
-        # the predictions by at most a float16 ulp at 1 % of the points
-        assert rv_err <= 2e-2 and (diff > 0).mean() < 0.05 and diff.max() <= 2.0 ** -10, (rv_err, (diff > 0).mean(), diff.max())
+        print("float16-graph fit d=%d, device against oracle: right_vector %.2e, predictions differing %.3f %%, max %.2e" % (d, rv_err, 100 * (diff > 0).mean(), diff.max()))
+        # right_vector = K_p^-1 z with lambda_min(K_p) ~ 0.02: ONE Gram entry of 1.8e7 that rounds the other way (an exp on a float16 tie) moves it by up to
+        # ~1e-2 of its size; the predictions by at most a float16 ulp at ~1 % of the points
+        assert rv_err <= 2e-2 and (diff > 0).mean() < 0.02 and diff.max() <= 2.0 ** -10, (rv_err, (diff > 0).mean(), diff.max())
 
 
 def test_state_carries_the_arithmetic():
