@@ -625,22 +625,26 @@ __global__ void add_diag_kernel(double *A, int64_t M, double v) {
     if (i < M) A[i * M + i] += v;
 }
 
+// whole-matrix passes: grid.y strides over the rows (a grid dimension other than x holds at most 65535 workgroups; M = 70 016 has more rows)
+constexpr unsigned kRowGrid = 32768;
+static unsigned row_grid(int64_t M) { return (unsigned)(M < (int64_t)kRowGrid ? M : (int64_t)kRowGrid); }
+
 __global__ void set_identity_kernel(double *A, int64_t M) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t r = blockIdx.y;
-    if (c < M) A[r * M + c] = r == c ? 1.0 : 0.0;
+    if (c >= M) return;
+    for (int64_t r = blockIdx.y; r < M; r += gridDim.y) A[r * M + c] = r == c ? 1.0 : 0.0;
 }
 
 __global__ void mirror_lower_kernel(double *A, int64_t M) {   // A[r][c] = A[c][r] for c > r
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t r = blockIdx.y;
-    if (c < M && c > r) A[r * M + c] = A[c * M + r];
+    if (c >= M) return;
+    for (int64_t r = blockIdx.y; r < c; r += gridDim.y) A[r * M + c] = A[c * M + r];
 }
 
 __global__ void zero_upper_kernel(double *A, int64_t M) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t r = blockIdx.y;
-    if (c < M && c > r) A[r * M + c] = 0.0;
+    if (c >= M) return;
+    for (int64_t r = blockIdx.y; r < c; r += gridDim.y) A[r * M + c] = 0.0;
 }
 
 }  // namespace scasml
@@ -796,7 +800,7 @@ extern "C" int scasml_cholesky(double *A, int64_t M, double nugget, int32_t *inf
         }
         la.close();
     }
-    hipLaunchKernelGGL(zero_upper_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)M), dim3(256), 0, s, A, M);
+    hipLaunchKernelGGL(zero_upper_kernel, dim3((unsigned)((M + 255) / 256), row_grid(M)), dim3(256), 0, s, A, M);
     return check_launch("cholesky launch");
 }
 
@@ -892,7 +896,7 @@ extern "C" int scasml_cholesky_inverse(const double *L, int64_t M, double *A, vo
     if (M > 65535 * (int64_t)NB) return fail(SCASML_ERR_UNSUPPORTED, "cholesky_inverse: M too large for this build");
     hipStream_t s = (hipStream_t)stream;
     auto tiles = [](int64_t n) { return (unsigned)((n + TB - 1) / TB); };
-    hipLaunchKernelGGL(set_identity_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)M), dim3(256), 0, s, A, M);
+    hipLaunchKernelGGL(set_identity_kernel, dim3((unsigned)((M + 255) / 256), row_grid(M)), dim3(256), 0, s, A, M);
     auto forward_chain = [&](int64_t J, int64_t jend, hipStream_t q) {    // rows [J, jend) of X = L^-1 final
         for (int64_t k0 = J; k0 < jend; k0 += NB) {
             const int64_t lim = k0 + NB;
@@ -958,7 +962,7 @@ extern "C" int scasml_cholesky_inverse(const double *L, int64_t M, double *A, vo
         }
         la.close();
     }
-    hipLaunchKernelGGL(mirror_lower_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)M), dim3(256), 0, s, A, M);
+    hipLaunchKernelGGL(mirror_lower_kernel, dim3((unsigned)((M + 255) / 256), row_grid(M)), dim3(256), 0, s, A, M);
     return check_launch("cholesky_inverse launch");
 }
 

@@ -35,6 +35,7 @@ for the rows on which b is the identity in sol, i.e. everything but the F rows: 
 rows and TWO collectives of an M-vector (DistCholesky.matvec), against two collectives PER BLOCK for a solve.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -44,16 +45,28 @@ BLK = _lib.DIST_BLOCK
 
 
 class Comm:
-    """The three collectives the path uses, on CUDA tensors; gloo groups (rehearsal on one GPU, tests) go through the host."""
+    """The three collectives the path uses, on CUDA tensors; gloo groups (rehearsal on one GPU, tests) go through the host.
 
-    def __init__(self, group=None):
+    ``force`` (or SCASML_DIST_FORCE_COLLECTIVES=1): issue every collective at world == 1 too.  A one-rank group makes each of them a copy
+    onto itself, but the call goes through the backend -- on a one-GPU box this is the only way the RCCL branches (device tensors, issued
+    from the two streams of the look-ahead factorisation) execute at all (tests/test_gpu_dist_gp.py, tools/dist_gp_demo.py --backend nccl)."""
+
+    def __init__(self, group=None, force=None):
         import torch.distributed as dist
         self.dist, self.group = dist, group
         self.on = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if self.on else 1
         self.rank = dist.get_rank(group) if self.on else 0
-        self.host = self.on and dist.get_backend(group) == "gloo"
+        self.backend = dist.get_backend(group) if self.on else None
+        self.host = self.backend == "gloo"
+        if force is None:
+            force = os.environ.get("SCASML_DIST_FORCE_COLLECTIVES") == "1"
+        self.active = self.world > 1 or (bool(force) and self.on)
         self.bytes_moved = 0
+        self.calls = {"broadcast": 0, "all_reduce": 0, "all_gather": 0}
+
+    def _src(self, src):
+        return src if self.group is None else self.dist.get_global_rank(self.group, src)
 
     def _via(self, t, fn):
         if not self.host:
@@ -65,13 +78,15 @@ class Comm:
         return t
 
     def broadcast(self, t, src):
-        if self.world > 1:
+        if self.active:
+            self.calls["broadcast"] += 1
             self.bytes_moved += t.numel() * t.element_size()
-            self._via(t, lambda x: self.dist.broadcast(x, src=src if self.group is None else self.dist.get_global_rank(self.group, src), group=self.group))
+            self._via(t, lambda x: self.dist.broadcast(x, src=self._src(src), group=self.group))
         return t
 
     def all_reduce(self, t):
-        if self.world > 1:
+        if self.active:
+            self.calls["all_reduce"] += 1
             self.bytes_moved += 2 * t.numel() * t.element_size()
             self._via(t, lambda x: self.dist.all_reduce(x, group=self.group))
         return t
@@ -79,14 +94,18 @@ class Comm:
     def all_gather(self, t):
         """-> (world, *t.shape) tensor; every rank passes the same shape."""
         import torch
-        if self.world == 1:
+        if not self.active:
             return t.unsqueeze(0)
+        self.calls["all_gather"] += 1
         self.bytes_moved += self.world * t.numel() * t.element_size()
         if self.host:
-            h = t.cpu()
-            out = [torch.empty_like(h) for _ in range(self.world)]
-            self.dist.all_gather(out, h, group=self.group)
-            return torch.stack(out).to(t.device)
+            # gloo's all_gather moves ~0.3 GB/s between two local ranks, its broadcast ~3 GB/s (measured on this image): the rehearsal gathers
+            # with one broadcast per rank into a single host buffer
+            out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype)
+            out[self.rank].copy_(t)
+            for q in range(self.world):
+                self.dist.broadcast(out[q], src=self._src(q), group=self.group)
+            return out.to(t.device)
         out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
         self.dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
         return out
@@ -100,14 +119,16 @@ def owned_blocks(nblk, rank, world):
 class DistCholesky:
     """K(phi, phi) + nugget I, block-row distributed: build(), factor(), solve(b)."""
 
-    def __init__(self, d, a, x_dom, x_bdy, nugget, comm=None, compat_idx=None, round_diag=False, f16_graph=False):
+    def __init__(self, d, a, x_dom, x_bdy, nugget, comm=None, compat_idx=None, round_diag=False, f16_graph=False, f16_extra=0):
         """compat_idx: the five Hutchinson indices -> the Gram AS CODED by the reference (shifted blocks, float16 entries:
         scasml_gp_gram_compat_rows); round_diag: the diagonal of K + nugget I rounded to float16 as well, i.e. the matrix
         kernel_phi_phi_perturb.astype(float16) of models/GP.py:268 that the right_vector solve of :599 uses."""
         torch = _lib.require_gpu()
         self.compat_idx = None if compat_idx is None else np.ascontiguousarray(np.asarray(compat_idx, dtype=np.int32))
         self.round_diag = bool(round_diag)
-        self.gram_bits = 1 | (4 if f16_graph else 0)       # scasml_gp_gram_compat_rows: bit 2 = the float16 op sequence on float16 rows (GP(f16_graph=True))
+        # scasml_gp_gram_compat_rows: bit 2 = the float16 op sequence on float16 rows (GP(f16_graph=True)); f16_extra = the GP's exploratory bit 3 --
+        # the same mask GP.kernel_phi_phi builds, so the distributed and the single-GPU Gram cannot differ
+        self.gram_bits = 1 | ((4 | int(f16_extra)) if f16_graph else 0)
         self.lib = _lib.load()
         self.comm = comm or Comm()
         self.d, self.a, self.nugget = int(d), float(a), float(nugget)
@@ -335,7 +356,8 @@ class DistributedGP:
         xd16, xb16 = np.asarray(x_t_domain, dtype=np.float32), np.asarray(x_t_boundary, dtype=np.float32)
         graph = bool(getattr(gp, "f16_graph", False)) and compat_idx is not None and \
             np.array_equal(xd16.astype(np.float16).astype(np.float32), xd16) and np.array_equal(xb16.astype(np.float16).astype(np.float32), xb16)
-        ch = DistCholesky(d, 1.0 / float(gp.sigma) ** 2, x_t_domain, x_t_boundary, gp.nugget, self.comm, compat_idx=compat_idx, f16_graph=graph).build().factor()
+        ch = DistCholesky(d, 1.0 / float(gp.sigma) ** 2, x_t_domain, x_t_boundary, gp.nugget, self.comm, compat_idx=compat_idx, f16_graph=graph,
+                          f16_extra=getattr(gp, "_f16_extra", 0)).build().factor()
         self.chol = ch
         N, Nb, M = ch.n_dom, ch.n_bdy, ch.M
         bdy_g = torch.as_tensor(np.asarray(gp.bdy_g(np.asarray(x_t_boundary)), dtype=np.float64), device="cuda").contiguous()
@@ -419,7 +441,7 @@ class DistributedGP:
             ch.diag = [None] * ch.nblk
             torch.cuda.empty_cache()
             ch2 = DistCholesky(d, 1.0 / float(gp.sigma) ** 2, x_t_domain, x_t_boundary, gp.nugget, self.comm, compat_idx=compat_idx,
-                               round_diag=True, f16_graph=graph).build().factor()
+                               round_diag=True, f16_graph=graph, f16_extra=getattr(gp, "_f16_extra", 0)).build().factor()
             rv = ch2.solve(b)
             self.chol = ch2
         gp.N_domain, gp.N_boundary, gp.phi_dim = N, Nb, M

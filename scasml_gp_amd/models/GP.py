@@ -28,6 +28,11 @@ Two surrogates (``compat``):
   (profiles/r04_eval_rounding_study.txt); u_hat and eps_PDE still leave as float16 values (:671, 769).
 Remaining deviations in both: Newton start at 0 instead of 1e-3*N(0,1) from PRNGKey(0) (:501); Cholesky instead of
 the SVD factor, so the float16 rounding of L itself (:266) has no counterpart (no measurable effect).
+Which triangle: every factorisation here (scasml_cholesky, dist_gp.DistCholesky, the oracle's eigh) reads the LOWER triangle of K, i.e. it
+factors tril(K) + tril(K, -1)^T.  With one rounding per entry K is symmetric and nothing is dropped.  Under ``f16_graph`` it is not (the
+(dt, div) entry and its mirror are two different float16 rounding sequences, up to 1.4e-3 relative apart): the reference's SVD (:260) and
+jnp.linalg.solve (:599) consume both halves, this build the lower one; kernel_phi_phi still returns the matrix as coded, asymmetric.  The GP
+error on the reference's logs is unaffected to the digits they print (tests/test_gpu_f16_graph.py pins the triangle and the logged numbers).
 """
 import ctypes as C
 import os
@@ -116,25 +121,27 @@ class GP(object):
 
     # ------------------------------------------------------------------ device helpers
     def _points_device(self, x):
-        """(n, d+1) numpy / torch -> (n, kp) float32 CUDA rows (X, t, zero pad).  The largest |coordinate| of a host array is noted on the
-        host (self._host_bound) so that the evaluation need not read it back from the device."""
+        """(n, d+1) numpy / torch -> ((n, kp) float32 CUDA rows (X, t, zero pad), was_numpy, host bound, float16 rows).  The largest
+        |coordinate| of a host array is taken on the host, so that the evaluation need not read it back from the device (None for device
+        tensors); ``float16 rows`` says the caller's array was float16 -- numpy or torch alike -- i.e. rows on which the reference's kernels
+        are float16 arithmetic (f16_graph).  Both travel as return values: nothing about one call is parked on the instance."""
         torch = _lib.require_gpu()
         was_numpy = not isinstance(x, torch.Tensor)
-        self._host_bound = None
-        self._host_f16 = False        # a float16 host array: rows on which the reference's kernels are float16 arithmetic (f16_graph)
+        bound = None
         if was_numpy:
-            self._host_f16 = np.asarray(x).dtype == np.float16
+            f16_rows = np.asarray(x).dtype == np.float16
             arr = np.ascontiguousarray(np.asarray(x), dtype=np.float32)
-            self._host_bound = float(np.abs(arr).max()) if arr.size else 0.0
+            bound = float(np.abs(arr).max()) if arr.size else 0.0
             xt = torch.from_numpy(arr).cuda()
         else:
+            f16_rows = x.dtype == torch.float16
             xt = x.to(device="cuda", dtype=torch.float32)
         if xt.dim() != 2 or xt.shape[1] != self.d + 1:
             raise ValueError("points must have shape (n, %d), got %s" % (self.d + 1, tuple(xt.shape)))
         kp = int(_lib.load().scasml_point_stride(self.d))
         pts = torch.zeros((xt.shape[0], kp), dtype=torch.float32, device="cuda")
         pts[:, :self.d + 1] = xt
-        return pts, was_numpy
+        return pts, was_numpy, bound, bool(f16_rows)
 
     def _split_for(self, x_bound):
         """eval_split, demoted from the fp16 x 2 mode to the fp32-exact bf16 x 3 mode where the coordinates may leave the fp16
@@ -161,14 +168,13 @@ class GP(object):
         m.colloc_is_f16 = int(self._colloc_is_f16)
         return m
 
-    def _eval_device(self, pts):
-        """Caller-supplied points: their coordinate bound (taken on the host for host arrays; one reduction + read for device tensors) lets
-        far-out rows fall back to the bf16 x 3 arithmetic instead of overflowing the fp16 planes."""
+    def _eval_device(self, pts, host_bound=None, f16_rows=False):
+        """Caller-supplied points: their coordinate bound (``host_bound`` of _points_device for host arrays; one reduction + read for device
+        tensors) lets far-out rows fall back to the bf16 x 3 arithmetic instead of overflowing the fp16 planes."""
         torch = _lib.require_gpu()
         out = torch.empty((pts.shape[0], 4), dtype=torch.float32, device="cuda")
         fp16_planes = (int(self.eval_split) == 22 and self.compat is None) or (self.compat == "reference" and self.compat_eval == "mfma")
-        hb, self._host_bound = getattr(self, "_host_bound", None), None
-        f16_rows, self._host_f16 = getattr(self, "_host_f16", False), False
+        hb = host_bound
         if self.compat == "reference" and self.f16_graph and f16_rows and getattr(self, "_colloc_is_f16", False):
             # float16 rows against float16 collocation points: the float64 kernel with the reference's float16 op sequence for the Laplacian-free entries
             N = self.N_domain + self.N_boundary
@@ -211,8 +217,8 @@ class GP(object):
                                                 _lib.ptr(out4), _lib.stream_ptr()), "gp_eval")
 
     def _predict_device(self, x_dev):
-        pts, _ = self._points_device(x_dev)
-        return self._eval_device(pts)[:, 0:1]
+        pts, _, hb, f16 = self._points_device(x_dev)
+        return self._eval_device(pts, hb, f16)[:, 0:1]
 
     # ------------------------------------------------------------------ training
     def kernel_phi_phi(self, x_t_domain, x_t_boundary):
@@ -414,6 +420,8 @@ class GP(object):
                 "x_t_boundary": np.asarray(self.x_t_boundary), "right_vector": np.asarray(self.right_vector),
                 "loss_history": np.asarray(getattr(self, "loss_history", []), dtype=np.float64),
                 "nugget": np.float64(self.nugget), "T": np.float64(self.T), "compat": np.str_(self.compat or ""), "f16_graph": np.bool_(self.f16_graph),
+                # the float16 op sequence is only taken on float16 collocation points; otherwise the fit silently used one rounding per entry
+                "f16_graph_effective": np.bool_(self.f16_graph and bool(getattr(self, "_colloc_is_f16", False))),
                 "laplacian_idx": np.asarray(self.laplacian_idx if self.laplacian_idx is not None else [], dtype=np.int32)}
 
     def load_state_dict(self, state):
@@ -444,15 +452,15 @@ class GP(object):
     # ------------------------------------------------------------------ inference
     def predict(self, x_t_infer):
         '''(n, 1) posterior mean (models/GP.py:653-671).'''
-        pts, was_numpy = self._points_device(x_t_infer)
-        out = self._eval_device(pts)[:, 0:1]
+        pts, was_numpy, hb, f16 = self._points_device(x_t_infer)
+        out = self._eval_device(pts, hb, f16)[:, 0:1]
         return out.cpu().numpy() if was_numpy else out
 
     def compute_gradient(self, x_t_infer, sol_infer=None):
         '''(n, d+1) gradient of the posterior mean, time derivative last (models/GP.py:673-687).'''
         torch = _lib.require_gpu()
         lib = _lib.load()
-        pts, was_numpy = self._points_device(x_t_infer)
+        pts, was_numpy, _, _ = self._points_device(x_t_infer)
         grad = torch.empty((pts.shape[0], self.d + 1), dtype=torch.float32, device="cuda")
         if self.compat == "reference":      # autodiff of the as-coded u_hat (through the float16 casts), result cast to float16 (:687)
             if self.right_vector is None:
@@ -488,8 +496,8 @@ class GP_Semilinear(GP):
     def compute_PDE_loss(self, x_t_infer):
         '''dt u + mu div u + sigma^2/2 Lap u + f(u, sigma div u); for Grad_Dependent_Nonlinear
         dt u + (sigma^2 u - 1/d - sigma^2/2) div u + sigma^2/2 Lap u  (models/GP.py:746-769)'''
-        pts, was_numpy = self._points_device(x_t_infer)
-        out = self._eval_device(pts)[:, 2:3]
+        pts, was_numpy, hb, f16 = self._points_device(x_t_infer)
+        out = self._eval_device(pts, hb, f16)[:, 2:3]
         return out.cpu().numpy() if was_numpy else out
 
 

@@ -1,6 +1,7 @@
 """Host driver shared by the four solver classes: builds the static schedule, owns the
 device buffers and issues the HIP kernels through the C ABI.  No numerics happen here."""
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -14,7 +15,7 @@ def _as_device(x_t, torch):
     """-> (float32 contiguous CUDA tensor, was_numpy, largest |coordinate| or None).  The bound of a host array is taken on the host
     before the upload; a device tensor's is the caller's business (PicardEngine._root_bound caches it per tensor version)."""
     if isinstance(x_t, torch.Tensor):
-        return x_t.to(device="cuda", dtype=torch.float32).contiguous(), False, None
+        return x_t.to(device="cuda", dtype=torch.float32).contiguous(), False, None     # x_t itself when it already is all three
     arr = np.ascontiguousarray(np.asarray(x_t), dtype=np.float32)
     return torch.from_numpy(arr).cuda(), True, (float(np.abs(arr).max()) if arr.size else 0.0)
 
@@ -50,7 +51,7 @@ class PicardEngine:
         self._kinds = {}
         self._owners = {}
         self._work = {}               # point / GP-value buffers, kept across calls (4.9 GB at the headline shape)
-        self._bound_cache = None      # (data_ptr, numel, version) -> largest |coordinate| of a device tensor of roots
+        self._bound_cache = None      # (weakref to the caller's tensor, (address, shape, version), largest |coordinate|): _root_bound
 
     def __getstate__(self):               # deep-copyable (tests/ComputingBudget.py:138): drop caches and events
         st = dict(self.__dict__)
@@ -179,7 +180,7 @@ class PicardEngine:
         kinds = self.site_kinds(n, par, rank, world) if n > 0 else None
         # roots outside the training cube widen the bound instead of silently breaking it (host arrays: measured before the upload;
         # device tensors: one reduction per tensor version, not per solve)
-        x_bound = self.path_bound(self._root_bound(x, x_max) if B else None, plan)
+        x_bound = self.path_bound(self._root_bound(x, x_max, x is x_t) if B else None, plan)
         for b0 in range(0, B, chunk):
             nb = min(chunk, B - b0)
             rng_c = _lib.Rng(rng.seed, rng.stream, root0 + b0, rank, world, flags, 0, owner, jax_keys)
@@ -199,14 +200,22 @@ class PicardEngine:
         self._jax_commit(jax_next, stream_id)
         return out, uhat, was_numpy
 
-    def _root_bound(self, x, x_max):
-        """Largest |coordinate| of the roots: given for host arrays; for a device tensor read once per (storage, version)."""
+    def _root_bound(self, x, x_max, own):
+        """Largest |coordinate| of the roots: given for host arrays; reduced on the device otherwise.  The reduction (and the read it ends
+        in) is cached ONLY for the caller's own tensor (``own``: the solve used x_t itself or a view of it), identified by a weak reference to
+        the tensor that owns the storage plus (address, extent, version): while that object is alive its storage cannot be handed to
+        another tensor.  A temporary made by .to() / .contiguous() (CPU, non-float32, non-contiguous input) is freed after the solve and the
+        caching allocator gives the next call's temporary the same address and version 0 -- it is reduced per solve."""
         if x_max is not None:
             return x_max
-        key = (x.data_ptr(), x.numel(), x._version)
-        if self._bound_cache is None or self._bound_cache[0] != key:
-            self._bound_cache = (key, float(x.abs().max()))
-        return self._bound_cache[1]
+        if not own:
+            return float(x.abs().max())
+        holder = x._base if x._base is not None else x
+        key = (x.data_ptr(), tuple(x.shape), x._version)
+        c = self._bound_cache
+        if c is None or c[0]() is not holder or c[1] != key:
+            self._bound_cache = c = (weakref.ref(holder), key, float(x.abs().max()))
+        return c[2]
 
     def _jax_keys(self, plan):
         """Device words [terminal key | the sub-keys this solve draws from the solver's stateful key] and the key state AFTER the solve,

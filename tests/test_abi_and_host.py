@@ -244,6 +244,54 @@ def test_no_spills_inside_the_gp_tile_loops():
         assert 4 * stage_bytes * bpc > 144 * 1024, "spill inside a counted-vmcnt tile loop: " + line
 
 
+def test_launch_bounds_of_the_as_coded_evaluation_kernel_hold_without_scratch():
+    """gp_eval_compat_mfma.hip sets __launch_bounds__(256, BPC) from a hand-written register estimate; if the estimate is low the
+    compiler honours the occupancy bound by spilling, silently.  Pinned from the code object's metadata for every instantiation: the as-coded
+    kernel (float16 entries, two planes -- the default and the benchmarked one) uses NO scratch at any d; the opt-in geometry mode may park a few
+    dwords (<= 32 bytes, KS = 7..9 and 15 at one plane) but never touches scratch inside a loop."""
+    import subprocess, sys, os, re
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc at %s" % hipcc)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_regs.py"), "gp_eval_compat_mfma.hip"],
+                         capture_output=True, text=True, check=True).stdout
+    seen = 0
+    for line in out.splitlines():
+        m = re.search(r"gp_eval_compat_mfma_kernel<(\d+), (\d+), (\w+), (\d+)>.*scratch\s+(\d+)\s+vgpr\s+(\d+)", line)
+        if not m:
+            continue
+        seen += 1
+        ks, bpc, r16, planes, scratch, vgpr = int(m.group(1)), int(m.group(2)), m.group(3) == "true", int(m.group(4)), int(m.group(5)), int(m.group(6))
+        assert "!!" not in line, "scratch traffic inside a loop: " + line
+        assert vgpr <= 512 // bpc, line                      # 512 VGPRs per SIMD lane, one 256-thread workgroup = one wave per SIMD
+        assert scratch == 0 if r16 else scratch <= 32, line
+    assert seen == 3 * 16                                     # KS = 1..16 (d <= 252) x {as coded, geometry with 1 plane, geometry with 2}
+
+
+def test_root_bound_is_cached_for_the_callers_tensor_only():
+    """the bound of a temporary (a CPU / non-float32 / non-contiguous input converted by _as_device) must not be served from the
+    cache -- the allocator recycles its address for the next call's temporary.  Host logic only: no GPU needed."""
+    import torch
+    from scasml_gp_amd.solvers._picard import PicardEngine
+    eng = PicardEngine.__new__(PicardEngine)
+    eng._bound_cache = None
+    small, large = torch.full((8, 4), 0.25), torch.full((8, 4), 40.0)
+    assert eng._root_bound(small, None, False) == 0.25 and eng._bound_cache is None
+    assert eng._root_bound(large, None, False) == 40.0                       # same shape, no cache: reduced again
+    own = torch.full((8, 4), 0.5)
+    assert eng._root_bound(own, None, True) == 0.5 and eng._bound_cache is not None
+    view = own[:4]
+    assert eng._root_bound(view, None, True) == 0.5                           # a view: its own key
+    own.mul_(6.0)                                                             # in-place change: the version moves, the cache misses
+    assert eng._root_bound(own, None, True) == 3.0
+    other = torch.full((8, 4), 9.0)
+    assert eng._root_bound(other, None, True) == 9.0                          # another tensor object
+    del other
+    assert eng._bound_cache[0]() is None                                      # held weakly: the cache keeps no tensor alive
+    assert eng._root_bound(own, 7.5, True) == 7.5                             # a host bound wins
+
+
 def test_header_is_plain_c(tmp_path):
     """The drop-in boundary is a C ABI: include/scasml_hip.h must compile as C99 with no extensions."""
     import os, subprocess

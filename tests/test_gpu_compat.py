@@ -70,7 +70,7 @@ def test_compat_training_and_evaluation_match_oracle(d, idx, nd, nb):
     tol = 3 * 2.0 ** -11 * np.abs(ogp.right_vector).max()
     r16 = lambda v: 2.0 ** -11 * np.abs(v)             # the product returns u_hat and eps_PDE as float16 values (models/GP.py:671, 769)
     assert np.all(np.abs(gp.predict(X)[:, 0] - ogp.predict(X)[:, 0]) <= 1e-6 * mag + tol + r16(ogp.predict(X)[:, 0]))
-    pts, _ = gp._points_device(X)
+    pts = gp._points_device(X)[0]
     out4 = gp._eval_device(pts).cpu().numpy()
     dt, div, lap = ogp.pde_parts(X)
     assert np.all(np.abs(out4[:, 1] - div[:, 0]) <= 1e-6 * magp + tol * a * d)

@@ -51,7 +51,7 @@ def _raw(gp, X, round16, kinds=None, rows_per_site=0):
     import torch
     from scasml_gp_amd import _lib
     lib = _lib.load()
-    pts, _ = gp._points_device(X)
+    pts = gp._points_device(X)[0]
     out4 = torch.zeros((pts.shape[0], 4), dtype=torch.float32, device="cuda")
     lap = torch.zeros((pts.shape[0],), dtype=torch.float32, device="cuda")
     kd = torch.from_numpy(np.asarray(kinds, dtype=np.uint8)).cuda() if kinds is not None else None
@@ -111,7 +111,7 @@ def test_rounded_entries_match_the_float64_statement_up_to_rounding_flips(d, idx
     assert np.all(np.abs(out4r[:, 0] - out4[:, 0]) <= 2.0 ** -11 * np.abs(out4[:, 0]) + 1e-7)
     # and the device float64 kernel agrees with both
     gp.compat_eval = "float64"
-    pts, _ = gp._points_device(X)
+    pts = gp._points_device(X)[0]
     ref = gp._eval_device(pts).cpu().numpy().astype(np.float64)
     assert np.all(np.abs(ref[:, 0] - ogp.predict(X)[:, 0]) <= 1e-6 * mag["I"] + flip["I"] + 2.0 ** -11 * np.abs(ref[:, 0]))
     assert np.all(np.abs(ref[:, 1] - out4r[:, 1]) <= 2e-5 * mag["div"] + flip["div"])

@@ -182,12 +182,50 @@ def _worker(rank, world, port, case, q):
         dist.destroy_process_group()
 
 
-def _run(world, case, timeout):
+def _worker_rccl(rank, world, port, case, q):
+    """ONE rank under init_process_group("nccl") (RCCL on ROCm) with Comm(force=True): at world == 1 every collective is a copy onto itself,
+    but it is issued through RCCL on device tensors -- from the side stream and the main stream of the look-ahead factorisation -- which is
+    the part of the distributed GP a one-GPU box can execute."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from scasml_gp_amd.dist_gp import Comm, DistCholesky, DistributedGP
+        from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
+        d, nd, nb = 20, 1600, 601                                    # M = 7001, 28 block rows
+        eq, dom, bdy = _problem(d, nd, nb)
+        one = GP_Grad_Dependent_Nonlinear(eq)
+        one.GPsolver(dom, bdy, GN_steps=20)
+        cm = Comm(force=True)
+        assert cm.backend == "nccl" and cm.active and not cm.host and cm.world == 1
+        a = 1.0 / float(one.sigma) ** 2
+        ahead = DistCholesky(d, a, dom, bdy, one.nugget, cm, compat_idx=one.laplacian_idx).build().factor(lookahead=True)
+        calls_factor = dict(cm.calls)
+        plain = DistCholesky(d, a, dom, bdy, one.nugget, Comm(force=False), compat_idx=one.laplacian_idx).build().factor(lookahead=False)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(ahead.R, plain.R))                   # collectives through RCCL on two streams vs none at all: the same factor
+        b = torch.from_numpy(np.random.default_rng(0).standard_normal(ahead.M)).cuda()
+        same = same and bool(torch.equal(ahead.solve(b), plain.solve(b))) and bool(torch.equal(ahead.matvec(b), plain.matvec(b)))
+        del ahead, plain
+        gp = GP_Grad_Dependent_Nonlinear(eq)
+        fit = DistributedGP(gp, cm)
+        fit.fit(dom, bdy, GN_steps=20)
+        rv_err = float(np.abs(gp.right_vector - one.right_vector).max() / np.abs(one.right_vector).max())
+        X = np.concatenate(eq.generate_test_data(200, 40))
+        pred_err = float(np.abs(gp.predict(X).astype(np.float64) - one.predict(X).astype(np.float64)).max())
+        q.put((0, cm.backend, same, calls_factor, dict(cm.calls), rv_err, pred_err, len(gp.loss_history) - len(one.loss_history)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, case, timeout, worker=None):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29600 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q)) for r in range(world)]
+    procs = [ctx.Process(target=worker or _worker, args=(r, world, port, case, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=timeout) for _ in procs)
@@ -230,3 +268,14 @@ def test_a_failed_pivot_on_one_rank_raises_on_every_rank():
     status is accumulated over the blocks and all-reduced once, so both ranks raise (instead of one leaving the other in a collective)."""
     res = _run(2, "indefinite", 300)
     assert len(res) == 2 and all(msg.startswith("ValueError") and "not positive definite" in msg for _, msg in res), res
+
+
+def test_one_rank_under_rccl_issues_every_collective_of_the_distributed_fit():
+    """init_process_group("nccl") with one rank in a fresh child process, Comm(force=True): broadcast, all_reduce and
+    all_gather_into_tensor run through RCCL on device tensors from both streams of the look-ahead factorisation; the factor, the solves and
+    the as-coded Newton-CG fit (M = 7001) equal the collective-free / single-GPU results."""
+    (_, backend, same, calls_factor, calls, rv_err, pred_err, dsteps), = _run(1, "rccl", 900, worker=_worker_rccl)
+    assert backend == "nccl" and same
+    assert calls_factor["broadcast"] == 28 and calls_factor["all_gather"] == 27 and calls_factor["all_reduce"] == 1, calls_factor
+    assert calls["broadcast"] > 1000 and calls["all_reduce"] > 1000, calls          # the substitutions of every CG product
+    assert rv_err <= 1e-6 and pred_err <= 2.0 ** -10 and dsteps == 0, (rv_err, pred_err, dsteps)

@@ -60,6 +60,22 @@ def test_gram_on_float16_rows_follows_the_float16_op_sequence():
     _lib.check(lib.scasml_gp_gram_compat_rows(d, a, _lib.ptr(xd), nd, _lib.ptr(xb), nb, idx.ctypes.data_as(C.c_void_p), 5, 100, 300, M, _lib.ptr(out), M,
                                               _lib.stream_ptr()), "gram rows")
     assert torch.equal(out, K[5][100:400])
+    # in this arithmetic K is NOT symmetric -- P[dt][div] and its mirror are two different float16 rounding sequences (with one rounding
+    # per entry the matrix is symmetric).  Every factorisation in the product (scasml_cholesky, DistCholesky, the oracle's eigh) reads the LOWER
+    # triangle: K_p := tril(K) + tril(K, -1)^T.  Pinned here so the three cannot part: the factor of K equals the factor of that matrix bit for bit.
+    assert bool((K[1] == K[1].T).all()) and float((K[5] != K[5].T).double().mean()) > 0.01
+    Mp = (M + 31) // 32 * 32
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    factors = []
+    for mat in (K[5], torch.tril(K[5]) + torch.tril(K[5], -1).T):
+        Lp = torch.eye(Mp, dtype=torch.float64, device="cuda")
+        Lp[:M, :M] = mat
+        _lib.check(lib.scasml_cholesky(_lib.ptr(Lp), Mp, 1e-2, _lib.ptr(info), _lib.stream_ptr()), "cholesky")
+        assert int(info.item()) == 0
+        factors.append(Lp)
+    assert torch.equal(factors[0], factors[1])
+    low = np.tril(got) + np.tril(got, -1).T
+    assert np.abs(np.linalg.cholesky(low + 1e-2 * np.eye(M)) - factors[0][:M, :M].cpu().numpy()).max() < 1e-9
 
 
 @pytest.mark.parametrize("d", [20, 40])

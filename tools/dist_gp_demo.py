@@ -5,6 +5,8 @@ GPsolver on the same data.  Prints one JSON line per rank 0.
 
     python tools/dist_gp_demo.py --ranks 2 --d 250 --n-dom 8333 --n-bdy 1667      # M = 34 999: BASELINE configs[4], staged
     python tools/dist_gp_demo.py --compat none ...                                 # the documented operators instead of the as-coded surrogate
+    python tools/dist_gp_demo.py --ranks 1 --backend nccl ...                      # one rank, every collective issued through RCCL
+    python tools/dist_gp_demo.py --n-dom 16667 --n-bdy 3333 --factor-only          # M = 70 001 (39 GB): past 2^31 matrix elements
 """
 import argparse
 import json
@@ -22,8 +24,12 @@ def worker(rank, world, port, args, q):
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if args.backend == "nccl":        # RCCL: one rank per GPU; on a one-GPU box that is ONE rank, with every collective forced through the backend
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from scasml_gp_amd.dist_gp import Comm, DistCholesky, DistributedGP
+    force = args.backend == "nccl" and world == 1
     from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
     from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
     eq = Grad_Dependent_Nonlinear(args.d + 1)
@@ -31,11 +37,11 @@ def worker(rank, world, port, args, q):
     dom, bdy = eq.generate_data(args.n_dom, args.n_bdy)
     xt = np.concatenate(eq.generate_test_data(500, 100))
     compat = None if args.compat == "none" else "reference"
-    out = {"ranks": world, "d": args.d, "collocation": "%d+%d" % (args.n_dom, args.n_bdy), "surrogate": "as coded (compat='reference')" if compat else "documented operators"}
+    out = {"ranks": world, "backend": dist.get_backend(), "collectives_forced_at_one_rank": force, "d": args.d, "collocation": "%d+%d" % (args.n_dom, args.n_bdy), "surrogate": "as coded (compat='reference')" if compat else "documented operators"}
     say = lambda msg: print("[rank %d, %.0f s] %s" % (rank, time.perf_counter() - t_start, msg), file=sys.stderr, flush=True) if rank == 0 else None
     t_start = time.perf_counter()
     probe = GP_Grad_Dependent_Nonlinear(eq, compat=compat)
-    cm = Comm()
+    cm = Comm(force=force)
     # stage timings of the distributed factorisation alone
     torch.cuda.synchronize(); t0 = time.perf_counter()
     ch = DistCholesky(args.d, 1.0 / (0.25 ** 2 * args.d), dom, bdy, 1e-2, cm, compat_idx=probe.laplacian_idx).build()
@@ -51,11 +57,19 @@ def worker(rank, world, port, args, q):
     torch.cuda.synchronize(); t4 = time.perf_counter()
     out.update(M=ch.M, block_rows=ch.nblk, panel_gb_per_rank=round(ch.memory_bytes() / 1e9, 2), gram_s=round(t1 - t0, 3),
                factor_s=round(t2 - t1, 3), factor_tflops_all_ranks=round(ch.M ** 3 / 3 / (t2 - t1) / 1e12, 2),
-               solve_s=round(t3 - t2, 3), matvec_s=round(t4 - t3, 3), collective_gb_per_rank=round(cm.bytes_moved / 1e9, 2))
+               solve_s=round(t3 - t2, 3), matvec_s=round(t4 - t3, 3), collective_gb_per_rank=round(cm.bytes_moved / 1e9, 2),
+               collective_calls=dict(cm.calls),
+               gram_pair_rows_per_s=round(sum(min(256, ch.M - i * 256) for i in ch.mine) * (args.n_dom + args.n_bdy) / (t1 - t0), 1))
     del ch
     torch.cuda.empty_cache()
+    if args.factor_only:
+        if rank == 0:
+            q.put(out)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     gp = GP_Grad_Dependent_Nonlinear(eq, compat=compat)
-    fit = DistributedGP(gp, Comm())
+    fit = DistributedGP(gp, Comm(force=force))
     torch.cuda.synchronize(); t0 = time.perf_counter()
     say("distributed fit starts")
     fit.fit(dom, bdy, GN_steps=20)
@@ -87,10 +101,15 @@ def main():
     ap.add_argument("--n-dom", type=int, default=8333)
     ap.add_argument("--n-bdy", type=int, default=1667)
     ap.add_argument("--no-single", action="store_true")
+    ap.add_argument("--factor-only", action="store_true", help="Gram rows, factorisation, one solve and one matvec; no Newton fit")
+    ap.add_argument("--backend", choices=["gloo", "nccl"], default="gloo",
+                    help="nccl = RCCL: needs one GPU per rank, so --ranks 1 on a one-GPU box (every collective is then forced through RCCL: Comm(force=True))")
     ap.add_argument("--compat", choices=["reference", "none"], default="reference",
                     help="reference (default): the as-coded surrogate -- Gram rows of scasml_gp_gram_compat_rows, the float16-rounded matrix solved by a second "
                          "distributed factorisation; none: the documented operators")
     args = ap.parse_args()
+    if args.backend == "nccl" and args.ranks != 1:
+        raise SystemExit("--backend nccl on this one-GPU tool needs --ranks 1 (RCCL refuses two ranks on one device)")
     import socket
     import torch.multiprocessing as mp
     with socket.socket() as sk:
