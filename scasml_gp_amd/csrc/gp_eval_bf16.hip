@@ -1,11 +1,7 @@
 // Fused GP posterior evaluation with x.y on the 16-bit matrix cores (split arithmetic).
 //
-// Why: on gfx950 the fp32-input MFMA (v_mfma_f32_32x32x2_f32) runs at the fp32 VALU rate, 1/16 of the 16-bit MFMA; the
-// epilogue keeps the vector ALUs busy ~0.9 of the launch, and matrix time does not hide under vector time on this chip: a 32x32x16
-// MFMA and the vector instructions around it take the SUM of their times, in one wave or across the waves of a SIMD (round 1's ablation of
-// this kernel; round 3's of gp_eval_compat_mfma.hip and tools/ubench_chain.hip, profiles/r03_compat_eval_experiments.txt -- the SQ counters'
-// "co-execution 0.55 of the MFMA-busy cycles" of profiles/r02_gp_eval_pmc.json is issue during the other pipe's tail, not throughput; with
-// both pipes in use the chip holds 1.54 GHz) -- so the matrix part has to be made short.
+// Why: on gfx950 the fp32-input MFMA (v_mfma_f32_32x32x2_f32) runs at the fp32 VALU rate, 1/16 of the 16-bit MFMA, and in this kernel matrix
+// time does not hide under vector time (the launch is the sum of the two: profiles/HISTORY.md 4.2, 4.4) -- so the matrix part is made short.
 // Each fp32 operand is split by truncation into bf16 planes  v = hi + mid + lo  (exact to 2^-24 |v|); the products hi*hi, hi*mid, mid*hi, mid*mid, hi*lo,
 // lo*hi carry every term down to 2^-24, i.e. x.y is as exact as the fp32 MFMA (SPLIT = 3, 6 MFMAs per
 // K-step); SPLIT = 2 keeps hi/mid only (3 MFMAs, ~2^-17 per product).  Accumulation is fp32 in the MFMA.
@@ -28,8 +24,7 @@
 // collocation tile one LDS slot [planes*KS KiB of A fragments | 2 KiB constants] filled two tiles ahead by
 // LDS-DMA; one barrier per tile.  The operands are scaled so that the product is the exponent of the kernel
 // (gp_common.hpp, gp_epilogue_scaled); tiles of boundary rows run a shorter epilogue.  Every wave does MFMAs then
-// epilogue of the same tile; the four waves of a SIMD belong to four unsynchronised workgroups (forcing a stagger or s_setprio
-// changed nothing, profiles/r02_gp_eval_experiments.txt -- there is no overlap to arrange, see above).
+// epilogue of the same tile; the four waves of a SIMD belong to four unsynchronised workgroups.
 #include <stdlib.h>
 #include <type_traits>
 

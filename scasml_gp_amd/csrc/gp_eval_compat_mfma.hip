@@ -25,15 +25,8 @@
 // reads the fp16 half directly: a rounding costs half a vector instruction.  A rounding decision can differ from the float64
 // statement's where the float32 value lands within ~2^-20 of a float16 midpoint (about 1 entry in 500); tests bound the effect.
 //
-// Where the launch time goes (profiles/r03_compat_eval_experiments.txt, r04_compat_eval_experiments.txt, r04_ubench_hetero.txt).  The launch time is
-// vector time PLUS matrix time, however the two kinds of instruction are arranged: a MFMA-only wave starves the vector-only waves beside it on its SIMD
-// (one instruction per 16 cycles each), and although waves that interleave both pay only ~8 issue cycles per MFMA in CYCLES, the chip's clock follows
-// the MFMA density (a stage of 15 MFMAs + the epilogue's vector mix: 4083 cycles at 1.99 GHz; with 8 MFMAs 3781 cycles at 2.33 GHz): every
-// instruction of either kind is paid for in time.  Built, measured and removed: the sums' ~16 v_fma_mix_f32 per pair on the matrix pipe (as a second
-// 32x32x16 MFMA: 21.25 ms against 19.75; as v_mfma_f32_4x4x4_16b_f16: 2.776 against 2.759 ms on 9216 workgroups), three in-wave software pipelines
-// (3 - 10 % slower), a low point plane on the MX-scaled FP6 path (10 MFMAs per stage instead of 15; 19.67 against 19.57 / 19.30 ms).  Kept: reads not run
-// ahead (one A-fragment register set, row constants read where used), which fits KS = 7 into 128 registers = a fourth wave per SIMD (19.3 -> 19.1 ms);
-// and, for callers who do not need the reference's rounding noise, the geometry mode below (12.4 ms).
+// Cost model: the launch time is vector time PLUS matrix time (the chip's clock follows the MFMA density), so the levers are fewer instructions of
+// either kind, not their arrangement; the measurements and the rejected arrangements are in profiles/HISTORY.md (4.4).
 //
 // Structure (as gp_eval_bf16.hip): 4-wave workgroups, 32 points per wave held in VGPRs as two fp16 planes for the whole sweep;
 // the unit of work is a STAGE = (collocation tile of 32 rows, geometry): [KS KiB A fragments | 1 KiB Q fragment | 1 KiB row

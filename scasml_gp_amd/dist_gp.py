@@ -156,6 +156,27 @@ class DistCholesky:
     def memory_bytes(self):
         return len(self.mine) * BLK * self.Mp * 8
 
+    @staticmethod
+    def budget(d, n_dom, n_bdy, world, rank=0):
+        """Device bytes this class allocates on ``rank`` for a fit of n_dom + n_bdy collocation points over ``world`` ranks, by buffer: what
+        __init__, build(), factor() and solve() hold at their peak (DESIGN.md section 6 prints this table for configs[4]).  Pure arithmetic:
+        usable without a GPU."""
+        M = 4 * n_dom + n_bdy
+        nblk = (M + BLK - 1) // BLK
+        Mp = nblk * BLK
+        owned = len(owned_blocks(nblk, rank, world))
+        blk = BLK * BLK * 8
+        cnt = (nblk - 1 + world - 1) // world                 # blocks per rank in the widest column panel (step k = 0)
+        out = {"M": M, "block_rows": nblk, "owned_block_rows": owned,
+               "panel_R": owned * BLK * Mp * 8,                # build(): this rank's block rows, full width (columns beyond the block's own stay zero)
+               "diag_factors": nblk * blk,                     # factor(): every diagonal factor, replicated (broadcast in step 1, reused by solve())
+               "collocation_f32": (n_dom + n_bdy) * (d + 1) * 4,
+               # factor(), per step: the send buffer, the gathered panel and its reordered copy; with look-ahead the panels of steps k and k + 1 coexist
+               "panel_exchange_peak": cnt * blk + world * cnt * blk + 2 * (nblk - 1) * blk,
+               "vectors": 6 * Mp * 8}                          # solve() / matvec(): right-hand side, y, x, accumulator, local rows, output
+        out["total"] = sum(v for k, v in out.items() if k not in ("M", "block_rows", "owned_block_rows"))
+        return out
+
     # -------------------------------------------------------------------------------------------- Gram
     def build(self):
         torch = _lib.require_gpu()
@@ -347,7 +368,8 @@ class DistributedGP:
         self.cg_iterations = []
         self.gauss_newton_steps = 0
 
-    def fit(self, x_t_domain, x_t_boundary, GN_steps=20, cg_tol=1e-10, cg_max=400):
+    def fit(self, x_t_domain, x_t_boundary, GN_steps=20, cg_tol=1e-10, cg_max=400, progress=None):
+        """progress: optional callable(str), told about every Newton step (long fits on a shared box must show signs of life)."""
         torch = _lib.require_gpu()
         lib, s = _lib.load(), _lib.stream_ptr()
         gp = self.gp
@@ -429,6 +451,8 @@ class DistributedGP:
             sol = sol + step                                            # alpha = 1, :541,573
             loss, Ab = residual(sol)
             hist.append(loss)
+            if progress is not None:
+                progress("Newton step %d: loss %.6g, %d CG products" % (len(hist) - 1, loss, it))
         gp.loss_history = hist
         gp.grad_norms = self.grad_norms
         gp._sol = sol

@@ -292,6 +292,20 @@ def test_root_bound_is_cached_for_the_callers_tensor_only():
     assert eng._root_bound(own, 7.5, True) == 7.5                             # a host bound wins
 
 
+def test_distributed_gp_memory_budget_for_configs4():
+    """DESIGN.md section 6 prints DistCholesky.budget for BASELINE configs[4] (d = 250, 83 333 + 16 667 collocation points, 8 ranks); the numbers
+    are pinned here, and tests/test_gpu_xl.py checks the same function against what the class really allocates at M = 70 001."""
+    from scasml_gp_amd.dist_gp import DistCholesky
+    b = DistCholesky.budget(250, 83333, 16667, 8)
+    assert (b["M"], b["block_rows"], b["owned_block_rows"]) == (349999, 1368, 171)
+    assert b["panel_R"] == 171 * 256 * 350208 * 8 and round(b["panel_R"] / 1e9, 1) == 122.6
+    assert b["diag_factors"] == 1368 * 256 * 256 * 8 and 125e9 < b["total"] < 127e9          # fits a 288 GB MI355X more than twice over
+    assert 247e9 < DistCholesky.budget(250, 83333, 16667, 4)["total"] < 250e9                # four GPUs: still fits
+    one = DistCholesky.budget(250, 16667, 3333, 1)
+    assert one["panel_R"] == 274 * 256 * 70144 * 8 and one["M"] == 70001
+    assert sum(DistCholesky.budget(250, 16667, 3333, 2, r)["owned_block_rows"] for r in range(2)) == 274
+
+
 def test_header_is_plain_c(tmp_path):
     """The drop-in boundary is a C ABI: include/scasml_hip.h must compile as C99 with no extensions."""
     import os, subprocess

@@ -38,6 +38,13 @@ def test_bench_prints_one_contract_line(extra):
     assert abs(chk["rel_l2"]["MLP"] - chk["logged"]["MLP"]) <= 5e-4 * chk["logged"]["MLP"]
     if not extra:                                     # the default is the reference's as-coded surrogate
         assert "as-coded" in j["config"]["surrogate"] and j["l2_rel_error"]["vs_cpu_oracle"]["abs_diff"] <= 1e-3
+    # the other BASELINE configurations and modes, timed in the same process (5 steps each)
+    runs = j["other_runs"]
+    assert "configs[1]" in runs[0]["workload"] and "B=1048576" in runs[0]["workload"] and runs[0]["kernel_ms"]["picard_mlp"] > 0
+    if "--solver" not in extra:
+        assert len(runs) == (4 if not extra else 3) and "configs[3]" in runs[1]["workload"] and "parity" in runs[2]["workload"]
+        assert all(r["value"] > 0 and r["ms_per_step"] > 0 and r["steps"] == 5 and r["kernel_ms"]["gp_eval"] > 0 for r in runs[1:])
+        assert not extra or "reference-geometry" not in runs[-1]["workload"]
 
 
 @pytest.mark.gpu
@@ -100,7 +107,7 @@ def test_the_rccl_branches_execute_on_one_rank():
     the barriers and MAX-reduction around the timed region, an all-reduce of the path's (B, 1+d) partial-sum buffer, the teardown --
     execute on this image, with WORLD_SIZE = 1 (SCASML_BENCH_FORCE_DIST=1)."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "256",
-           "--train-domain", "96", "--train-boundary", "32", "--no-cpu-baseline"]
+           "--train-domain", "96", "--train-boundary", "32", "--no-cpu-baseline", "--no-other-runs"]
     env = dict(os.environ, SCASML_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 200),
                RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)

@@ -32,12 +32,18 @@ def _oracle_with(gp, d):
     return oeq, ogp
 
 
-def _assert_close_to_oracle(gp, got, want):
+def _assert_close_to_oracle(eng, n, par, x_rows, root0, stream_id, got, want):
+    """As-coded surrogate on the matrix cores: u_hat and eps_PDE are float16 VALUES, so a plain tolerance would have to be ~1e-2 wide on z.
+    tests/_explained_parity.py accounts for every element instead (oracle == float64-kernel device run to 5e-5 + 2e-4 |want|; the product run
+    differs from that one ONLY through u_hat / eps_PDE values that land one float16 ulp apart; negative controls).  Documented operators:
+    the plain tight tolerance."""
+    gp = eng.gp
     diff = np.abs(got - want)
     if gp.compat == "reference":
-        # u_hat and eps_PDE are float16 values: an entry rounded differently (float32 value here, float64 there) moves u_hat by one float16
-        # ulp and a z component by that times N / (MC delta_t) -- rare and bounded (tests/test_gpu_full_size.py uses the same bounds)
-        assert diff[:, 0].max() < 3e-4 and (diff > 1e-4).mean() < 0.08 and diff.max() < 1e-2, (diff[:, 0].max(), (diff > 1e-4).mean(), diff.max())
+        from _explained_parity import assert_explained
+        again = assert_explained(eng, n, par, x_rows, root0, stream_id, want)
+        assert np.array_equal(again, got.astype(np.float64))      # the accounted-for run IS the run under test
+        assert diff[:, 0].max() < 6e-4, diff[:, 0].max()          # u: at most a float16 ulp of u_hat's scale through the mean
     else:
         assert np.all(diff <= 5e-5 + 2e-4 * np.abs(want)), diff.max()
 
@@ -100,7 +106,8 @@ def test_config3_full_history_n4_matches_oracle_on_sampled_roots(config3):
     want = np.concatenate([ora.uz_solve(N3, M3, x_t[r:r + 1], root0=int(r)) for r in rows])
     got = full[rows].cpu().numpy()
     if gp.compat == "reference":
-        _assert_close_to_oracle(gp, got, want)
+        for r, g_row, w_row in zip(rows, got, want):
+            _assert_close_to_oracle(solver._engine, N3, M3, x_t[r:r + 1], int(r), 5, g_row[None], w_row[None])
     else:
         assert np.max(np.abs(got - want)) < 1e-4          # outputs are clipped to +-0.1
     from scasml_gp_amd import tables
@@ -145,7 +152,7 @@ def test_config4_d250_two_thousand_collocation_points_scasml_n3_matches_oracle(c
     hip = ScaSML(eq, gp, seed=2)
     got = hip.uz_solve(3, 3, xt)
     want = PicardOracle(oeq, "quad", gp=ogp, seed=2, stream=0).uz_solve(3, 3, xt)
-    _assert_close_to_oracle(gp, got, want)
+    _assert_close_to_oracle(hip._engine, 3, 3, xt, 0, 0, got, want)
 
 
 def test_config4_fit_at_ten_thousand_collocation_points():

@@ -159,14 +159,23 @@ def test_block_row_path_at_world_1_equals_the_single_gpu_gram_and_factor(factore
     from scasml_gp_amd.dist_gp import BLK, DistCholesky
     gp, Kp, dom, bdy = factored
     L = gp.cholesky_phi_phi_perturb
+    torch.cuda.synchronize()
+    before = torch.cuda.memory_allocated()
     ch = DistCholesky(D, 1.0 / float(gp.sigma) ** 2, dom, bdy, gp.nugget, compat_idx=gp.laplacian_idx).build()
-    assert ch.M == M_XL and ch.nblk == 274 and ch.memory_bytes() == 274 * 256 * 70144 * 8 and ch.R.numel() > 2 ** 32
+    budget = DistCholesky.budget(D, N_DOM, N_BDY, 1)
+    assert ch.M == M_XL and ch.nblk == 274 and ch.memory_bytes() == budget["panel_R"] == 274 * 256 * 70144 * 8 and ch.R.numel() > 2 ** 32
     for i in (273, 272, 200, 137, 1):                        # Gram rows (scasml_gp_gram_rows / _compat_rows) against the full-matrix kernels
         r0, r1 = i * BLK, min((i + 1) * BLK, M_XL)
         mine = torch.tril(ch.R[r0:r1, :M_XL], diagonal=r0 - 1)
         assert torch.equal(mine, torch.tril(Kp[r0:r1], diagonal=r0 - 1)), i
+    del mine
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
     ch.factor()
     torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() - before
+    # the per-rank budget DESIGN.md section 6 prints for M = 350 000 is this function: what the class really held at its peak stays inside it
+    assert budget["panel_R"] <= peak <= budget["total"] + (64 << 20), (peak, budget)
     scale, worst = float(L.abs().max()), 0.0
     for i in range(ch.nblk):
         r0, r1 = i * BLK, min((i + 1) * BLK, M_XL)

@@ -72,7 +72,7 @@ def worker(rank, world, port, args, q):
     fit = DistributedGP(gp, Comm(force=force))
     torch.cuda.synchronize(); t0 = time.perf_counter()
     say("distributed fit starts")
-    fit.fit(dom, bdy, GN_steps=20)
+    fit.fit(dom, bdy, GN_steps=20, progress=say)
     torch.cuda.synchronize(); t1 = time.perf_counter()
     say("distributed fit done")
     out.update(fit_s=round(t1 - t0, 2), newton_steps=len(gp.loss_history) - 1, cg_products=fit.cg_iterations,
