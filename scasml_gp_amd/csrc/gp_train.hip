@@ -78,81 +78,6 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int64_t M, i
     for (int j = 0; j < NB; ++j) A[r * M + k0 + j] = x[j];
 }
 
-// (1 + 2) in ONE launch: every panel workgroup refactors the diagonal block in LDS -- 11 kflop, redundantly, with the arithmetic of
-// chol_diag_kernel element for element (the factor is bit-identical) -- and then solves its 256 rows against it.  A step of the small
-// factorisations is three dependent ~12 us launches; this removes one of them (M = 4224: 132 launches).  The factored block cannot be
-// written in place (a workgroup that starts late would read it instead of A_kk): workgroup 0 PARKS it in the block to the right of
-// the diagonal block (upper triangle: rows k0 .. k0+31 are final and nothing reads above the diagonal), and chol_commit_diag_kernel
-// moves every parked block home before the upper triangle is cleared.
-__global__ __launch_bounds__(256) void chol_diag_panel_kernel(double *A, int64_t M, int64_t k0, int32_t *info) {
-    __shared__ double T[NB][NB + 1], Lk[NB][NB + 1];
-    __shared__ double sd[2], pinv[2];
-    const int c = threadIdx.x & 31, rq = threadIdx.x >> 5;      // element (r, c), r = rq + 8 i
-#pragma unroll
-    for (int i = 0; i < 4; ++i) T[rq + 8 * i][c] = A[(k0 + rq + 8 * i) * M + (k0 + c)];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const double v = T[0][0];
-        if (!(v > 0.0)) {
-            if (blockIdx.x == 0 && *info == 0) *info = (int32_t)(k0 + 1);
-            sd[0] = pinv[0] = nan("");
-        } else {
-            sd[0] = sqrt(v);
-            pinv[0] = 1.0 / sd[0];
-        }
-    }
-    __syncthreads();
-    for (int j = 0; j < NB; ++j) {
-        const double is = pinv[j & 1];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = rq + 8 * i;
-            if (c == j) {
-                Lk[r][j] = r == j ? sd[j & 1] : (r > j ? T[r][j] * is : 0.0);
-            } else if (c > j && r >= c) {
-                const double v = fma(-(T[r][j] * is), T[c][j] * is, T[r][c]);
-                T[r][c] = v;
-                if (r == j + 1 && c == j + 1) {
-                    if (!(v > 0.0)) {
-                        if (blockIdx.x == 0 && *info == 0) *info = (int32_t)(k0 + j + 2);
-                        sd[(j + 1) & 1] = pinv[(j + 1) & 1] = nan("");
-                    } else {
-                        const double sq = sqrt(v);
-                        sd[(j + 1) & 1] = sq;
-                        pinv[(j + 1) & 1] = 1.0 / sq;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if (blockIdx.x == 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) A[(k0 + rq + 8 * i) * M + (k0 + NB + c)] = Lk[rq + 8 * i][c];
-    }
-    const int64_t r = k0 + NB + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= M) return;
-    double x[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) x[j] = A[r * M + k0 + j];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        double v = x[j];
-#pragma unroll
-        for (int p = 0; p < j; ++p) v = fma(-x[p], Lk[j][p], v);
-        x[j] = v / Lk[j][j];
-    }
-#pragma unroll
-    for (int j = 0; j < NB; ++j) A[r * M + k0 + j] = x[j];
-}
-
-// every parked diagonal factor (all blocks but the last, which chol_diag_kernel factors in place) -> its own block
-__global__ __launch_bounds__(NB *NB) void chol_commit_diag_kernel(double *A, int64_t M) {
-    const int64_t k0 = (int64_t)blockIdx.x * NB;
-    const int r = threadIdx.y, c = threadIdx.x;
-    A[(k0 + r) * M + (k0 + c)] = A[(k0 + r) * M + (k0 + NB + c)];
-}
-
 // ---- C(TB x TB) -= A(TB x K) * B(K x TB) on the FP64 matrix cores ------------------------------------
 // v_mfma_f64_16x16x4_f64: lane l supplies A[row = l&15][k = l>>4] and B[k = l>>4][col = l&15]; the four
 // results of a lane are C[row = (l>>4) + 4*i][col = l&15], i = 0..3 (cdna_hip_programming.md section 3: the
@@ -842,18 +767,12 @@ extern "C" int scasml_cholesky(double *A, int64_t M, double nugget, int32_t *inf
     constexpr int64_t kOuter = kOuterRows;
     auto factor_panel = [&](int64_t J, int64_t jend, hipStream_t q) {   // columns [J, jend) final, all rows
         for (int64_t k0 = J; k0 < jend; k0 += NB) {
-            const int64_t rest = M - k0 - NB;
-#if SCASML_CHOL_SPLIT_DIAG   // development A/B: the diagonal block and the panel as two launches
+            // the diagonal block and the panel stay two launches: refactoring the block inside every panel workgroup (one launch fewer per
+            // step) measured SLOWER, 6.1 against 4.9 ms at M = 4224 (profiles/r05_cholesky_fused_diag_panel.txt)
             hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(NB, NB), 0, q, A, M, k0, info_dev);
+            const int64_t rest = M - k0 - NB;
             if (rest <= 0) break;
             hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)((rest + 255) / 256)), dim3(256), 0, q, A, M, k0);
-#else
-            if (rest <= 0) {                                     // the last block: nothing below it, factored in place
-                hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(NB, NB), 0, q, A, M, k0, info_dev);
-                break;
-            }
-            hipLaunchKernelGGL(chol_diag_panel_kernel, dim3((unsigned)((rest + 255) / 256)), dim3(256), 0, q, A, M, k0, info_dev);
-#endif
             if (k0 + NB < jend) launch_chol_update<2>(A, M, k0, NB, k0 + NB, jend, q);
         }
     };
@@ -883,9 +802,6 @@ extern "C" int scasml_cholesky(double *A, int64_t M, double nugget, int32_t *inf
         }
         la.close();
     }
-#if !SCASML_CHOL_SPLIT_DIAG
-    if (M > NB) hipLaunchKernelGGL(chol_commit_diag_kernel, dim3((unsigned)(M / NB - 1)), dim3(NB, NB), 0, s, A, M);
-#endif
     hipLaunchKernelGGL(zero_upper_kernel, dim3((unsigned)((M + 255) / 256), row_grid(M)), dim3(256), 0, s, A, M);
     return check_launch("cholesky launch");
 }
