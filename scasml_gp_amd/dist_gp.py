@@ -141,6 +141,8 @@ class DistCholesky:
         self.mine = owned_blocks(self.nblk, self.comm.rank, self.comm.world)
         self.R = None
         self.diag = [None] * self.nblk          # replicated 256 x 256 diagonal factors
+        self.ninv = None                        # -L_kk^-1 of each, made by the first solve() (_neg_inverse_blocks)
+        self._mine_dev = None
         self.info = torch.zeros(1, dtype=torch.int32, device="cuda")
         self.bad = torch.zeros(1, dtype=torch.float64, device="cuda")   # blocks this rank found not positive definite (scasml_cholesky resets info per call)
 
@@ -169,7 +171,7 @@ class DistCholesky:
         cnt = (nblk - 1 + world - 1) // world                 # blocks per rank in the widest column panel (step k = 0)
         out = {"M": M, "block_rows": nblk, "owned_block_rows": owned,
                "panel_R": owned * BLK * Mp * 8,                # build(): this rank's block rows, full width (columns beyond the block's own stay zero)
-               "diag_factors": nblk * blk,                     # factor(): every diagonal factor, replicated (broadcast in step 1, reused by solve())
+               "diag_factors": 2 * nblk * blk,                 # factor(): every diagonal factor, replicated (broadcast in step 1); solve(): -L_kk^-1 of each
                "collocation_f32": (n_dom + n_bdy) * (d + 1) * 4,
                # factor(), per step: the send buffer, the gathered panel and its reordered copy; with look-ahead the panels of steps k and k + 1 coexist
                "panel_exchange_peak": cnt * blk + world * cnt * blk + 2 * (nblk - 1) * blk,
@@ -286,61 +288,84 @@ class DistCholesky:
     # -------------------------------------------------------------------------------------------- substitutions
     def _local_rows(self, v):
         """The owned block rows of a replicated vector of length Mp, stacked."""
+        return v.view(self.nblk, BLK)[self._mine_idx()].reshape(-1).clone() if self.mine else v.new_zeros(0)
+
+    def _mine_idx(self):
         torch = _lib.require_gpu()
-        return v.view(self.nblk, BLK)[torch.as_tensor(self.mine, device="cuda", dtype=torch.long)].reshape(-1).clone() if self.mine \
-            else v.new_zeros(0)
+        if self._mine_dev is None:
+            self._mine_dev = torch.as_tensor(self.mine, device="cuda", dtype=torch.long)
+        return self._mine_dev
+
+    def _neg_inverse_blocks(self):
+        """-L_kk^-1 of every (replicated) diagonal factor, made once after factor(): a substitution step's 256 x 256 triangular solve of ONE vector
+        is then a single 256 x 256 product (scasml_gemv_sub: y -= (-L^-1) b) instead of the sixteen launches of the blocked scasml_trsm_lower --
+        the substitutions are chains of 2 x nblk dependent steps, i.e. launch-latency bound (M = 70 001: 107 -> 40 ms per solve)."""
+        torch = _lib.require_gpu()
+        if self.ninv is None:
+            lib, s = self.lib, _lib.stream_ptr()
+            ninv = torch.zeros((self.nblk, BLK, BLK), dtype=torch.float64, device="cuda")
+            ninv.diagonal(dim1=1, dim2=2).fill_(-1.0)
+            for k in range(self.nblk):
+                _lib.check(lib.scasml_trsm_lower(_lib.ptr(self.diag[k]), BLK, _lib.ptr(ninv[k]), BLK, 0, s), "trsm(diag^-1)")
+            self.ninv = ninv
+        return self.ninv
 
     def solve(self, b):
         """x = (L L^T)^-1 b for a replicated b (length M; a CUDA float64 tensor); returns x replicated."""
         torch = _lib.require_gpu()
         lib, s, cm = self.lib, _lib.stream_ptr(), self.comm
         R, Mp, nb, w, rank = self.R, self.Mp, self.nblk, cm.world, cm.rank
+        ninv = self._neg_inverse_blocks()
         bp = torch.zeros(Mp, dtype=torch.float64, device="cuda")
         bp[:self.M] = b
         loc = self._local_rows(bp)
-        y = torch.empty(Mp, dtype=torch.float64, device="cuda")
+        rhs = torch.empty(Mp, dtype=torch.float64, device="cuda")   # block k: the up-to-date right-hand side of step k, replicated by the broadcast
+        y = torch.zeros(Mp, dtype=torch.float64, device="cuda")
         for k in range(nb):                                    # forward: L y = b, right-looking
             owner = k % w
-            yk = y[k * BLK:(k + 1) * BLK]
+            bk, yk = rhs[k * BLK:(k + 1) * BLK], y[k * BLK:(k + 1) * BLK]
             if rank == owner:
                 slot = (k - rank) // w
-                yk.copy_(loc[slot * BLK:(slot + 1) * BLK])
-            cm.broadcast(yk, owner)
-            _lib.check(lib.scasml_trsm_lower(_lib.ptr(self.diag[k]), BLK, _lib.ptr(yk), 1, 0, s), "trsm(diag)")
+                bk.copy_(loc[slot * BLK:(slot + 1) * BLK])
+            cm.broadcast(bk, owner)
+            _lib.check(lib.scasml_gemv_sub(_lib.ptr(ninv[k]), BLK, BLK, BLK, _lib.ptr(bk), _lib.ptr(yk), 0, s), "gemv(diag^-1)")   # y_k = L_kk^-1 b_k
             s0 = self._slot0(k)
             rows = (len(self.mine) - s0) * BLK
             if rows:
                 _lib.check(lib.scasml_gemv_sub(self._ptr(R, s0 * BLK, k * BLK, Mp), Mp, rows, BLK, _lib.ptr(yk),
                                                C.c_void_p(loc.data_ptr() + 8 * s0 * BLK), 0, s), "gemv_sub")
-        x = torch.empty(Mp, dtype=torch.float64, device="cuda")
-        acc = torch.zeros(Mp, dtype=torch.float64, device="cuda")   # this rank's share of sum_{i > k} L_ik^T x_i, all k
+        x = torch.zeros(Mp, dtype=torch.float64, device="cuda")
+        acc = torch.zeros(Mp, dtype=torch.float64, device="cuda")   # this rank's share of -sum_{i > k} L_ik^T x_i, all k
         for k in range(nb - 1, -1, -1):                        # backward: L^T x = y
-            xk = x[k * BLK:(k + 1) * BLK]
-            xk.copy_(acc[k * BLK:(k + 1) * BLK])
-            cm.all_reduce(xk)
-            xk.add_(y[k * BLK:(k + 1) * BLK])                  # acc holds minus the sums
-            _lib.check(lib.scasml_trsm_lower(_lib.ptr(self.diag[k]), BLK, _lib.ptr(xk), 1, 1, s), "trsm^T(diag)")
+            tk, xk = rhs[k * BLK:(k + 1) * BLK], x[k * BLK:(k + 1) * BLK]
+            tk.copy_(acc[k * BLK:(k + 1) * BLK])
+            cm.all_reduce(tk)
+            tk.add_(y[k * BLK:(k + 1) * BLK])
+            _lib.check(lib.scasml_gemv_sub(_lib.ptr(ninv[k]), BLK, BLK, BLK, _lib.ptr(tk), _lib.ptr(xk), 1, s), "gemv^T(diag^-1)")   # x_k = L_kk^-T t_k
             if k % w == rank and k > 0:                        # fold x_k into the accumulator over this block row's columns < k
                 slot = (k - rank) // w
                 _lib.check(lib.scasml_gemv_sub(self._ptr(R, slot * BLK, 0, Mp), Mp, BLK, k * BLK, _lib.ptr(xk), _lib.ptr(acc), 1, s), "gemv_sub^T")
         return x[:self.M].clone()
 
     def matvec(self, v):
-        """K_p v = L (L^T v) for a replicated v (length M): each rank sweeps its block rows twice, two collectives of Mp doubles."""
+        """K_p v = L (L^T v) for a replicated v (length M): TWO launches over the rank's whole stacked panel (its strict upper part is zero after
+        factor(), so the full width can be swept: twice the bytes of the triangle, one launch instead of one per block row) and two collectives
+        of Mp doubles.  The transposed sweep combines its row groups with atomics: the last bits depend on their order."""
         torch = _lib.require_gpu()
         lib, s, cm = self.lib, _lib.stream_ptr(), self.comm
         R, Mp = self.R, self.Mp
+        rows = len(self.mine) * BLK
         vp = torch.zeros(Mp, dtype=torch.float64, device="cuda")
         vp[:self.M] = v
         acc = torch.zeros(Mp, dtype=torch.float64, device="cuda")          # -(L^T v), summed over ranks
-        for slot, i in enumerate(self.mine):
-            _lib.check(lib.scasml_gemv_sub(self._ptr(R, slot * BLK, 0, Mp), Mp, BLK, (i + 1) * BLK, C.c_void_p(vp.data_ptr() + 8 * i * BLK),
-                                           _lib.ptr(acc), 1, s), "gemv_sub^T")
+        if rows:
+            _lib.check(lib.scasml_gemv_sub(_lib.ptr(R), Mp, rows, Mp, _lib.ptr(self._local_rows(vp)), _lib.ptr(acc), 1, s), "gemv_sub^T")
         cm.all_reduce(acc)
         out = torch.zeros(Mp, dtype=torch.float64, device="cuda")
-        for slot, i in enumerate(self.mine):                                # u_i = -L_i acc = L_i (L^T v)
-            _lib.check(lib.scasml_gemv_sub(self._ptr(R, slot * BLK, 0, Mp), Mp, BLK, (i + 1) * BLK, _lib.ptr(acc),
-                                           C.c_void_p(out.data_ptr() + 8 * i * BLK), 0, s), "gemv_sub")
+        if rows:
+            loc = torch.zeros(rows, dtype=torch.float64, device="cuda")    # u_i = -L_i acc = L_i (L^T v), this rank's rows
+            _lib.check(lib.scasml_gemv_sub(_lib.ptr(R), Mp, rows, Mp, _lib.ptr(acc), _lib.ptr(loc), 0, s), "gemv_sub")
+            out.view(self.nblk, BLK)[self._mine_idx()] = loc.view(-1, BLK)
         cm.all_reduce(out)
         return out[:self.M].clone()
 
@@ -462,7 +487,7 @@ class DistributedGP:
             # matrix with the float16-rounded diagonal, in the memory of the first
             _lib.check(lib.scasml_round16(C.c_void_p(b.data_ptr() + 8 * (2 * N + Nb)), N, s), "round16")
             ch.R = None
-            ch.diag = [None] * ch.nblk
+            ch.diag, ch.ninv = [None] * ch.nblk, None
             torch.cuda.empty_cache()
             ch2 = DistCholesky(d, 1.0 / float(gp.sigma) ** 2, x_t_domain, x_t_boundary, gp.nugget, self.comm, compat_idx=compat_idx,
                                round_diag=True, f16_graph=graph, f16_extra=getattr(gp, "_f16_extra", 0)).build().factor()

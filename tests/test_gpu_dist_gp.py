@@ -207,7 +207,9 @@ def _worker_rccl(rank, world, port, case, q):
         torch.cuda.synchronize()
         same = bool(torch.equal(ahead.R, plain.R))                   # collectives through RCCL on two streams vs none at all: the same factor
         b = torch.from_numpy(np.random.default_rng(0).standard_normal(ahead.M)).cuda()
-        same = same and bool(torch.equal(ahead.solve(b), plain.solve(b))) and bool(torch.equal(ahead.matvec(b), plain.matvec(b)))
+        same = same and bool(torch.equal(ahead.solve(b), plain.solve(b)))
+        mv = plain.matvec(b)                                          # (its transposed sweep adds row groups with atomics: last bits vary)
+        same = same and float((ahead.matvec(b) - mv).abs().max()) <= 1e-12 * float(mv.abs().max())
         del ahead, plain
         gp = GP_Grad_Dependent_Nonlinear(eq)
         fit = DistributedGP(gp, cm)

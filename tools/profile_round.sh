@@ -7,7 +7,7 @@ set -e
 tag=$1; shift
 out=$PWD/gpurun_out
 export TMPDIR=/tmp
-args="--steps 3 --warmup 1 --no-cpu-baseline --no-gp-train-large --no-reference-logs-check $*"
+args="--steps 3 --warmup 1 --no-cpu-baseline --no-gp-train-large --no-reference-logs-check --no-other-runs $*"
 python3 bench.py --steps 5 --warmup 2 $* > $out/${tag}_bench_line.json
 rocprofv3 -L > $out/${tag}_counters_list.txt 2>&1 || true
 rocprofv3 --kernel-trace --stats -d $out/${tag}_trace -o run --output-format csv -- python3 bench.py $args > $out/${tag}_bench_under_rocprof.json
