@@ -96,3 +96,38 @@ def test_sample_of_the_full_batch_matches_the_oracle(headline):
         assert abs(np.linalg.norm(got[:, 0]) - np.linalg.norm(want[:, 0])) <= 1e-3 * np.linalg.norm(want[:, 0])
     else:
         assert diff.max() < 1e-4                           # outputs are clipped to +-0.1: 1e-3 relative to the clip
+
+
+def test_config1_mlp_d20_n2_at_its_full_batch_of_2_20_roots():
+    """BASELINE.json configs[1] at the batch bench.py's other_runs times (d = 20, solvers.MLP n = rho = 2, 2^20 roots = 4.8e7 path-steps by the reference's count): the
+    size-independent properties -- finite, clipped at norm_estimation, deterministic, another call draws other normals, any slice solved on
+    its own reproduces its rows bit for bit -- and the oracle on 64 roots spread over the batch."""
+    import torch
+    from oracle.equation import GradDependentNonlinear
+    from oracle.mlp import PicardOracle
+    from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
+    from scasml_gp_amd.solvers.MLP import MLP
+    d, n, big = 20, 2, 1 << 20
+    eq = Grad_Dependent_Nonlinear(d + 1)
+    eq.geometry()
+    g = np.random.default_rng(1234)
+    x_t = np.concatenate([g.uniform(-0.5, 0.5, (big, d)), g.uniform(0.0, 0.5, (big, 1))], axis=1).astype(np.float32)
+    x_dev = torch.from_numpy(x_t).cuda()
+    eng = MLP(eq, seed=0)._engine
+    full, none, _ = eng.solve(n, n, x_dev, stream_id=3)
+    assert none is None and full.shape == (big, d + 1) and bool(torch.isfinite(full).all())
+    assert float(full.abs().max()) <= float(eq.norm_estimation) * (1 + 1e-6)          # MLP.py:272-274
+    again, _, _ = eng.solve(n, n, x_dev, stream_id=3)
+    other, _, _ = eng.solve(n, n, x_dev, stream_id=4)
+    assert torch.equal(again, full) and not torch.equal(other, full)
+    for lo, hi in [(0, 64), (500000, 500257), (big - 1000, big)]:                     # root sharding: a slice is its rows of the whole
+        part, _, _ = eng.solve(n, n, x_dev[lo:hi], root0=lo, stream_id=3)
+        assert torch.equal(part, full[lo:hi])
+    ora = PicardOracle(GradDependentNonlinear(d + 1), "quad", seed=0, stream=3)
+    for lo in (0, 349520, 699050, big - 16):
+        want = ora.uz_solve(n, n, x_t[lo:lo + 16], root0=lo)
+        got = full[lo:lo + 16].cpu().numpy()
+        assert np.all(np.abs(got - want) <= 2e-5 + 1e-4 * np.abs(want)), np.abs(got - want).max()
+    from scasml_gp_amd import tables
+    # SURVEY.md section 3.2: 46 path-steps per root as the reference counts them; 28 are executed (its n == 0 terminal draws are discarded work)
+    assert tables.executed_path_steps(eng.plan(n, n)) == 28 and tables.reference_path_steps("quad", n, n) == 46
