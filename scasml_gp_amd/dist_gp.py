@@ -394,7 +394,11 @@ class DistributedGP:
         self.gauss_newton_steps = 0
 
     def fit(self, x_t_domain, x_t_boundary, GN_steps=20, cg_tol=1e-10, cg_max=400, progress=None):
-        """progress: optional callable(str), told about every Newton step (long fits on a shared box must show signs of life)."""
+        """cg_tol: relative residual at which the inner conjugate-gradient solve of a Newton step stops.  1e-10 (default) reproduces the dense
+        Newton iterates of the single-GPU path step for step; "adaptive" is the inexact-Newton forcing term min(1e-2, |grad_k| / |grad_0|)
+        (Eisenstat-Walker): early steps are solved loosely, the last ones tightly -- the same minimiser to the stopping rule's accuracy
+        (models/GP.py:521: |grad| < 1e-5) in about a third of the products.
+        progress: optional callable(str), told about every Newton step (long fits on a shared box must show signs of life)."""
         torch = _lib.require_gpu()
         lib, s = _lib.load(), _lib.stream_ptr()
         gp = self.gp
@@ -436,14 +440,14 @@ class DistributedGP:
             v[rows] = r
             return 0.5 * ch.matvec(v)[rows]
 
-        def cg(rhs, Ab):
+        def cg(rhs, Ab, tol):
             """(H + damping I) x = rhs by preconditioned conjugate gradients; None on negative curvature."""
             x = torch.zeros_like(rhs)
             r = rhs.clone()
             z = precond(r)
             p = z.clone()
             rz = float(torch.dot(r, z))
-            stop = cg_tol * float(torch.linalg.vector_norm(rhs))
+            stop = tol * float(torch.linalg.vector_norm(rhs))
             it = 0
             while float(torch.linalg.vector_norm(r)) > stop and it < cg_max:
                 hp = hess(p, Ab)
@@ -467,10 +471,11 @@ class DistributedGP:
             self.grad_norms.append(float(torch.linalg.vector_norm(grad)))
             if self.grad_norms[-1] < 1e-5:                              # :521
                 break
-            step, it = cg(-grad, Ab)
+            tol = min(1e-2, max(1e-10, self.grad_norms[-1] / self.grad_norms[0])) if cg_tol == "adaptive" else float(cg_tol)
+            step, it = cg(-grad, Ab, tol)
             if step is None:                                            # indefinite Hessian: Gauss-Newton operator instead
                 self.gauss_newton_steps += 1
-                step, it2 = cg(-grad, None)
+                step, it2 = cg(-grad, None, tol)
                 it += it2
             self.cg_iterations.append(it)
             sol = sol + step                                            # alpha = 1, :541,573

@@ -281,3 +281,24 @@ def test_one_rank_under_rccl_issues_every_collective_of_the_distributed_fit():
     assert calls_factor["broadcast"] == 28 and calls_factor["all_gather"] == 27 and calls_factor["all_reduce"] == 1, calls_factor
     assert calls["broadcast"] > 1000 and calls["all_reduce"] > 1000, calls          # the substitutions of every CG product
     assert rv_err <= 1e-6 and pred_err <= 2.0 ** -10 and dsteps == 0, (rv_err, pred_err, dsteps)
+
+
+def test_inexact_newton_reaches_the_same_fit_in_fewer_products():
+    """DistributedGP.fit(cg_tol="adaptive"): the inner CG tolerance follows the gradient norm (Eisenstat-Walker forcing term) -- the minimiser the
+    dense Newton of the single-GPU path reaches, to the accuracy of the reference's own stopping rule (|grad| < 1e-5, models/GP.py:521), in a
+    fraction of the operator products.  World = 1 in process, the as-coded surrogate."""
+    from scasml_gp_amd.dist_gp import DistributedGP
+    from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
+    eq, dom, bdy = _problem(20, 700, 140)                          # M = 2940
+    one = GP_Grad_Dependent_Nonlinear(eq)
+    one.GPsolver(dom, bdy, GN_steps=20)
+    tight, loose = GP_Grad_Dependent_Nonlinear(eq), GP_Grad_Dependent_Nonlinear(eq)
+    f_tight, f_loose = DistributedGP(tight), DistributedGP(loose)
+    f_tight.fit(dom, bdy, GN_steps=20)
+    f_loose.fit(dom, bdy, GN_steps=20, cg_tol="adaptive")
+    assert np.abs(tight.right_vector - one.right_vector).max() <= 1e-6 * np.abs(one.right_vector).max()
+    assert sum(f_loose.cg_iterations) < 0.6 * sum(f_tight.cg_iterations), (f_loose.cg_iterations, f_tight.cg_iterations)
+    assert loose.grad_norms[-1] < 1e-5 or len(loose.loss_history) == 21
+    assert abs(loose.loss_history[-1] - one.loss_history[-1]) <= 1e-7 * one.loss_history[-1]
+    X = np.concatenate(eq.generate_test_data(200, 40))
+    assert np.abs(loose.predict(X).astype(np.float64) - one.predict(X).astype(np.float64)).max() <= 2.0 ** -10      # float16 values: within an ulp

@@ -145,7 +145,7 @@ def test_sample_sharded_scasml_partials(B):
 def test_root_bound_is_taken_per_solve_for_converted_inputs():
     """the largest |coordinate| of the roots decides whether the fp16 planes of the evaluation can be used.  For a CPU torch
     tensor the engine works on a device COPY that is freed after the solve; the next call's copy gets the same address with version 0, and a
-    bound cached under (address, size, version) was then served to roots sixty times larger -- planes overflow, silently.  The bound is now reduced
+    bound cached under (address, size, version) was then served to roots a hundred times larger -- planes overflow, silently.  The bound is now reduced
     per solve for converted inputs (cached only for the caller's own device tensor): far-out roots handed over as a CPU tensor right after
     in-cube roots of the same shape give what the NumPy route (bound taken on the host, never cached) gives, bit for bit, and finite."""
     import torch
@@ -153,7 +153,7 @@ def test_root_bound_is_taken_per_solve_for_converted_inputs():
     eng = hip._engine
     near = _test_points(20, 32, 5).astype(np.float32)
     far = near.copy()
-    far[:, :-1] *= 120.0                                                   # |x| up to 60: beyond the fp16 planes' gate at d = 20 (|x| <= 49.8)
+    far[:, :-1] *= 128.0                                                   # |x| up to 64 (an exact scaling): beyond the fp16 planes' gate at d = 20 (|x| <= 49.8)
     want = eng.solve(2, 2, far, stream_id=11)[0]                           # NumPy route
     first = eng.solve(2, 2, torch.from_numpy(near), stream_id=11)[0]       # CPU tensor, in the cube: a temporary device copy
     second = eng.solve(2, 2, torch.from_numpy(far), stream_id=11)[0]       # CPU tensor, same shape, far outside
@@ -161,5 +161,5 @@ def test_root_bound_is_taken_per_solve_for_converted_inputs():
     assert torch.equal(first, eng.solve(2, 2, near, stream_id=11)[0])
     dev = torch.from_numpy(far).cuda()                                     # the caller's own device tensor: cached by identity, invalidated by writes
     assert torch.equal(eng.solve(2, 2, dev, stream_id=11)[0], want) and eng._bound_cache is not None
-    dev[:, :-1] /= 120.0
+    dev[:, :-1] /= 128.0
     assert torch.equal(eng.solve(2, 2, dev, stream_id=11)[0], first)

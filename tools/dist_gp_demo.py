@@ -72,7 +72,8 @@ def worker(rank, world, port, args, q):
     fit = DistributedGP(gp, Comm(force=force))
     torch.cuda.synchronize(); t0 = time.perf_counter()
     say("distributed fit starts")
-    fit.fit(dom, bdy, GN_steps=20, progress=say)
+    fit.fit(dom, bdy, GN_steps=20, progress=say, cg_tol="adaptive" if args.adaptive_cg else 1e-10)
+    out["cg_tol"] = "adaptive (inexact Newton)" if args.adaptive_cg else 1e-10
     torch.cuda.synchronize(); t1 = time.perf_counter()
     say("distributed fit done")
     out.update(fit_s=round(t1 - t0, 2), newton_steps=len(gp.loss_history) - 1, cg_products=fit.cg_iterations,
@@ -101,6 +102,7 @@ def main():
     ap.add_argument("--n-dom", type=int, default=8333)
     ap.add_argument("--n-bdy", type=int, default=1667)
     ap.add_argument("--no-single", action="store_true")
+    ap.add_argument("--adaptive-cg", action="store_true", help="inexact Newton: the inner CG tolerance follows the gradient norm (DistributedGP.fit(cg_tol='adaptive'))")
     ap.add_argument("--factor-only", action="store_true", help="Gram rows, factorisation, one solve and one matvec; no Newton fit")
     ap.add_argument("--backend", choices=["gloo", "nccl"], default="gloo",
                     help="nccl = RCCL: needs one GPU per rank, so --ranks 1 on a one-GPU box (every collective is then forced through RCCL: Comm(force=True))")
