@@ -85,6 +85,48 @@ def test_two_ranks_factor_M70k_as_coded_to_the_single_gpu_factor():
         assert moved > 0.4 * 70144 * 70144 * 8 / 2          # the column panels reach every rank once
 
 
+def test_block_row_factor_at_M_140k_fills_half_the_hbm():
+    """The block-row path alone at d = 250, 33 334 + 6 666 collocation points: M = 140 002 features = 40 % of configs[4]'s M, 1.96e10 matrix elements
+    (16 % of its 1.2e11; 157 GB of one MI355X's 288 GB in ONE panel, element offsets up to 2^34.2).  The as-coded Gram rows, the right-looking
+    factorisation with look-ahead, a solve and K_p v -- checked without a second copy of the matrix: L L^T against Gram block rows saved before the
+    factorisation (from the last third), and K_p (K_p^-1 b) = b."""
+    import torch
+    from scasml_gp_amd.dist_gp import BLK, DistCholesky
+    from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
+    from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
+    free, _ = torch.cuda.mem_get_info()
+    if free < 200e9:
+        pytest.skip("needs 200 GB of free device memory, %.0f GB are free" % (free / 1e9))
+    nd, nb = 33334, 6666
+    eq = Grad_Dependent_Nonlinear(D + 1)
+    state = np.random.get_state()
+    np.random.seed(1234)
+    dom, bdy = eq.generate_data(nd, nb)
+    np.random.set_state(state)
+    gp = GP_Grad_Dependent_Nonlinear(eq)
+    ch = DistCholesky(D, 1.0 / float(gp.sigma) ** 2, dom, bdy, gp.nugget, compat_idx=gp.laplacian_idx).build()
+    M = 4 * nd + nb
+    assert ch.M == M == 140002 and ch.nblk == 547 and ch.memory_bytes() == DistCholesky.budget(D, nd, nb, 1)["panel_R"] > 156e9
+    picks = [546, 545, 400, 365]
+    saved = {i: ch.R[i * BLK:(i + 1) * BLK].clone() for i in picks}        # K + nugget I, block rows from the last third (columns <= the block's own)
+    ch.factor()
+    torch.cuda.synchronize()
+    scale = max(float(v.abs().max()) for v in saved.values())
+    for i in picks:
+        r0, r1, nc = i * BLK, min((i + 1) * BLK, M), min((i + 1) * BLK, M)
+        recon = ch.R[r0:r1, :nc] @ ch.R[:nc, :nc].T                         # rows of L L^T (the panel's strict upper part is zero)
+        want = saved[i][:r1 - r0, :nc]
+        lower = torch.arange(nc, device="cuda")[None, :] <= torch.arange(r0, r1, device="cuda")[:, None]
+        assert float(((recon - want) * lower).abs().max()) <= 1e-11 * 256 * scale, i
+    del saved, recon, want
+    b = torch.from_numpy(np.random.default_rng(0).standard_normal(M)).cuda()
+    x = ch.solve(b)
+    back = ch.matvec(x)                                                      # K_p x = L (L^T x)
+    assert float((back - b).abs().max()) <= 1e-8 * float(b.abs().max()) * max(1.0, float(x.abs().max()))
+    del ch
+    torch.cuda.empty_cache()
+
+
 @pytest.fixture(scope="module", params=["reference", None], ids=["as-coded", "documented"])
 def factored(request):
     """(gp, K_p) after GP.kernel_phi_phi at M = 70 001: Gram, Cholesky factor (gp._L_pad, 70 016 x 70 016) -- 78 GB live."""
@@ -194,47 +236,5 @@ def test_block_row_path_at_world_1_equals_the_single_gpu_gram_and_factor(factore
     got = ch.matvec(b)                                       # K_p b = L (L^T b): the preconditioner product of the Newton-CG fit
     want = L @ (L.T @ b)
     assert float((got - want).abs().max()) <= 1e-11 * float(want.abs().max())
-    del ch
-    torch.cuda.empty_cache()
-
-
-def test_block_row_factor_at_M_140k_fills_half_the_hbm():
-    """The block-row path alone at d = 250, 33 334 + 6 666 collocation points: M = 140 002 features = 40 % of configs[4]'s M, 1.96e10 matrix elements
-    (16 % of its 1.2e11; 157 GB of one MI355X's 288 GB in ONE panel, element offsets up to 2^34.2).  The as-coded Gram rows, the right-looking
-    factorisation with look-ahead, a solve and K_p v -- checked without a second copy of the matrix: L L^T against Gram block rows saved before the
-    factorisation (from the last third), and K_p (K_p^-1 b) = b."""
-    import torch
-    from scasml_gp_amd.dist_gp import BLK, DistCholesky
-    from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
-    from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
-    free, _ = torch.cuda.mem_get_info()
-    if free < 200e9:
-        pytest.skip("needs 200 GB of free device memory, %.0f GB are free" % (free / 1e9))
-    nd, nb = 33334, 6666
-    eq = Grad_Dependent_Nonlinear(D + 1)
-    state = np.random.get_state()
-    np.random.seed(1234)
-    dom, bdy = eq.generate_data(nd, nb)
-    np.random.set_state(state)
-    gp = GP_Grad_Dependent_Nonlinear(eq)
-    ch = DistCholesky(D, 1.0 / float(gp.sigma) ** 2, dom, bdy, gp.nugget, compat_idx=gp.laplacian_idx).build()
-    M = 4 * nd + nb
-    assert ch.M == M == 140002 and ch.nblk == 547 and ch.memory_bytes() == DistCholesky.budget(D, nd, nb, 1)["panel_R"] > 156e9
-    picks = [546, 545, 400, 365]
-    saved = {i: ch.R[i * BLK:(i + 1) * BLK].clone() for i in picks}        # K + nugget I, block rows from the last third (columns <= the block's own)
-    ch.factor()
-    torch.cuda.synchronize()
-    scale = max(float(v.abs().max()) for v in saved.values())
-    for i in picks:
-        r0, r1, nc = i * BLK, min((i + 1) * BLK, M), min((i + 1) * BLK, M)
-        recon = ch.R[r0:r1, :nc] @ ch.R[:nc, :nc].T                         # rows of L L^T (the panel's strict upper part is zero)
-        want = saved[i][:r1 - r0, :nc]
-        lower = torch.arange(nc, device="cuda")[None, :] <= torch.arange(r0, r1, device="cuda")[:, None]
-        assert float(((recon - want) * lower).abs().max()) <= 1e-11 * 256 * scale, i
-    del saved, recon, want
-    b = torch.from_numpy(np.random.default_rng(0).standard_normal(M)).cuda()
-    x = ch.solve(b)
-    back = ch.matvec(x)                                                      # K_p x = L (L^T x)
-    assert float((back - b).abs().max()) <= 1e-8 * float(b.abs().max()) * max(1.0, float(x.abs().max()))
     del ch
     torch.cuda.empty_cache()
