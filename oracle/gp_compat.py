@@ -82,7 +82,7 @@ class OracleGPCompat(OracleGP):
     def __init__(self, eq, idx, round16=True, round_factor=True, round_out=None, f16_graph=False):
         super().__init__(eq)
         # f16_graph (0, 1 = True, 2, 3): on float16 rows evaluate kappa and derivative blocks through the reference's float16 op sequence (module docstring).
-        # Off by default: the product rounds each entry once, and HIP <-> oracle parity is stated in that arithmetic.
+        # Off by default: the product rounds each entry once (profiles/HISTORY.md, round-4 section 9), and HIP <-> oracle parity is stated in that arithmetic.
         self.f16_graph = (int(f16_graph) if f16_graph else 0) if round16 else 0      # 1 / True: kappa + first order; 2: + the dt / div second-order blocks
         self.round_factor = bool(round_factor) and bool(round16)
         # predict / compute_PDE_loss / compute_gradient return .astype(float16) (models/GP.py:671, 687, 769)

@@ -135,7 +135,7 @@ __device__ __forceinline__ void compat_blocks(int d, double a, const PairGeom &g
 //   second order, h = dt_x or div_x of kappa, w = m_d or f16(sum_f32 m_k):  gS = f16(f16(f16(w inv16) kappa16) inv16),
 //   grad_y h [k] = -f16(-2 t1 [k differentiated directly] + f16(gS m_k));  dt_y picks k = d, div_y is the float16 sum over k < d.
 // inv16 = f16(1 / f16(2 sigma^2)): the division by the constant reaches the device as a multiplication by its folded reciprocal (XLA's
-// algebraic simplifier); the reference's logged GP errors decide for this reading (tests/studies/f16_graph_study.py).
+// algebraic simplifier); the reference's logged GP errors decide for this reading (profiles/HISTORY.md section 2, tests/studies/f16_graph_study.py).
 // The Hutchinson blocks keep one rounding per entry (compat_blocks).  Float32 accumulations run in index order.
 __device__ __forceinline__ _Float16 hmul(_Float16 a, _Float16 b) { return (_Float16)((float)a * (float)b); }   // exact product, one rounding
 
@@ -181,7 +181,7 @@ __device__ __forceinline__ void f16_graph_blocks(int d, double a, FX x, FY y, do
 }
 // (round16 bit 3, exploratory: lap_y kappa and lap_x kappa through the same float16 sequence -- the mean over the five drawn indices of the Hessian
 // diagonal of kappa in the SHIFTED argument, H_i = f16(f16(gS_i m_i) - 2 t1), gS_i from w = m_i; jnp.mean accumulates in float32 and rounds once,
-// the product with the weakly typed d is float16.  The logs do not decide for it: DESIGN.md section 2.)
+// the product with the weakly typed d is float16.  The logs do not decide for it: profiles/HISTORY.md section 2.)
 template <class FX, class FY>
 __device__ __forceinline__ double f16_graph_hutchinson(int d, double a, const CompatIdx &ix, FX x, FY y) {   // x, y: the geometry's rows, already shifted
     const _Float16 c16 = (_Float16)(2.0 / a);

@@ -41,7 +41,7 @@ def test_host_entry_points_under_asan_and_ubsan(tmp_path):
 
 
 def test_the_sanitizer_build_catches_the_abi2_overrun(tmp_path):
-    """The class of bug behind round 2's unexplained abort: ABI 2's scasml_normal_table(float*) copied the library's
+    """The class of bug behind round 2's unexplained abort (profiles/HISTORY.md, round-4 section 8): ABI 2's scasml_normal_table(float*) copied the library's
     whole table into the caller's buffer.  The same copy into a buffer one row short, under the sanitizer: it must be reported --
     this is what says the build above would have caught it."""
     _sanitizer_toolchain(tmp_path)

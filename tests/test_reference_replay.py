@@ -100,7 +100,7 @@ def test_full_history_mlp_numbers_all_printed_digits(d):
     """results_full_history/Grad_Dependent_Nonlinear/<d>d/SimpleUniform/SimpleUniform.log: MLP_full_history, n = 2, M = 3.  Every draw of that
     solver comes from one key (MLP_full_history.py:92-93, 99, 133, 138), so the uniform time of a sample and its normals are functions of
     overlapping threefry outputs -- which is why a restatement on independent draws (oracle/mlp.py on Philox, and the HIP path) lands at 0.150
-    where the log says 0.184 at d = 20: with the reference's stream the numbers are the log's, digit for digit."""
+    where the log says 0.184 at d = 20 (profiles/HISTORY.md, round-4 sections 2 and 9): with the reference's stream the numbers are the log's, digit for digit."""
     from oracle.equation import GradDependentNonlinear, deepxde_points, logistic_wave_f16
     from oracle.replay import ReplayMLPFullHistory
     state = np.random.get_state()
