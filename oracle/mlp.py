@@ -109,8 +109,8 @@ class PicardOracle:
     # reference call surface -------------------------------------------------
     def uz_solve(self, n, par, x_t, root0=0, rank=0, world=1, owner=None):
         """par = rho (quad) or M (fh).  With world > 1 returns this rank's UN-CLIPPED partial
-        sums: the units of the ROOT call (terminal samples, then the sample paths of each
-        level) are dealt to ranks by ``owner[unit]`` (round-robin, unit % world, if None;
+        sums: the units of the ROOT call (terminal samples, then the nodes (m, k) of each
+        level's sample paths, each with its subtrees) are dealt to ranks by ``owner[unit]`` (round-robin, unit % world, if None;
         SURVEY.md section 8(e)); sum the ranks' results and pass them to ``finalize``."""
         x_t = np.asarray(x_t, dtype=np.float32).astype(np.float64)
         self.par = int(par)
@@ -270,15 +270,13 @@ class PicardOracle:
                 lp = l - 1                           # nodes of the previous level: q_prev x (1 + children's sub-keys)
                 jsplit += int(Q[rho - 1, n - lp - 1]) * (1 + self._jax_splits_in_call(lp) + (self._jax_splits_in_call(lp - 1) if lp else 0))
             for m in range(mc):
-                owned = self._owned(top, unit)
-                unit += 1
-                if not owned:
-                    o += q * (1 + s_l + s_lm)
-                    continue
                 X = x.copy()
                 W = np.zeros_like(x)
                 o_k0 = o                             # offsets of this path's k=0 children (compat_crn)
                 for k in range(q):
+                    # sample sharding: the unit is the NODE (l, m, k) with its subtrees; the path itself (X, W) advances on every rank
+                    owned = self._owned(top, unit)
+                    unit += 1
                     if jx is not None:
                         per_node = 1 + self._jax_splits_in_call(l) + (self._jax_splits_in_call(l - 1) if l else 0)
                         sk = jsplit + k * per_node
@@ -295,6 +293,10 @@ class PicardOracle:
                     W = W + dW
                     X = X + self.mu * dts[:, k][:, None] + self.sigma * dW   # MLP.py:225
                     tk = cloc[:, k]
+                    if not owned:                    # this node's term belongs to another rank
+                        self.sites_executed -= 1
+                        o += s_l + s_lm
+                        continue
                     sim = self._uz(l, X, tk, roots, base + o, cbase=cbase + o_k0 + 1, jx=kid)
                     o += s_l
                     y = self._f(X, tk, sim[:, 0], sim[:, 1:])

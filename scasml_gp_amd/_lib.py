@@ -8,7 +8,7 @@ MAX_Q = 6
 MAX_DIM = 252
 GP_TILE = 32
 DIST_BLOCK = 256
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 MODE_MLP, MODE_GENERATE, MODE_ACCUMULATE = 0, 1, 2
 RNG_COMPAT_CRN = 1

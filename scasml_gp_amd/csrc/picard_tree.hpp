@@ -252,10 +252,6 @@ struct Walker {
         const uint32_t s_l = (uint32_t)tm.sites_l, s_lm = (uint32_t)tm.sites_lm1;
         const float inv_mc = rcp_fast((float)mc);
         for (int m = 0; m < mc; ++m) {
-            if (!owned(TOP)) {
-                o += (uint32_t)q * (1u + s_l + s_lm);
-                continue;
-            }
             float4 X = x, W = f4(0.0f);
             // compat_crn: the children of every node k draw their terminal normals where the k = 0 children do
             // (MLP.py:167-168,178: one fixed key per uz_solve call, so calls of equal shape share their draws)
@@ -263,6 +259,17 @@ struct Walker {
             for (int k = 0; k < q; ++k) {
                 const uint32_t site = base + o;
                 o += 1;
+                // Monte-Carlo sample sharding: the unit dealt to a rank is a NODE (l, m, k) of the root call with the subtrees below it, not a whole
+                // sample path -- a node's term w_k f(P_k, child estimators) is one addend of the root's sums, and its state is either read back
+                // (ACCUMULATE), drawn directly (full history) or replayed from the path's cheap draws (below); at n = rho = 3 this cuts the largest
+                // unit from 264 sites to 88 and the dealt-load imbalance over 8 ranks from 3.19 to 1.06
+                const bool mine = owned(TOP);
+                if constexpr (VAR == 1 || MODE == SCASML_MODE_ACCUMULATE) {
+                    if (!mine) {                                 // nothing incremental in these forms
+                        o += s_l + s_lm;
+                        continue;
+                    }
+                }
                 float tk, wk;
                 float4 wvec;  // the vector multiplying y in the z estimator
                 float dplus, dminus;
@@ -309,6 +316,12 @@ struct Walker {
                     wk = tau;
                     wvec = xi;
                     dplus = dminus = __builtin_amdgcn_rsqf(D + 1e-6f);     // :158-159
+                }
+                if constexpr (VAR == 0 && MODE != SCASML_MODE_ACCUMULATE) {
+                    if (!mine) {                                 // the path has advanced (X, W); this node's term belongs to another rank
+                        o += s_l + s_lm;
+                        continue;
+                    }
                 }
                 if constexpr (MODE == SCASML_MODE_GENERATE) emit_point(X, tk, site);
                 float4 gp = f4(0.0f);

@@ -68,7 +68,7 @@ extern "C" int32_t scasml_plan_deal_units(const scasml_plan *plan_h, int32_t wor
     if (world < 1 || world > 255) return fail(SCASML_ERR_ARG, "plan_deal_units: world must be 1..255");
     const int n = plan_h->n;
     int64_t units = plan_h->mg[n];
-    for (int l = 0; l < n; ++l) units += plan_h->term[n][l].mc;
+    for (int l = 0; l < n; ++l) units += (int64_t)plan_h->term[n][l].mc * plan_h->term[n][l].q;   // a unit is a NODE (l, m, k) with its subtrees
     if (units > capacity) return fail(SCASML_ERR_ARG, "plan_deal_units: %lld units exceed the capacity %d", (long long)units, capacity);
     // unit costs in enumeration order; the levels come in blocks of equal cost, the most expensive level last
     std::vector<double> cost, load;
@@ -84,8 +84,8 @@ extern "C" int32_t scasml_plan_deal_units(const scasml_plan *plan_h, int32_t wor
     for (int m = 0; m < plan_h->mg[n]; ++m) cost[u++] = 0.6;
     for (int l = 0; l < n; ++l) {
         const scasml_term &t = plan_h->term[n][l];
-        const double c = t.q * (1.0 + subtree_cost(plan_h, l) + (l > 0 ? subtree_cost(plan_h, l - 1) : 0.0));
-        for (int m = 0; m < t.mc; ++m) cost[u++] = c;
+        const double c = 1.0 + subtree_cost(plan_h, l) + (l > 0 ? subtree_cost(plan_h, l - 1) : 0.0);
+        for (int m = 0; m < t.mc * t.q; ++m) cost[u++] = c;
     }
     for (int64_t k = 0; k < units; ++k) {           // longest processing time first (ties: lower unit index, lower rank)
         int64_t best = -1;
@@ -119,8 +119,8 @@ extern "C" int scasml_plan_site_kinds(const scasml_plan *plan_h, int32_t rank, i
             if (!mine(unit)) kinds_h[o] = 2;
         for (int l = 0; l < n; ++l) {
             const scasml_term &t = plan_h->term[n][l];
-            const int64_t span = (int64_t)t.q * (1 + t.sites_l + t.sites_lm1);
-            for (int m = 0; m < t.mc; ++m, ++unit, o += span)
+            const int64_t span = 1 + t.sites_l + t.sites_lm1;          // one node and the subtrees below it
+            for (int m = 0; m < t.mc * t.q; ++m, ++unit, o += span)
                 if (!mine(unit))
                     for (int64_t k = 0; k < span; ++k) kinds_h[o + k] = 2;
         }

@@ -23,9 +23,9 @@ def root_slice(total, rank, world):
 
 
 def sample_units(plan):
-    """Number of shardable units of the root call: terminal samples + sample paths of every level."""
+    """Number of shardable units of the root call: terminal samples + the NODES (l, m, k) of every level's sample paths, each with its subtrees."""
     n = plan.n
-    return int(plan.mg[n]) + sum(int(plan.term[n][l].mc) for l in range(n))
+    return int(plan.mg[n]) + sum(int(plan.term[n][l].mc) * int(plan.term[n][l].q) for l in range(n))
 
 
 def allreduce_partial_sums(partial, group=None):

@@ -48,7 +48,7 @@ def test_bench_prints_one_contract_line(extra):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ranks,variant,level,expect_s", [(4, "fh", "3", 4), (4, "quad", "3", 2), (2, "quad", "2", 1)])
+@pytest.mark.parametrize("ranks,variant,level,expect_s", [(4, "fh", "3", 4), (4, "quad", "3", 4), (2, "quad", "2", 2)])
 def test_plain_invocation_spawns_its_ranks_and_reports_both_shardings(ranks, variant, level, expect_s):
     """`python bench.py --gpus N` with no launcher around it: the parent spawns the N ranks (here sharing the one GPU of
     the test box and meeting over gloo: --rehearse-on-one-gpu), rank 0 prints the one line, which carries the root-sharded
