@@ -7,10 +7,11 @@ Two shardings of the Picard solve:
                  ``root0`` = its global offset (Philox counters are keyed by the GLOBAL root index,
                  so the result does not depend on the rank count).  No data-path collective; an
                  optional all_gather returns the full result everywhere.  This is what bench.py uses.
-* ``samples`` -- the Monte-Carlo units of the ROOT call (terminal samples, then the sample paths of
-                 every level) are dealt round-robin over ranks; each rank produces un-clipped partial
-                 sums of shape (B, 1+d) and ONE all-reduce(sum) over xGMI combines them, followed by
-                 the clip of MLP.py:272-274.  The reference has no counterpart (single device).
+* ``samples`` -- the Monte-Carlo units of the ROOT call (terminal samples, then the nodes (m, k) of every
+                 level's sample paths, each with the subtrees below it) are dealt to ranks by cost
+                 (scasml_plan_deal_units); each rank produces un-clipped partial sums of shape (B, 1+d) and ONE
+                 all-reduce(sum) over xGMI combines them, followed by the clip of MLP.py:272-274.  The reference
+                 has no counterpart (single device).
 """
 
 
