@@ -66,6 +66,23 @@ def test_sample_sharded_partials_add_up_at_full_size(headline):
     assert torch.allclose(eng.finalize_partials(total), full, atol=2e-5, rtol=1e-5)
 
 
+def test_eight_ranks_share_the_samples_of_the_headline_shape(headline):
+    """The north-star split at the headline shape (n = rho = 3): the root call's 62 units -- terminal samples and the NODES of its sample paths --
+    dealt over EIGHT ranks by cost balance to 6 % (whole paths as units: 3.19), and the eight partial estimators add up to the unsharded
+    one (one all-reduce in the multi-GPU run; here the ranks are walked in turn on 2048 of the roots)."""
+    import torch
+    solver, _, _, _, _, x_dev, full, _ = headline
+    eng = solver._engine
+    owner, _, load = eng.unit_owners(N, N, 8)
+    assert len(owner) == 62 and set(owner.tolist()) == set(range(8)) and load.max() / load.mean() < 1.07
+    sub = x_dev[4096:6144]
+    total = None
+    for r in range(8):
+        part, _, _ = eng.solve(N, N, sub, root0=4096, rank=r, world=8, stream_id=7)
+        total = part.clone() if total is None else total + part
+    assert torch.allclose(eng.finalize_partials(total), full[4096:6144], atol=2e-5, rtol=1e-5)
+
+
 def test_sample_of_the_full_batch_matches_the_oracle(headline):
     from oracle.equation import GradDependentNonlinear
     from oracle.gp import OracleGP
