@@ -60,8 +60,8 @@ typedef struct {
     int32_t world;    /* 1 = no sample sharding; >1 => outputs are un-clipped partial sums  */
     uint32_t flags;   /* SCASML_RNG_*                                                       */
     uint32_t reserved;
-    const uint8_t *unit_owner;  /* DEVICE bytes, one per unit of the root call (terminal samples, then the nodes (m, k) of the
-                                   sample paths of level 0, 1, ...): the rank that owns it, from scasml_plan_deal_units.  NULL: unit % world. */
+    const uint8_t *unit_owner;  /* DEVICE bytes, one per unit of the root call (terminal samples, then the addends of the nodes (m, k) of the
+                                   sample paths of level 0, 1, ...: scasml_plan_deal_units): the rank that owns it, from scasml_plan_deal_units.  NULL: unit % world. */
     const uint32_t *jax_keys;   /* SCASML_RNG_JAX_STREAM: DEVICE words [k0 k1] x (1 + S): the key every call's terminal draws use,
                                    split(PRNGKey(0), 1)[0] (solvers/MLP.py:167-168), then the S sub-keys this solve takes from the solver's
                                    stateful key (MLP.py:220) in the reference's call order (quadrature solvers; the full-history solvers
@@ -247,16 +247,18 @@ int scasml_gp_eval_sites(const scasml_gp_model *gp_h, const float *points, int64
 int scasml_plan_site_kinds(const scasml_plan *plan_h, int32_t rank, int32_t world, const uint8_t *unit_owner_h, uint8_t *kinds_h);
 
 /* Monte-Carlo sample sharding: the shardable units of the ROOT call are its mg[n] terminal
- * samples and, for every level l < n, the NODES (m, k) of its mc sample paths (q nodes each), every node with the child
- * subtrees below it.  A node's term w_k f(P_k, child estimators) is one addend of the root's sums; its state X_k, W_k is
- * read back (ACCUMULATE), drawn directly (full history) or replayed from the path's own cheap draws (solvers/MLP.py:215-225),
- * so a path need not stay on one rank.  Costs are unequal (at n = rho = 3: 27 units of 1 terminal site, 20 of 1 site, 9 of
- * 10 and 6 of 88), so they are dealt by cost -- longest processing time first onto the least loaded rank -- not
- * round-robin: dealt-load max / mean 1.00, 1.06, 1.06 over 2, 4, 8 ranks (whole paths as units, as up to ABI 5: 1.00, 1.60, 3.19).
- * Cost of a unit = its Euler-Maruyama sites + 0.6 x its terminal sites (a terminal-time point needs u_hat only).
- * Returns the number of units (<0 on error); fills owner_h[0 .. units) (needs capacity >= units, world <= 255) and, if not
- * NULL, load_h[0 .. world) with the cost dealt to every rank.  Philox is keyed by tree site, so the sum over ranks does not
- * depend on the dealing. */
+ * samples and, for every level l < n and every node (m, k) of its mc sample paths (q nodes each), the ADDENDS that node
+ * contributes to the root's sums: "+" = w_k f(P_k, uz(l)) with the level-l subtree below the node (at l = 0 also the
+ * surrogate's residual term) and, for l > 0, "-" = the level-(l-1) subtree's term -- enumerated node by node, "+" first.
+ * A node's state X_k, W_k is read back (ACCUMULATE), drawn directly (full history) or replayed from the path's own cheap
+ * draws (solvers/MLP.py:215-225), and its surrogate values are evaluated by whoever owns either addend, so neither a
+ * path nor a node need stay on one rank.  Costs are unequal (at n = rho = 3: 27 terminal samples, 20 addends of 1 site,
+ * 9 of 10, 6 of 58 and 6 of 30), so they are dealt by cost -- longest processing time first onto the least loaded rank:
+ * dealt-load max / mean 1.00 at 2, 4 and 8 ranks (whole paths as units, as up to ABI 5: 1.00, 1.60, 3.19); full history
+ * n = 4, M = 3: 1.00, 1.00, 1.24 (whole samples: 1.43).  Cost of a unit = its Euler-Maruyama sites + 0.6 x its terminal
+ * sites (a terminal-time point needs u_hat only).  Returns the number of units (<0 on error); fills owner_h[0 .. units)
+ * (needs capacity >= units, world <= 255) and, if not NULL, load_h[0 .. world) with the cost dealt to every rank.  Philox is
+ * keyed by tree site, so the sum over ranks does not depend on the dealing. */
 int32_t scasml_plan_deal_units(const scasml_plan *plan_h, int32_t world, uint8_t *owner_h, int32_t capacity, double *load_h);
 
 /* Full gradient of the posterior mean, n_inf x (d+1), time last: GP.compute_gradient (:673-687). */

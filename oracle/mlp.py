@@ -109,8 +109,8 @@ class PicardOracle:
     # reference call surface -------------------------------------------------
     def uz_solve(self, n, par, x_t, root0=0, rank=0, world=1, owner=None):
         """par = rho (quad) or M (fh).  With world > 1 returns this rank's UN-CLIPPED partial
-        sums: the units of the ROOT call (terminal samples, then the nodes (m, k) of each
-        level's sample paths, each with its subtrees) are dealt to ranks by ``owner[unit]`` (round-robin, unit % world, if None;
+        sums: the units of the ROOT call (terminal samples, then per node (m, k) of each level's sample
+        paths its "+" addend and, for l > 0, its "-" addend) are dealt to ranks by ``owner[unit]`` (round-robin, unit % world, if None;
         SURVEY.md section 8(e)); sum the ranks' results and pass them to ``finalize``."""
         x_t = np.asarray(x_t, dtype=np.float32).astype(np.float64)
         self.par = int(par)
@@ -274,9 +274,14 @@ class PicardOracle:
                 W = np.zeros_like(x)
                 o_k0 = o                             # offsets of this path's k=0 children (compat_crn)
                 for k in range(q):
-                    # sample sharding: the unit is the NODE (l, m, k) with its subtrees; the path itself (X, W) advances on every rank
+                    # sample sharding: the units are the two addends of the NODE (l, m, k): "+" (the node's term with the level-l subtree and, at
+                    # l = 0, the residual term) and, for l > 0, "-" (the level-(l-1) subtree's term); the path itself (X, W) advances on every rank
                     owned = self._owned(top, unit)
                     unit += 1
+                    owned_minus = False
+                    if l:
+                        owned_minus = self._owned(top, unit)
+                        unit += 1
                     if jx is not None:
                         per_node = 1 + self._jax_splits_in_call(l) + (self._jax_splits_in_call(l - 1) if l else 0)
                         sk = jsplit + k * per_node
@@ -293,21 +298,23 @@ class PicardOracle:
                     W = W + dW
                     X = X + self.mu * dts[:, k][:, None] + self.sigma * dW   # MLP.py:225
                     tk = cloc[:, k]
-                    if not owned:                    # this node's term belongs to another rank
+                    if not owned and not owned_minus:    # both addends of this node belong to other ranks
                         self.sites_executed -= 1
                         o += s_l + s_lm
                         continue
-                    sim = self._uz(l, X, tk, roots, base + o, cbase=cbase + o_k0 + 1, jx=kid)
-                    o += s_l
-                    y = self._f(X, tk, sim[:, 0], sim[:, 1:])
-                    u = u + wloc[:, k] * y / mc                              # MLP.py:248
-                    z = z + (wloc[:, k] * y)[:, None] * W / (mc * dplus[k])[:, None]   # MLP.py:249
-                    if l:
-                        sim = self._uz(l - 1, X, tk, roots, base + o, cbase=cbase + o_k0 + 1 + s_l, jx=kid2)
-                        o += s_lm
+                    if owned:
+                        sim = self._uz(l, X, tk, roots, base + o, cbase=cbase + o_k0 + 1, jx=kid)
                         y = self._f(X, tk, sim[:, 0], sim[:, 1:])
-                        u = u - wloc[:, k] * y / mc                          # MLP.py:269
-                        z = z - (wloc[:, k] * y)[:, None] * W / (mc * dminus[k])[:, None]  # MLP.py:271
+                        u = u + wloc[:, k] * y / mc                              # MLP.py:248
+                        z = z + (wloc[:, k] * y)[:, None] * W / (mc * dplus[k])[:, None]   # MLP.py:249
+                    o += s_l
+                    if l:
+                        if owned_minus:
+                            sim = self._uz(l - 1, X, tk, roots, base + o, cbase=cbase + o_k0 + 1 + s_l, jx=kid2)
+                            y = self._f(X, tk, sim[:, 0], sim[:, 1:])
+                            u = u - wloc[:, k] * y / mc                          # MLP.py:269
+                            z = z - (wloc[:, k] * y)[:, None] * W / (mc * dminus[k])[:, None]  # MLP.py:271
+                        o += s_lm
                     elif self.gp is not None:                                # ScaSML.py:274-280
                         P = np.concatenate([X, tk[:, None]], axis=1)
                         eps = self.gp.compute_PDE_loss(P)[:, 0]
@@ -327,9 +334,13 @@ class PicardOracle:
             s_l = site_count("fh", l, M)
             s_lm = site_count("fh", l - 1, M) if l else 0
             for m in range(mc):
-                owned = self._owned(top, unit)
+                owned = self._owned(top, unit)                     # the "+" addend of this (single-node) sample; "-" below for l > 0
                 unit += 1
-                if not owned:
+                owned_minus = False
+                if l:
+                    owned_minus = self._owned(top, unit)
+                    unit += 1
+                if not owned and not owned_minus:
                     o += 1 + s_l + s_lm
                     continue
                 site = base + o
@@ -350,17 +361,19 @@ class PicardOracle:
                     X = x + self.mu * D[:, None] + self.sigma * np.sqrt(D)[:, None] * xi   # :139-141
                     wgt = xi / np.sqrt(D + 1e-6)[:, None]          # :158-159
                 tk = t + D
-                sim = self._uz(l, X, tk, roots, base + o, jx=kid)
-                o += s_l
-                y = self._f(X, tk, sim[:, 0], sim[:, 1:])
-                u = u + tau * y / mc                               # :157
-                z = z + (tau * y)[:, None] * wgt / mc
-                if l:
-                    sim = self._uz(l - 1, X, tk, roots, base + o, jx=kid)
-                    o += s_lm
+                if owned:
+                    sim = self._uz(l, X, tk, roots, base + o, jx=kid)
                     y = self._f(X, tk, sim[:, 0], sim[:, 1:])
-                    u = u - tau * y / mc                           # :175
-                    z = z - (tau * y)[:, None] * wgt / mc
+                    u = u + tau * y / mc                               # :157
+                    z = z + (tau * y)[:, None] * wgt / mc
+                o += s_l
+                if l:
+                    if owned_minus:
+                        sim = self._uz(l - 1, X, tk, roots, base + o, jx=kid)
+                        y = self._f(X, tk, sim[:, 0], sim[:, 1:])
+                        u = u - tau * y / mc                           # :175
+                        z = z - (tau * y)[:, None] * wgt / mc
+                    o += s_lm
                 elif self.gp is not None:                          # ScaSML_full_history.py:189-195
                     P = np.concatenate([X, tk[:, None]], axis=1)
                     eps = self.gp.compute_PDE_loss(P)[:, 0]

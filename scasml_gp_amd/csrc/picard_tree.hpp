@@ -259,13 +259,16 @@ struct Walker {
             for (int k = 0; k < q; ++k) {
                 const uint32_t site = base + o;
                 o += 1;
-                // Monte-Carlo sample sharding: the unit dealt to a rank is a NODE (l, m, k) of the root call with the subtrees below it, not a whole
-                // sample path -- a node's term w_k f(P_k, child estimators) is one addend of the root's sums, and its state is either read back
-                // (ACCUMULATE), drawn directly (full history) or replayed from the path's cheap draws (below); at n = rho = 3 this cuts the largest
-                // unit from 264 sites to 88 and the dealt-load imbalance over 8 ranks from 3.19 to 1.06
-                const bool mine = owned(TOP);
+                // Monte-Carlo sample sharding: the units dealt to ranks are the two ADDENDS a node (l, m, k) of the root call contributes to the root's
+                // sums -- "+": w_k f(P_k, uz(l)) with the level-l subtree below the node (and, at l = 0, the surrogate's residual term), "-": the
+                // level-(l-1) subtree's term (l > 0) -- not whole sample paths: the node's state is read back (ACCUMULATE), drawn directly (full
+                // history) or replayed from the path's own cheap draws (below), and its surrogate values are evaluated by whoever owns either
+                // addend.  At n = rho = 3 the largest unit shrinks from 264 sites to 58 and the dealt-load imbalance over 8 ranks from 3.19 to 1.00
+                const bool mine = owned(TOP);                    // the "+" addend
+                bool mine_minus = false;
+                if constexpr (L > 0) mine_minus = owned(TOP);
                 if constexpr (VAR == 1 || MODE == SCASML_MODE_ACCUMULATE) {
-                    if (!mine) {                                 // nothing incremental in these forms
+                    if (!mine && !mine_minus) {                  // nothing incremental in these forms
                         o += s_l + s_lm;
                         continue;
                     }
@@ -318,7 +321,7 @@ struct Walker {
                     dplus = dminus = __builtin_amdgcn_rsqf(D + 1e-6f);     // :158-159
                 }
                 if constexpr (VAR == 0 && MODE != SCASML_MODE_ACCUMULATE) {
-                    if (!mine) {                                 // the path has advanced (X, W); this node's term belongs to another rank
+                    if (!mine && !mine_minus) {                  // the path has advanced (X, W); this node's terms belong to other ranks
                         o += s_l + s_lm;
                         continue;
                     }
@@ -331,23 +334,27 @@ struct Walker {
                 float4 zc;
                 const uint32_t jkid = jfirst + (uint32_t)k * (1u + nsplits<L>() + nsplits<L - 1>()) + 1u;   // the children's first sub-key
                 const uint64_t jkrow = jrow * (uint32_t)mc + (uint32_t)m;
-                uz<L, false>(X, tk, base + o, (a.crn && VAR == 0) ? c_plus : base + o, uc, zc, jkrow, jkid);
-                o += s_l;
-                if constexpr (MODE != SCASML_MODE_GENERATE) {
-                    const float y = f_eval(uc, zc, gp) * (wk * inv_mc);
-                    u += y;                                      // MLP.py:248
-                    z = fma4(y * dplus, wvec, z);                // MLP.py:249
-                }
-                if constexpr (L > 0) {
-                    uz<L - 1, false>(X, tk, base + o, (a.crn && VAR == 0) ? c_minus : base + o, uc, zc, jkrow, jkid + nsplits<L>());
-                    o += s_lm;
+                if (mine) {
+                    uz<L, false>(X, tk, base + o, (a.crn && VAR == 0) ? c_plus : base + o, uc, zc, jkrow, jkid);
                     if constexpr (MODE != SCASML_MODE_GENERATE) {
                         const float y = f_eval(uc, zc, gp) * (wk * inv_mc);
-                        u -= y;                                  // MLP.py:269
-                        z = fma4(-y * dminus, wvec, z);          // MLP.py:271
+                        u += y;                                  // MLP.py:248
+                        z = fma4(y * dplus, wvec, z);            // MLP.py:249
                     }
+                }
+                o += s_l;
+                if constexpr (L > 0) {
+                    if (mine_minus) {
+                        uz<L - 1, false>(X, tk, base + o, (a.crn && VAR == 0) ? c_minus : base + o, uc, zc, jkrow, jkid + nsplits<L>());
+                        if constexpr (MODE != SCASML_MODE_GENERATE) {
+                            const float y = f_eval(uc, zc, gp) * (wk * inv_mc);
+                            u -= y;                              // MLP.py:269
+                            z = fma4(-y * dminus, wvec, z);      // MLP.py:271
+                        }
+                    }
+                    o += s_lm;
                 } else if constexpr (MODE == SCASML_MODE_ACCUMULATE) {
-                    const float e = gp.z * (wk * inv_mc);        // ScaSML.py:274-280
+                    const float e = gp.z * (wk * inv_mc);        // ScaSML.py:274-280 (l = 0: one addend, mine)
                     u += e;
                     z = fma4(e * dminus, wvec, z);
                 }

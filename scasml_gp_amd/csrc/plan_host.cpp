@@ -68,7 +68,9 @@ extern "C" int32_t scasml_plan_deal_units(const scasml_plan *plan_h, int32_t wor
     if (world < 1 || world > 255) return fail(SCASML_ERR_ARG, "plan_deal_units: world must be 1..255");
     const int n = plan_h->n;
     int64_t units = plan_h->mg[n];
-    for (int l = 0; l < n; ++l) units += (int64_t)plan_h->term[n][l].mc * plan_h->term[n][l].q;   // a unit is a NODE (l, m, k) with its subtrees
+    // units past the terminal samples: per node (l, m, k) its "+" addend (the node and the level-l subtree) and, for l > 0, its "-" addend (the
+    // level-(l-1) subtree) -- enumerated node by node, "+" first, exactly as Walker::level() asks owned()
+    for (int l = 0; l < n; ++l) units += (int64_t)plan_h->term[n][l].mc * plan_h->term[n][l].q * (l > 0 ? 2 : 1);
     if (units > capacity) return fail(SCASML_ERR_ARG, "plan_deal_units: %lld units exceed the capacity %d", (long long)units, capacity);
     // unit costs in enumeration order; the levels come in blocks of equal cost, the most expensive level last
     std::vector<double> cost, load;
@@ -84,8 +86,11 @@ extern "C" int32_t scasml_plan_deal_units(const scasml_plan *plan_h, int32_t wor
     for (int m = 0; m < plan_h->mg[n]; ++m) cost[u++] = 0.6;
     for (int l = 0; l < n; ++l) {
         const scasml_term &t = plan_h->term[n][l];
-        const double c = 1.0 + subtree_cost(plan_h, l) + (l > 0 ? subtree_cost(plan_h, l - 1) : 0.0);
-        for (int m = 0; m < t.mc * t.q; ++m) cost[u++] = c;
+        const double cp = 1.0 + subtree_cost(plan_h, l), cm = l > 0 ? subtree_cost(plan_h, l - 1) : 0.0;
+        for (int m = 0; m < t.mc * t.q; ++m) {
+            cost[u++] = cp;
+            if (l > 0) cost[u++] = cm;
+        }
     }
     for (int64_t k = 0; k < units; ++k) {           // longest processing time first (ties: lower unit index, lower rank)
         int64_t best = -1;
@@ -119,10 +124,18 @@ extern "C" int scasml_plan_site_kinds(const scasml_plan *plan_h, int32_t rank, i
             if (!mine(unit)) kinds_h[o] = 2;
         for (int l = 0; l < n; ++l) {
             const scasml_term &t = plan_h->term[n][l];
-            const int64_t span = 1 + t.sites_l + t.sites_lm1;          // one node and the subtrees below it
-            for (int m = 0; m < t.mc * t.q; ++m, ++unit, o += span)
-                if (!mine(unit))
-                    for (int64_t k = 0; k < span; ++k) kinds_h[o + k] = 2;
+            for (int m = 0; m < t.mc * t.q; ++m) {                     // node by node: its own site, the "+" subtree, the "-" subtree (l > 0)
+                const bool plus = mine(unit++);
+                const bool minus = l > 0 ? mine(unit++) : false;
+                if (!plus && !minus) kinds_h[o] = 2;                     // the node's point is evaluated by whoever owns either addend
+                o += 1;
+                if (!plus)
+                    for (int64_t k = 0; k < t.sites_l; ++k) kinds_h[o + k] = 2;
+                o += t.sites_l;
+                if (!minus)
+                    for (int64_t k = 0; k < t.sites_lm1; ++k) kinds_h[o + k] = 2;
+                o += t.sites_lm1;
+            }
         }
     }
     return 0;

@@ -7,8 +7,8 @@ Two shardings of the Picard solve:
                  ``root0`` = its global offset (Philox counters are keyed by the GLOBAL root index,
                  so the result does not depend on the rank count).  No data-path collective; an
                  optional all_gather returns the full result everywhere.  This is what bench.py uses.
-* ``samples`` -- the Monte-Carlo units of the ROOT call (terminal samples, then the nodes (m, k) of every
-                 level's sample paths, each with the subtrees below it) are dealt to ranks by cost
+* ``samples`` -- the Monte-Carlo units of the ROOT call (terminal samples, then per node (m, k) of every
+                 level's sample paths its "+" and "-" addends with their subtrees) are dealt to ranks by cost
                  (scasml_plan_deal_units); each rank produces un-clipped partial sums of shape (B, 1+d) and ONE
                  all-reduce(sum) over xGMI combines them, followed by the clip of MLP.py:272-274.  The reference
                  has no counterpart (single device).
@@ -24,9 +24,10 @@ def root_slice(total, rank, world):
 
 
 def sample_units(plan):
-    """Number of shardable units of the root call: terminal samples + the NODES (l, m, k) of every level's sample paths, each with its subtrees."""
+    """Number of shardable units of the root call: terminal samples + the addends of the NODES (l, m, k) of every level's sample paths
+    ("+" with the level-l subtree; "-" with the level-(l-1) subtree where l > 0)."""
     n = plan.n
-    return int(plan.mg[n]) + sum(int(plan.term[n][l].mc) * int(plan.term[n][l].q) for l in range(n))
+    return int(plan.mg[n]) + sum(int(plan.term[n][l].mc) * int(plan.term[n][l].q) * (2 if l else 1) for l in range(n))
 
 
 def allreduce_partial_sums(partial, group=None):

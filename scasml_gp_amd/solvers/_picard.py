@@ -263,7 +263,7 @@ def deal_units(plan, world):
     """Host side of scasml_plan_deal_units: (owner uint8 per unit, load per rank)."""
     lib = _lib.load()
     n = plan.n
-    units = int(plan.mg[n]) + sum(int(plan.term[n][l].mc) * int(plan.term[n][l].q) for l in range(n))   # terminal samples + nodes (l, m, k)
+    units = int(plan.mg[n]) + sum(int(plan.term[n][l].mc) * int(plan.term[n][l].q) * (2 if l else 1) for l in range(n))   # terminal samples + the addends of the nodes
     owner = np.zeros(max(units, 1), dtype=np.uint8)
     load = np.zeros(world, dtype=np.float64)
     got = lib.scasml_plan_deal_units(C.byref(plan), world, owner.ctypes.data_as(C.c_void_p), units, load.ctypes.data_as(C.c_void_p))

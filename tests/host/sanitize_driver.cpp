@@ -72,7 +72,7 @@ int main() {
             CHECK(kinds[(size_t)ppr - 1] == 1);
             if (n == 0) continue;
             int units = p.mg[n];
-            for (int l = 0; l < n; ++l) units += p.term[n][l].mc * p.term[n][l].q;   // terminal samples + the nodes (m, k) of every level
+            for (int l = 0; l < n; ++l) units += p.term[n][l].mc * p.term[n][l].q * (l > 0 ? 2 : 1);   // terminal samples + the addends of the nodes (m, k)
             for (int world : {1, 2, 3, 8, 255}) {
                 std::vector<uint8_t> owner((size_t)units);
                 std::vector<double> load((size_t)world);

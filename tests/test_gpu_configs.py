@@ -123,7 +123,7 @@ def test_config3_full_batch_properties_and_eight_way_sample_split(config3):
     # a slice of roots solved on its own reproduces its rows bit for bit (root sharding)
     part, uh, _ = eng.solve(N3, M3, x_dev[7000:7040], root0=7000, stream_id=5)
     assert torch.equal(part, full[7000:7040]) and torch.equal(uh, uhat[7000:7040])
-    # the north-star split: 201 Monte-Carlo units dealt over 8 ranks by cost, partial estimators add up to the full result
+    # the north-star split: 240 Monte-Carlo units (terminal samples and the +/- addends of the samples) dealt over 8 ranks by cost, partial estimators add up to the full result
     sub = x_dev[:2048]
     total = None
     for r in range(8):

@@ -64,7 +64,7 @@ def test_root_slice_partitions_exactly():
 def test_sample_units_counts_root_fan_out():
     from scasml_gp_amd import tables
     from scasml_gp_amd.parallel import sample_units
-    # SURVEY.md 8(e) counts whole sample paths (27 + 5 + 3 + 2 = 37 units of very unequal cost); the unit dealt here is a NODE of a path
-    # (q = 4, 3, 3 nodes per path at levels 0, 1, 2), which is what balances eight ranks (tests/test_abi_and_host.py)
-    assert sample_units(tables.build_plan("quad", 3, 3, 0.5, True)) == 27 + 5 * 4 + 3 * 3 + 2 * 3
-    assert sample_units(tables.build_plan("fh", 4, 3, 0.5, True)) == 81 + 81 + 27 + 9 + 3
+    # SURVEY.md 8(e) counts whole sample paths (27 + 5 + 3 + 2 = 37 units of very unequal cost); the units dealt here are the addends of a path's
+    # NODES (q = 4, 3, 3 nodes per path at levels 0, 1, 2; a "+" and a "-" addend per node above level 0), which is what balances eight ranks
+    assert sample_units(tables.build_plan("quad", 3, 3, 0.5, True)) == 27 + 5 * 4 + 2 * (3 * 3 + 2 * 3)
+    assert sample_units(tables.build_plan("fh", 4, 3, 0.5, True)) == 81 + 81 + 2 * (27 + 9 + 3)
