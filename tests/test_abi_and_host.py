@@ -229,18 +229,30 @@ def test_units_are_dealt_by_cost(lib):
     assert lib.scasml_plan_deal_units(C.byref(fh), 2, o.ctypes.data_as(C.c_void_p), 10, None) == -1
 
 
-def test_no_spills_inside_the_gp_tile_loops():
-    """A register spill or reload inside the tile loop of the GP evaluation kernels is a performance cliff (round 1 measured
-    72 ms for a spilling build against 8), and it makes the counted `s_waitcnt vmcnt(N)` of the LDS-DMA hand-over more
-    conservative than written.  tools/kernel_regs.py compiles the file to ISA text and reports scratch instructions inside
-    loops: only the kernels that drain fully (three LDS slots, `vmcnt(0)`) may have any.  Needs hipcc ($HIPCC or /opt/rocm)."""
-    import subprocess, sys, os, re
+@pytest.fixture(scope="module")
+def kernel_regs_reports():
+    """tools/kernel_regs.py (device-only compile to ISA text, ~50 s per file) for the two evaluation kernels, run side by side once per module."""
+    import subprocess, sys, os
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc at %s" % hipcc)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_regs.py"), "gp_eval_bf16.hip"],
-                         capture_output=True, text=True, check=True).stdout
+
+    def run(name):
+        return subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_regs.py"), name], capture_output=True, text=True, check=True).stdout
+    files = ["gp_eval_bf16.hip", "gp_eval_compat_mfma.hip"]
+    with ThreadPoolExecutor(max_workers=2) as ex:
+        return dict(zip(files, ex.map(run, files)))
+
+
+def test_no_spills_inside_the_gp_tile_loops(kernel_regs_reports):
+    """A register spill or reload inside the tile loop of the GP evaluation kernels is a performance cliff (round 1 measured
+    72 ms for a spilling build against 8), and it makes the counted `s_waitcnt vmcnt(N)` of the LDS-DMA hand-over more
+    conservative than written.  tools/kernel_regs.py compiles the file to ISA text and reports scratch instructions inside
+    loops: only the kernels that drain fully (three LDS slots, `vmcnt(0)`) may have any.  Needs hipcc ($HIPCC or /opt/rocm)."""
+    import re
+    out = kernel_regs_reports["gp_eval_bf16.hip"]
     assert "gp_eval_bf16_kernel<7, 2, 4, true, 4, true>" in out            # the headline instantiation is there
     for line in out.splitlines():
         if "!!" not in line:
@@ -252,18 +264,13 @@ def test_no_spills_inside_the_gp_tile_loops():
         assert 4 * stage_bytes * bpc > 144 * 1024, "spill inside a counted-vmcnt tile loop: " + line
 
 
-def test_launch_bounds_of_the_as_coded_evaluation_kernel_hold_without_scratch():
+def test_launch_bounds_of_the_as_coded_evaluation_kernel_hold_without_scratch(kernel_regs_reports):
     """gp_eval_compat_mfma.hip sets __launch_bounds__(256, BPC) from a hand-written register estimate; if the estimate is low the
     compiler honours the occupancy bound by spilling, silently.  Pinned from the code object's metadata for every instantiation: the as-coded
     kernel (float16 entries, two planes -- the default and the benchmarked one) uses NO scratch at any d; the opt-in geometry mode may park a few
     dwords (<= 32 bytes, KS = 7..9 and 15 at one plane) but never touches scratch inside a loop."""
-    import subprocess, sys, os, re
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    if not os.path.exists(hipcc):
-        pytest.skip("no hipcc at %s" % hipcc)
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_regs.py"), "gp_eval_compat_mfma.hip"],
-                         capture_output=True, text=True, check=True).stdout
+    import re
+    out = kernel_regs_reports["gp_eval_compat_mfma.hip"]
     seen = 0
     for line in out.splitlines():
         m = re.search(r"gp_eval_compat_mfma_kernel<(\d+), (\d+), (\w+), (\d+)>.*scratch\s+(\d+)\s+vgpr\s+(\d+)", line)
