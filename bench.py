@@ -16,6 +16,9 @@ With N > 1 the line also carries "samples_sharding": the north-star split -- the
 over `sample_ranks` ranks by cost (scasml_plan_deal_units), ONE RCCL all-reduce of the (B, 1+d) partial estimators per
 step -- timed on the same workload right after the root-sharded leg (strong scaling: the B roots of one GPU are shared).
 
+With SCASML_BENCH_DIST_GP=1 (opt-in) an N > 1 run also fits the block-row distributed GP (M = 7001) over its own process group and reports
+"dist_gp_check": right_vector against the single-GPU fit -- the first thing to run on a multi-GPU node.
+
 At N = 1 the line also carries "other_runs": the other BASELINE configurations and modes (configs[1], configs[3], the
 reference-stream parity mode, the geometry mode), 5 timed steps each in this same process, and "gp_train": the stages of the
 surrogate's fit with their FP64-MFMA fractions.  Layout of this file: workloads -> timing -> rooflines -> the line (main).
@@ -338,6 +341,34 @@ class SampleSharding:
         dmax = torch.tensor([float((sharded - whole).abs().max()) if self.cnt else 0.0], dtype=torch.float64, device="cpu" if self.ranks.on_host else "cuda")
         self.ranks.dist.all_reduce(dmax, op=self.ranks.dist.ReduceOp.MAX)
         return float(dmax.item())
+
+
+def dist_gp_check(ranks):
+    """SCASML_BENCH_DIST_GP=1, N > 1: the block-row distributed fit of the as-coded surrogate (scasml_gp_amd/dist_gp.py; d = 20, 1600 + 601
+    collocation points, M = 7001: 28 block rows over the ranks) over the run's own process group -- RCCL on a multi-GPU node -- against the
+    single-GPU fit of the same data on rank 0.  Untimed side check, off by default (a first contact with real xGMI should not be able to take
+    the headline line down with it); every rank takes part."""
+    import torch
+    from scasml_gp_amd.dist_gp import Comm, DistributedGP
+    from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
+    from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
+    eq = Grad_Dependent_Nonlinear(21)
+    dom, bdy, _ = harness_sets(eq, 1600, 601)
+    gp = GP_Grad_Dependent_Nonlinear(eq)
+    cm = Comm()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fit = DistributedGP(gp, cm)
+    fit.fit(dom, bdy, GN_steps=20)
+    torch.cuda.synchronize()
+    out = {"M": gp.phi_dim, "ranks": cm.world, "backend": cm.backend, "fit_s": round(time.perf_counter() - t0, 2), "newton_steps": len(gp.loss_history) - 1,
+           "cg_products": int(sum(fit.cg_iterations)), "collective_calls": dict(cm.calls), "collective_gb_per_rank": round(cm.bytes_moved / 1e9, 3)}
+    if ranks.rank == 0:
+        one = GP_Grad_Dependent_Nonlinear(eq)
+        one.GPsolver(dom, bdy, GN_steps=20)
+        out["right_vector_rel_diff_vs_single_gpu"] = float(np.abs(gp.right_vector - one.right_vector).max() / np.abs(one.right_vector).max())
+        out["newton_steps_single_gpu"] = len(one.loss_history) - 1
+    return out
 
 
 def rccl_selftest(ranks, B, d):
@@ -701,6 +732,7 @@ def main():
         samples_leg = sharding.report(t_s, t_r, args.steps)
         samples_leg["max_abs_diff_vs_unsharded"] = sharding.max_abs_diff_vs_unsharded()
     selftest = rccl_selftest(ranks, B, d) if (ranks.on and world == 1 and not ranks.on_host) else None
+    dist_gp = dist_gp_check(ranks) if (world > 1 and os.environ.get("SCASML_BENCH_DIST_GP") == "1") else None
     if rank != 0:
         ranks.close()
         return
@@ -734,7 +766,7 @@ def main():
         "rccl_note": "no multi-GPU node has been available to this build: the N > 1 path (init_process_group('nccl'), the in-group all-reduce) is "
                      "rehearsed over gloo on one GPU only (tests/test_gpu_bench_contract.py) until a SCALE run exists; with SCASML_BENCH_FORCE_DIST=1 the "
                      "same branches run over RCCL with one rank (rccl_selftest)",
-        "backend": (ranks.dist.get_backend() if ranks.on else None), "rccl_selftest": selftest, "samples_sharding": samples_leg,
+        "backend": (ranks.dist.get_backend() if ranks.on else None), "rccl_selftest": selftest, "samples_sharding": samples_leg, "dist_gp_check": dist_gp,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "Grad_Dependent_Nonlinear d=%d, %s, B=%d roots/GPU%s" % (
                        d, wl.name, B, " (BASELINE.json configs[2])" if (args.solver, args.variant, d, n) == ("scasml", "quad", 100, 3) else ""),

@@ -57,6 +57,8 @@ def test_plain_invocation_spawns_its_ranks_and_reports_both_shardings(ranks, var
            "--train-domain", "96", "--train-boundary", "32", "--d", "20", "--variant", variant, "--level", level,
            "--rehearse-on-one-gpu"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    if ranks == 2:
+        env["SCASML_BENCH_DIST_GP"] = "1"             # + the distributed GP fit over the run's own process group (opt-in side check)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -71,6 +73,12 @@ def test_plain_invocation_spawns_its_ranks_and_reports_both_shardings(ranks, var
     # the sharded estimator IS the unsharded one: same sites, same draws, same surrogate values; only the order of the additions differs
     assert s["max_abs_diff_vs_unsharded"] <= 2e-5, s["max_abs_diff_vs_unsharded"]
     assert abs(s["roots_leg"]["value"] - j["value"]) / j["value"] < 0.5      # same leg, timed twice
+    if ranks == 2:
+        g = j["dist_gp_check"]
+        assert g["M"] == 7001 and g["ranks"] == 2 and g["backend"] == "gloo" and g["collective_calls"]["all_gather"] > 0
+        assert g["right_vector_rel_diff_vs_single_gpu"] <= 1e-6 and g["newton_steps"] == g["newton_steps_single_gpu"]
+    else:
+        assert j["dist_gp_check"] is None
 
 
 @pytest.mark.gpu
