@@ -5,6 +5,7 @@ What runs where:
 * Gram K(phi,phi) in closed form (25 blocks, float64) ............ scasml_gp_gram      (:182-258)
 * Cholesky of K + nugget*I (replaces the SVD factor, :260-267) ... scasml_cholesky
 * K_p^{-1} by two blocked triangular solves, Newton step solves .. scasml_trsm_lower  (:439,533,599)
+* the Newton objective as a method of its own (:430-444) ....... GP.loss_function -> scasml_gp_newton_b, scasml_trsm_lower
 * the Newton iteration (:487-604): with A = K_p^{-1} explicit, gradient and Hessian of b(sol)^T A b(sol)
   are block-wise elementwise expressions (b is affine except for the product z1*z5 in F, :705-719), so
   no autodiff and no per-iteration GEMM is needed ........... scasml_gp_newton_b / _gemv / _gp_newton_system
@@ -270,6 +271,35 @@ class GP(object):
 
     def time_der_rep(self, sol, rhs_f):
         raise NotImplementedError
+
+    def loss_function(self, sol, rhs_f=None, bdy_g=None, L=None):
+        '''The Newton objective |L^-1 b(sol)|^2 with b = [z1, g(x_bdy), z3, F(sol) + rhs_f, z5] (models/GP.py:430-444), on the device: b by
+        scasml_gp_newton_b, one blocked triangular solve against the factor of kernel_phi_phi (``L``: another lower factor of the same order;
+        default the one held).  Returns a float64 scalar (the reference casts the value to float16 for its log).'''
+        torch = _lib.require_gpu()
+        lib = _lib.load()
+        if getattr(self, "_L_pad", None) is None and L is None:
+            raise _lib.ScasmlError("no factor: call kernel_phi_phi(x_domain, x_boundary) or GPsolver first")
+        N, Nb, M = self.N_domain, self.N_boundary, self.phi_dim
+        s = _lib.stream_ptr()
+        sol_d = torch.as_tensor(np.asarray(sol, dtype=np.float64).reshape(-1), device="cuda").contiguous()
+        if sol_d.numel() != 3 * N:
+            raise ValueError("sol has %d entries, expected 3 N_domain = %d" % (sol_d.numel(), 3 * N))
+        g = self.bdy_g(self.x_t_boundary) if bdy_g is None else np.asarray(bdy_g, dtype=np.float64).reshape(-1)
+        g_d = torch.as_tensor(np.asarray(g, dtype=np.float64), device="cuda").contiguous()
+        if L is None:
+            Lp = self._L_pad
+        else:
+            Lp = torch.eye(_round_up(M, 32), dtype=torch.float64, device="cuda")
+            Lp[:M, :M] = torch.as_tensor(np.asarray(L, dtype=np.float64), device="cuda")
+        Mp = Lp.shape[0]
+        b = torch.zeros((Mp, 1), dtype=torch.float64, device="cuda")
+        _lib.check(lib.scasml_gp_newton_b(int(self.equation.eq_id), int(self.d), float(self.equation.sigma()), float(self.equation.mu()), _lib.ptr(sol_d),
+                                          _lib.ptr(g_d), N, Nb, _lib.ptr(b), s), "gp_newton_b")
+        if rhs_f is not None:
+            b[2 * N + Nb:3 * N + Nb, 0] += torch.as_tensor(np.asarray(rhs_f, dtype=np.float64).reshape(-1), device="cuda")
+        _lib.check(lib.scasml_trsm_lower(_lib.ptr(Lp), Mp, _lib.ptr(b), 1, 0, s), "trsm")
+        return np.float64(torch.dot(b[:, 0], b[:, 0]).item())
 
     def _chol_solve_padded(self, Hp, rhs, n, damping):
         """(H + damping*I)^-1 rhs on an identity-padded system (in place Cholesky + two triangular solves); None if not SPD."""

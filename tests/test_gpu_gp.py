@@ -101,6 +101,20 @@ def test_training_matches_oracle(d, nd, nb):
     assert rv.shape == (4 * nd + nb, 1)
     assert np.abs(rv - rvo).max() <= 1e-7 * np.abs(rvo).max()
     assert np.allclose(sol_dom, want_dom, atol=2e-5)
+    # GP.loss_function (models/GP.py:430-444) as a method of its own: the Newton objective at the start, at the minimiser, with an explicit
+    # boundary vector / source term / factor
+    N = nd
+    assert abs(gp.loss_function(np.zeros(3 * N)) - ora.loss_history[0]) <= 1e-8 * ora.loss_history[0]
+    sol = gp._sol.cpu().numpy()
+    assert abs(gp.loss_function(sol) - ora.loss_history[-1]) <= 1e-8 * ora.loss_history[-1]
+    L = gp.cholesky_phi_phi_perturb.cpu().numpy()
+    g = gp.bdy_g(bdy)
+    assert abs(gp.loss_function(sol, rhs_f=np.zeros(N), bdy_g=g, L=L) - gp.loss_function(sol)) <= 1e-12 * gp.loss_function(sol)
+    b = np.concatenate([sol[:N], g, sol[N:2 * N], gp.time_der_rep(sol, 0.25 * np.ones(N)), sol[2 * N:]])
+    want = float(np.sum(np.linalg.solve(L, b) ** 2))
+    assert abs(gp.loss_function(sol, rhs_f=0.25 * np.ones(N)) - want) <= 1e-9 * want
+    with pytest.raises(ValueError):
+        gp.loss_function(np.zeros(3 * N + 1))
 
 
 @pytest.mark.parametrize("f16_colloc", [False, True])
