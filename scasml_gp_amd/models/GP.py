@@ -523,6 +523,14 @@ class GP_Semilinear(GP):
         sol = np.asarray(sol, dtype=np.float64)
         return self.equation.F_parts(sol[:N], sol[N:2 * N], sol[2 * N:])[0] + rhs_f
 
+    def DF_domain_without_time(self, sol):
+        '''Jacobian of F in the unknowns (z1, z3, z5): (N, 3N) = [diag dF/dz1 | diag dF/dz3 | diag dF/dz5], float16 as the reference returns it
+        (models/GP.py:722-743).  Host NumPy; the device Newton uses the same derivatives through eq_F (csrc/equations.hpp).'''
+        N = self.N_domain
+        sol = np.asarray(sol, dtype=np.float64).reshape(-1)
+        d1, d3, d5 = self.equation.F_parts(sol[:N], sol[N:2 * N], sol[2 * N:])[1]
+        return np.hstack([np.diag(np.broadcast_to(v, (N,))) for v in (d1, d3, d5)]).astype(np.float16)
+
     def compute_PDE_loss(self, x_t_infer):
         '''dt u + mu div u + sigma^2/2 Lap u + f(u, sigma div u); for Grad_Dependent_Nonlinear
         dt u + (sigma^2 u - 1/d - sigma^2/2) div u + sigma^2/2 Lap u  (models/GP.py:746-769)'''

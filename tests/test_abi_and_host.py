@@ -321,6 +321,23 @@ def test_distributed_gp_memory_budget_for_configs4():
     assert sum(DistCholesky.budget(250, 16667, 3333, 2, r)["owned_block_rows"] for r in range(2)) == 274
 
 
+def test_gp_host_views_of_the_collocation_operator():
+    """GP.time_der_rep and GP.DF_domain_without_time (models/GP.py:705-743) against the reference's formulas written out: host NumPy, no GPU."""
+    from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
+    from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
+    d, N = 20, 7
+    gp = GP_Grad_Dependent_Nonlinear(Grad_Dependent_Nonlinear(d + 1))
+    gp.N_domain, gp.N_boundary = N, 3
+    sol = np.random.default_rng(0).standard_normal(3 * N)
+    z1, z3, z5 = sol[:N], sol[N:2 * N], sol[2 * N:]
+    s2 = 0.25 ** 2
+    F = -s2 * z1 * z5 + (1 / d + s2 / 2) * z5 - (s2 / 2) * z3                               # :717
+    assert np.allclose(gp.time_der_rep(sol, np.zeros(N)), F, rtol=1e-14) and np.allclose(gp.time_der_rep(sol, np.ones(N)), F + 1, rtol=1e-14)
+    want = np.hstack([-s2 * np.diag(z5), -(s2 / 2) * np.eye(N), -(s2 * np.diag(z1) - (1 / d + s2 / 2) * np.eye(N))]).astype(np.float16)   # :733-743
+    got = gp.DF_domain_without_time(sol)
+    assert got.dtype == np.float16 and got.shape == (N, 3 * N) and np.array_equal(got, want)
+
+
 def test_header_is_plain_c(tmp_path):
     """The drop-in boundary is a C ABI: include/scasml_hip.h must compile as C99 with no extensions."""
     import os, subprocess
