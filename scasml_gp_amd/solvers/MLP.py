@@ -29,6 +29,14 @@ class MLP:
     def g(self, x_t):
         return self.equation.g(x_t)[:, 0]                         # :43-55
 
+    def inverse_gamma(self, gamma_input):
+        '''Inverse of the gamma function through Lambert W (solvers/MLP.py:57-69); scalar or array in, the same out.'''
+        return tables.inverse_gamma(gamma_input)
+
+    def lgwt(self, N, a, b):
+        '''(nodes, weights) exactly as the reference's routine returns them, its scalar quirk at :99 included (solvers/MLP.py:71-109).'''
+        return tables.lgwt_reference(int(N), a, b)
+
     def approx_parameters(self, rhomax):
         return tables.approx_parameters(int(rhomax), float(self.T))   # :111-139 (cached)
 

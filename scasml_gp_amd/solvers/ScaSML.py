@@ -39,6 +39,14 @@ class ScaSML:
     def g(self, x_t):
         return (self.equation.g(x_t) - self.GP.predict(x_t))[:, 0]   # :49-63
 
+    def inverse_gamma(self, gamma_input):
+        '''Inverse of the gamma function through Lambert W (solvers/ScaSML.py:65-77); scalar or array in, the same out.'''
+        return tables.inverse_gamma(gamma_input)
+
+    def lgwt(self, N, a, b):
+        '''(nodes, weights) exactly as the reference's routine returns them, its scalar quirk at :99 included (solvers/ScaSML.py:79-117).'''
+        return tables.lgwt_reference(int(N), a, b)
+
     def approx_parameters(self, rhomax):
         return tables.approx_parameters(int(rhomax), float(self.T))
 

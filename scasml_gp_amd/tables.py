@@ -44,6 +44,19 @@ def _lgwt_reference(n_nodes, a, b, max_iter=100):
     return x, w
 
 
+def inverse_gamma(gamma_input):
+    """solvers/MLP.py:57-69 as the solver classes expose it: scalar or array."""
+    x = np.asarray(gamma_input, dtype=np.float64)
+    L = np.log((x + 0.036534) / np.sqrt(2 * np.pi))
+    out = np.real(L / np.real(lambertw(L / np.e)) + 0.5)
+    return float(out) if out.ndim == 0 else out
+
+
+def lgwt_reference(n_nodes, a, b):
+    """solvers/MLP.py:71-109 as the solver classes expose it (``lgwt(N, a, b)``)."""
+    return _lgwt_reference(int(n_nodes), a, b)
+
+
 @functools.lru_cache(maxsize=None)
 def approx_parameters(rhomax, T=0.5):
     """(Mf, Mg, Q, c, w) of solvers/MLP.py:111-139, cached."""

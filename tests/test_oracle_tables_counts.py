@@ -57,3 +57,23 @@ def test_exact_solution_formula():
     assert np.isclose(eq.exact_solution(x)[0, 0], 1 - 1 / (1 + np.exp(0.45)))
     assert np.isclose(eq.mu(), -1 / 3 - 0.25 ** 2 / 2) and eq.sigma() == 0.25
     assert np.allclose(eq.g(x), eq.exact_solution(x))
+
+
+def test_solver_classes_expose_inverse_gamma_and_lgwt():
+    """solvers/MLP.py:57-109 (and the copy in ScaSML.py:65-117): the two table routines are methods of the reference's solver classes; the
+    drop-in classes keep them (host NumPy: no GPU needed to construct an MLP).  Values: SURVEY.md Appendix B."""
+    import numpy as np
+    from oracle import tables as otab
+    from scasml_gp_amd.equations.equations import Grad_Dependent_Nonlinear
+    from scasml_gp_amd.solvers.MLP import MLP
+    from scasml_gp_amd.solvers.ScaSML import ScaSML
+    s = MLP(Grad_Dependent_Nonlinear(21))
+    assert abs(s.inverse_gamma(3.0 ** 1.5) - 3.880) < 1e-3 and abs(s.inverse_gamma(2.0) - 3.002) < 1e-3
+    assert np.allclose(s.inverse_gamma(np.array([2.0, 3.0])), [otab.inverse_gamma(2.0), otab.inverse_gamma(3.0)], rtol=1e-15)
+    x, w = s.lgwt(3, 0.0, 0.5)
+    xo, wo = otab.lgwt(3, 0.0, 0.5)
+    assert np.array_equal(x, xo) and np.array_equal(w, wo) and abs(w.sum() - 0.2598) < 1e-4           # not Gauss-Legendre (E-1): the reference's rule
+    x1, w1 = s.lgwt(1, 0.0, 0.5)
+    assert np.allclose(x1, [0.25]) and np.allclose(w1, [0.5])
+    assert np.isnan(s.lgwt(2, 0.0, 0.5)[1]).any()                                                       # the q = 2 NaN weight
+    assert ScaSML.inverse_gamma is not None and ScaSML.lgwt is not None
