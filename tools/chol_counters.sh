@@ -1,5 +1,6 @@
 #!/bin/bash
 # Run on the GPU box (through gpurun): matrix-pipe counters of the factorisation kernels at a given M.
+# (SQ counters only: a FETCH_SIZE / WRITE_SIZE pass over the ~17 000 launches of two factorisations at M = 70 016 did not finish in 7 minutes.)
 #   tools/chol_counters.sh <M> <tag>     writes gpurun_out/<tag>_trace, gpurun_out/<tag>_pmc and gpurun_out/<tag>_cholesky_counters.txt
 set -e
 M=$1; tag=$2
