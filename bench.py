@@ -384,7 +384,13 @@ def rccl_selftest(ranks, B, d):
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     e1.record()
     torch.cuda.synchronize()
-    return {"ranks": 1, "buffer": "(%d, %d) f32" % (B, d + 1), "allreduce_ms": round(e0.elapsed_time(e1) / 10, 4), "unchanged": bool(torch.equal(buf, ref))}
+    sub = dist.new_group([0])                               # the sample-sharded leg reduces inside sub-groups of the world: one of those, through RCCL
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=sub)
+    t = torch.tensor([1.5], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)                # the MAX-over-ranks of the timed region
+    torch.cuda.synchronize()
+    return {"ranks": 1, "buffer": "(%d, %d) f32" % (B, d + 1), "allreduce_ms": round(e0.elapsed_time(e1) / 10, 4),
+            "unchanged": bool(torch.equal(buf, ref)) and float(t.item()) == 1.5, "subgroup_allreduce": True}
 
 
 # =========================================================================================== CPU baseline and accuracy

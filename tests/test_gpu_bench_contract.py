@@ -123,4 +123,4 @@ def test_the_rccl_branches_execute_on_one_rank():
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert j["backend"] == "nccl" and j["rccl_ranks"] == 1 and j["value"] > 0
     st = j["rccl_selftest"]
-    assert st["ranks"] == 1 and st["unchanged"] and st["allreduce_ms"] > 0
+    assert st["ranks"] == 1 and st["unchanged"] and st["allreduce_ms"] > 0 and st["subgroup_allreduce"]
