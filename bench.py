@@ -72,9 +72,13 @@ def parse():
                     help="roots: each rank its own B roots, no collective (weak scaling, default); samples: every rank the same "
                          "B roots and 1/world of the Monte-Carlo units of the root call, ONE all-reduce of the partial estimators "
                          "(strong scaling; BASELINE.json north_star)")
-    ap.add_argument("--max-imbalance", type=float, default=1.15,
-                    help="samples leg: use the largest number of sample ranks (a divisor of the rank count) whose dealt load "
-                         "max/mean stays below this; the remaining factor shards roots")
+    ap.add_argument("--min-sample-efficiency", type=float, default=0.9,
+                    help="samples leg: use the largest number of sample ranks S (a divisor of the rank count) whose PREDICTED strong-scaling "
+                         "efficiency -- unsharded step / (ranks x (slowest rank's modelled time + the stated all-reduce cost)) -- reaches this "
+                         "(BASELINE.json north_star: 0.9); the remaining factor shards roots.  0: all ranks share the samples")
+    ap.add_argument("--allreduce-busbw-gbs", type=float, default=100.0,
+                    help="stated cost of the one all-reduce in that prediction: bus bandwidth of RCCL's all-reduce at this message size (GB/s) ...")
+    ap.add_argument("--allreduce-latency-us", type=float, default=40.0, help="... and its fixed latency; no multi-GPU node has measured either yet")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-logs-check", action="store_true", help="skip the d = 20 runs on the reference's own random stream (about a second)")
     ap.add_argument("--no-other-runs", action="store_true", help="skip the other_runs block (the other BASELINE configs and modes, 5 timed steps each)")
@@ -271,30 +275,74 @@ def other_runs(ranks, args, eq100, gp100, x_dom, x_bdy):
     return out
 
 
+def other_runs_summary(others):
+    """[[short label, ms_per_step, value]] of other_runs, well under 600 characters."""
+    if not others:
+        return None
+    out = []
+    for o in others:
+        w = o["workload"]
+        label = ("configs[1] MLP d=20 n=2 B=2^20" if "configs[1]" in w else
+                 "configs[3] ScaSML_fh d=100 n=4 M=3 B=2^14" if "configs[3]" in w else
+                 "configs[2] parity mode (jax stream + f16 casts)" if "parity mode" in w else
+                 "configs[2] reference-geometry" if "reference-geometry" in w else
+                 "configs[4] staged: d=250 ScaSML n=3 B=2^10, 20000 colloc" if "configs[4]" in w else w[:48])
+        out.append([label, o["ms_per_step"], float("%.4g" % o["value"])])
+    return out
+
+
 # =========================================================================================== multi-GPU legs
-def sample_split(eng, n, par, world, max_imbalance):
-    """(sample ranks S, root groups G, imbalance at S, imbalance if all `world` ranks shared the samples): the largest
-    divisor S of `world` whose cost-dealt load max/mean stays under the bound."""
-    from scasml_gp_amd.solvers._picard import deal_units
-    plan = eng.plan(n, par)
-    imb = {}
+# A sample-sharded rank's step beyond its dealt share of the unsharded step (ms, one MI355X, headline shape, profiles/r06_sample_sharding_rank_times.txt):
+# three launches whose ramp and tail do not shrink with the share, ACCUMULATE's un-pipelined root call (8 ranks: 2.80 measured, 2.68 by share alone)
+SAMPLE_RANK_FIXED_MS = 0.12
+
+
+def allreduce_model_ms(nbytes, ranks, args):
+    """The STATED cost of one all-reduce of `nbytes` over `ranks` ranks (no multi-GPU node has measured it): latency + 2 (S - 1) / S x bytes / bus bandwidth."""
+    if ranks <= 1:
+        return 0.0
+    return args.allreduce_latency_us * 1e-3 + 2.0 * (ranks - 1) / ranks * nbytes / (args.allreduce_busbw_gbs * 1e9) * 1e3
+
+
+def sample_split_table(eng, n, par, world, unsharded_ms, roots, d, args):
+    """Per divisor S of `world` (S sample ranks x G = world / S root groups): the dealt load (scasml_plan_deal_units with the surrogate's site
+    costs: second evaluations of shared node points and replayed path steps included), the slowest rank's modelled step -- its share of the
+    measured unsharded step of these `roots` roots, cut G ways by the root groups, plus the fixed cost of a sharded step -- the stated
+    all-reduce cost for (roots / G)(1 + d) floats, and the predicted strong-scaling efficiency unsharded / (world x (rank + all-reduce))."""
+    from scasml_gp_amd.solvers._picard import deal_units, site_cost
+    plan, cost = eng.plan(n, par), site_cost(eng.gp)
+    whole = float(deal_units(plan, 1, cost)[1][0])
+    table = []
     for s in range(1, world + 1):
-        if world % s == 0:
-            load = deal_units(plan, s)[1]
-            imb[s] = float(load.max() / load.mean())
-    best = max(s for s, v in imb.items() if v <= max_imbalance or s == 1)
-    return best, world // best, imb[best], imb[world]
+        if world % s:
+            continue
+        g = world // s
+        load = deal_units(plan, s, cost)[1]
+        rank_ms = unsharded_ms / g * float(load.max()) / whole + (SAMPLE_RANK_FIXED_MS if s > 1 else 0.0)
+        ar_ms = allreduce_model_ms((roots // g) * (d + 1) * 4, s, args)
+        table.append({"sample_ranks": s, "root_groups": g, "dealt_load_max_over_mean": round(float(load.max() / load.mean()), 4),
+                      "dealt_load_sum_over_unsharded": round(float(load.sum()) / whole, 4), "modelled_rank_ms": round(rank_ms, 4),
+                      "allreduce_ms_stated": round(ar_ms, 4), "predicted_efficiency": round(unsharded_ms / (world * (rank_ms + ar_ms)), 4)})
+    return table
 
 
 class SampleSharding:
-    """The north-star split: Monte-Carlo units of the root call over S ranks (one all-reduce), roots over the G groups."""
+    """The north-star split: Monte-Carlo units of the root call over S ranks (one all-reduce), roots over the G groups.  S is chosen by
+    PREDICTED efficiency from a short calibration of the unsharded step on every rank (the slowest rank's time, so all ranks agree)."""
 
-    def __init__(self, ranks, wl, max_imbalance):
+    def __init__(self, ranks, wl, args):
         import torch
         from scasml_gp_amd import parallel
         self.ranks, self.wl, self.parallel = ranks, wl, parallel
         world, rank = ranks.world, ranks.rank
-        self.S, self.G, self.imb, self.imb_all = sample_split(wl.eng, wl.n, wl.par, world, max_imbalance) if world > 1 else (1, 1, 1.0, 1.0)
+        self.S, self.G, self.table, self.calibration_ms = 1, 1, None, None
+        if world > 1:
+            self.calibration_ms = timed_leg(ranks, wl.step, 3, 2) / 3 * 1e3
+            self.table = sample_split_table(wl.eng, wl.n, wl.par, world, self.calibration_ms, wl.B, wl.d, args)
+            ok = [row for row in self.table if row["predicted_efficiency"] >= args.min_sample_efficiency or row["sample_ranks"] == 1]
+            self.S = max(row["sample_ranks"] for row in ok)
+            self.G = world // self.S
+        self.row = next((row for row in self.table if row["sample_ranks"] == self.S), None) if self.table else None
         self.group_id, self.srank = rank // self.S, rank % self.S
         self.group = None
         if world > 1 and self.S > 1:
@@ -304,13 +352,21 @@ class SampleSharding:
                     self.group = h
         self.lo, self.cnt = parallel.root_slice(wl.B, self.group_id, self.G)
         self.x_shared = wl.x_dev if rank == 0 else torch.from_numpy(wl.synth(1234)).cuda()   # the same B roots on every rank
+        self.compute_events = None                                # [(start, end)] of eng.solve alone, when the leg is being timed per rank
 
     def step(self, sid=None):
+        import torch
         wl, eng = self.wl, self.wl.eng
         if sid is None:
             sid = eng.calls
             eng.calls += 1
+        if self.compute_events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         out, uhat, _ = eng.solve(wl.n, wl.par, self.x_shared[self.lo:self.lo + self.cnt], root0=self.lo, rank=self.srank, world=self.S, stream_id=sid)
+        if self.compute_events is not None:
+            e1.record()
+            self.compute_events.append((e0, e1))
         if self.S > 1:
             if self.ranks.on_host:
                 host = out.cpu()
@@ -321,14 +377,33 @@ class SampleSharding:
             eng.finalize_partials(out)
         return out, uhat
 
-    def report(self, t_s, t_r, steps):
+    def rank_compute_ms(self):
+        """Every rank's own compute time per step of the leg just timed (HIP events around its three kernels, the all-reduce outside):
+        gathered so that rank 0 can print the measured times next to the dealt loads."""
+        import torch
+        torch.cuda.synchronize()
+        ev, self.compute_events = self.compute_events, None
+        mine = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+        t = torch.zeros(self.ranks.world, dtype=torch.float64, device="cpu" if self.ranks.on_host else "cuda")
+        t[self.ranks.rank] = mine
+        self.ranks.dist.all_reduce(t, op=self.ranks.dist.ReduceOp.SUM)
+        return [round(float(v), 4) for v in t.tolist()]
+
+    def report(self, t_s, t_r, steps, rank_ms):
         wl, world = self.wl, self.ranks.world
-        return {"sample_ranks": self.S, "root_groups": self.G, "unit_load_imbalance_max_over_mean": round(self.imb, 3),
-                "imbalance_if_all_ranks_shared_samples": round(self.imb_all, 3),
+        ms_s, ms_r = t_s / steps * 1e3, t_r / steps * 1e3
+        return {"sample_ranks": self.S, "root_groups": self.G,
+                "chosen_by": "largest S with predicted_efficiency >= the requested minimum (S = 1: roots only)",
+                "unit_load_imbalance_max_over_mean": self.row["dealt_load_max_over_mean"], "predicted_efficiency": self.row["predicted_efficiency"],
+                "predicted_from": {"unsharded_step_ms_calibration": round(self.calibration_ms, 3), "fixed_ms_per_sharded_rank_step": SAMPLE_RANK_FIXED_MS,
+                                   "per_S": self.table},
                 "collective": "1 all-reduce of (B/G, 1+d) f32 per step over %d ranks" % self.S,
-                "scaling": "strong", "roots_total": wl.B, "ms_per_step": round(t_s / steps * 1e3, 3),
+                "scaling": "strong", "roots_total": wl.B, "ms_per_step": round(ms_s, 3),
                 "value": round(wl.B * wl.steps_exec * steps / t_s, 1),
-                "roots_leg": {"scaling": "weak", "roots_total": world * wl.B, "ms_per_step": round(t_r / steps * 1e3, 3),
+                # measured: the B roots of ONE GPU's unsharded step (the roots leg's per-GPU work) shared by all `world` ranks
+                "efficiency_vs_unsharded_step": round(ms_r / (world * ms_s), 4),
+                "rank_compute_ms": rank_ms, "rank_compute_ms_max_over_mean": round(max(rank_ms) / (sum(rank_ms) / len(rank_ms)), 4) if rank_ms else None,
+                "roots_leg": {"scaling": "weak", "roots_total": world * wl.B, "ms_per_step": round(ms_r, 3),
                               "value": round(world * wl.B * wl.steps_exec * steps / t_r, 1)}}
 
     def max_abs_diff_vs_unsharded(self):
@@ -590,6 +665,11 @@ def gp_eval_roofline(args, wl, gp_ms):
                        "not rounded: factored sums)" % (planes, "" if planes == 1 else "s")) if geometry else
                       "gp_eval_compat_mfma_kernel (as-coded surrogate: 3 shifted geometries x 2 fp16 planes, float16 entries)",
             "peak": peak, "frac": round(ach / peak, 4), "vector": vector,
+            # what binds this kernel is the SUM of its vector time and its matrix time, not the matrix roof (`frac`, kept as the contract's A / P):
+            # the primary fraction is modelled (vector + matrix) time over the profiled launch, from the PMC passes on this kernel source
+            "bound": "valu+mfma (sum model)", "primary_fraction": "frac_of_sum_model",
+            "frac_of_sum_model": vector["frac_of_sum_model"] if vector else None,
+            "frac_of_matrix_roof": round(ach / peak, 4),
             "mfma_issued_tflops": round(issued, 1), "mfma_issued_frac": round(issued / peak, 4),
             "as_coded": {"flops_per_launch": flops_ac, "achieved": round(ach_ac, 3), "frac": round(ach_ac / peak, 4),
                          "note": "algorithmic flops of the surrogate the reference's code builds: 3 x.y products per pair where eps_PDE is "
@@ -725,7 +805,7 @@ def main():
     x_dom, x_bdy, xt_h = harness_sets(eq, args.train_domain, args.train_boundary)
     gp, t_train = fit_surrogate(eq, x_dom, x_bdy, args.compat) if args.solver == "scasml" else (None, 0.0)
     wl = Workload(eq, gp, args.solver, args.variant, n, args.M, B, rank, rng=args.rng, compat_f16=args.compat_f16)
-    sharding = SampleSharding(ranks, wl, args.max_imbalance)
+    sharding = SampleSharding(ranks, wl, args)
     by_samples = args.shard == "samples" and world > 1
     main_step = sharding.step if by_samples else wl.step
 
@@ -735,7 +815,9 @@ def main():
     if world > 1:
         t_other = timed_leg(ranks, wl.step if by_samples else sharding.step, args.steps, args.warmup)
         t_s, t_r = (elapsed, t_other) if by_samples else (t_other, elapsed)
-        samples_leg = sharding.report(t_s, t_r, args.steps)
+        sharding.compute_events = []                          # a third, short pass: every rank's own compute time per sharded step
+        timed_leg(ranks, sharding.step, min(args.steps, 5), 0)
+        samples_leg = sharding.report(t_s, t_r, args.steps, sharding.rank_compute_ms())
         samples_leg["max_abs_diff_vs_unsharded"] = sharding.max_abs_diff_vs_unsharded()
     selftest = rccl_selftest(ranks, B, d) if (ranks.on and world == 1 and not ranks.on_host) else None
     dist_gp = dist_gp_check(ranks) if (world > 1 and os.environ.get("SCASML_BENCH_DIST_GP") == "1") else None
@@ -768,7 +850,13 @@ def main():
         "metric": "Euler-Maruyama path-steps/sec + L2 rel-error, Grad_Dependent_Nonlinear d=%d n=%d" % (d, n),
         "value": round(value, 1), "unit": "path-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-        "scaling": "strong" if by_samples else "weak", "rccl_ranks": ranks.dist.get_world_size() if ranks.on else 1,
+        "scaling": "strong" if by_samples else "weak",
+        # N > 1: the headline `value` above is the collective-free ROOTS leg unless --shard samples; the north-star leg (Monte-Carlo samples
+        # of the root call shared by the ranks, one all-reduce per step) is this block -- not to be mistaken for the headline's scaling
+        "north_star_samples_leg": ({k: samples_leg[k] for k in ("value", "ms_per_step", "scaling", "sample_ranks", "root_groups",
+                                                                 "efficiency_vs_unsharded_step", "predicted_efficiency")}
+                                   if samples_leg else None),
+        "rccl_ranks": ranks.dist.get_world_size() if ranks.on else 1,
         "rccl_note": "no multi-GPU node has been available to this build: the N > 1 path (init_process_group('nccl'), the in-group all-reduce) is "
                      "rehearsed over gloo on one GPU only (tests/test_gpu_bench_contract.py) until a SCALE run exists; with SCASML_BENCH_FORCE_DIST=1 the "
                      "same branches run over RCCL with one rank (rccl_selftest)",
@@ -793,6 +881,8 @@ def main():
         "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
         "gp_train_s": round(t_train, 2),
         "roofline": roofline, "roofline_path": path_roofline(wl, kernel_ms), "other_runs": others, "gp_train": gp_train, "cpu_baseline": cpu,
+        # LAST key, compact: the driver's record keeps the tail of this line -- [label, ms_per_step, path-steps/s] of every other run
+        "other_runs_summary": other_runs_summary(others),
     }
     print(json.dumps(line))
     ranks.close()

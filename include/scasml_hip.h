@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SCASML_ABI_VERSION 6
+#define SCASML_ABI_VERSION 7
 #define SCASML_MAX_LEVEL 5   /* Picard level n <= 5 (kernels are instantiated per level)      */
 #define SCASML_MAX_Q 6       /* quadrature nodes per rule <= 6 (rho <= 5, solvers/MLP.py:132)  */
 #define SCASML_MAX_DIM 252   /* spatial dimension d <= 252 (one 4-dim quad per lane, +t, +3 spare columns) */
@@ -253,13 +253,18 @@ int scasml_plan_site_kinds(const scasml_plan *plan_h, int32_t rank, int32_t worl
  * A node's state X_k, W_k is read back (ACCUMULATE), drawn directly (full history) or replayed from the path's own cheap
  * draws (solvers/MLP.py:215-225), and its surrogate values are evaluated by whoever owns either addend, so neither a
  * path nor a node need stay on one rank.  Costs are unequal (at n = rho = 3: 27 terminal samples, 20 addends of 1 site,
- * 9 of 10, 6 of 58 and 6 of 30), so they are dealt by cost -- longest processing time first onto the least loaded rank:
- * dealt-load max / mean 1.00 at 2, 4 and 8 ranks (whole paths as units, as up to ABI 5: 1.00, 1.60, 3.19); full history
- * n = 4, M = 3: 1.00, 1.00, 1.24 (whole samples: 1.43).  Cost of a unit = its Euler-Maruyama sites + 0.6 x its terminal
- * sites (a terminal-time point needs u_hat only).  Returns the number of units (<0 on error); fills owner_h[0 .. units)
- * (needs capacity >= units, world <= 255) and, if not NULL, load_h[0 .. world) with the cost dealt to every rank.  Philox is
- * keyed by tree site, so the sum over ranks does not depend on the dealing. */
-int32_t scasml_plan_deal_units(const scasml_plan *plan_h, int32_t world, uint8_t *owner_h, int32_t capacity, double *load_h);
+ * 9 of 10, 6 of 79 and 6 of 9 sites), so they are dealt by cost -- longest processing time first onto the least loaded rank.
+ * site_cost_h (host, may be NULL): {Euler-Maruyama site of a level-0 term (surrogate kind 0), of a level l > 0 term (kind 4: u_hat and
+ * div only), terminal site (kind 3: u_hat only), one replayed path step}, relative; NULL = {1, 1, 0.6, 0} (ABI <= 6).  ABI 7: the weights
+ * are the caller's (the as-coded surrogate at the headline shape measures {1, 0.62, 0.50, 0.04}: a rank that drew nine u_hat-and-div sites
+ * for free was 7 % slower than its dealt load said); a "-" addend stays with its node's "+" addend unless the least loaded rank ends lower
+ * even after evaluating the node's point a second time (the zero-cost "-" addends of level-1 nodes therefore never move a node point to a
+ * second rank); load_h includes the second evaluations and, for the quadrature solvers, the steps a rank replays up to the last node of a
+ * path it owns an addend of.  Dealt-load max / mean with the measured weights: 1.00 / 1.00 / 1.01 at 2 / 4 / 8 ranks (whole paths as
+ * units, as up to ABI 5: 1.00, 1.60, 3.19); full history n = 4, M = 3: 1.00, 1.00, 1.2 (whole samples: 1.43).
+ * Returns the number of units (<0 on error); fills owner_h[0 .. units) (needs capacity >= units, world <= 255) and, if not NULL,
+ * load_h[0 .. world) with the cost dealt to every rank.  Philox is keyed by tree site, so the sum over ranks does not depend on the dealing. */
+int32_t scasml_plan_deal_units(const scasml_plan *plan_h, int32_t world, const double *site_cost_h, uint8_t *owner_h, int32_t capacity, double *load_h);
 
 /* Full gradient of the posterior mean, n_inf x (d+1), time last: GP.compute_gradient (:673-687). */
 int scasml_gp_gradient(const scasml_gp_model *gp_h, const float *points, int64_t n_inf,
@@ -369,6 +374,31 @@ int scasml_gp_compat_pack_mfma(int32_t d, float a, const float *x_dom, int32_t n
 int scasml_gp_eval_compat_sites(int32_t d, float a, float sigma_eq, float mu_eq, int32_t eq_id, const float *model, int32_t n_dom,
                                 int32_t n_bdy, const int32_t *idx_h, int32_t round16, float x_bound, const float *points, int64_t n_inf,
                                 int64_t rows_per_site, const uint8_t *site_kinds, float *out4, float *lap, void *stream);
+/* ABI 7.  The same evaluation over a LIST of sites: site_order[0 .. n_listed) (DEVICE int32, distinct site indices < n_inf / rows_per_site) are
+ * the sites to evaluate, in launch order; rows_per_site must be a multiple of 32 (a 32-row wavefront tile is then one site) and n_inf a whole
+ * number of sites.  The grid covers the listed sites only: a Monte-Carlo sample-sharded rank launches nothing over the sites of other ranks
+ * (scasml_gp_eval_compat_sites launches a workgroup per 128 rows of the whole buffer and returns at once from 85 % of them on each of 8 ranks),
+ * and a list in falling cost order (site kind 0, then 4, then 3 and 1: solvers/_picard.py site_order) leaves the cheapest workgroups to the
+ * grid's last, partly filled round.  Every row's values are those of scasml_gp_eval_compat_sites bit for bit, whatever the order
+ * (tests/test_gpu_compat_mfma.py).  Rows of sites that are not listed are left untouched. */
+int scasml_gp_eval_compat_site_list(int32_t d, float a, float sigma_eq, float mu_eq, int32_t eq_id, const float *model, int32_t n_dom,
+                                    int32_t n_bdy, const int32_t *idx_h, int32_t round16, float x_bound, const float *points, int64_t n_inf,
+                                    int64_t rows_per_site, const uint8_t *site_kinds, const int32_t *site_order, int32_t n_listed,
+                                    float *out4, float *lap, void *stream);
+
+/* ABI 7.  Cross-kernel feature rows K(x, phi): GP.kernel_x_t_phi (models/GP.py:271-294; op 0), laplacian_x_t_kernel_x_t_phi (:326-354; op 1),
+ * dt_x_t_kernel_x_t_phi (:356-383; op 2), div_x_t_kernel_x_t_phi (:385-411; op 3), dx_t_kernel_x_t_phi (:296-324; op 4) and, with a single
+ * row, kernel_x_t_phi_single (:630-651) -- the matrices the reference materialises for predict / compute_gradient / compute_PDE_loss; the hot
+ * path contracts them on the fly (scasml_gp_eval*), these entry points exist for callers of the reference's class surface.
+ *   x_inf  : n_inf rows of d+1 coordinates (time last), row stride ld_inf floats (the point buffers of this library qualify)
+ *   op 0-3 : out[i * ld + col] = (L^op_x L^oy_y kappa)(x_i, y_j), columns in the Gram's order [u(dom), u(bdy), Lap(dom), dt(dom), div(dom)], ld >= M
+ *   op 4   : out[(i * M + col) * (d+1) + k] = d/dx_k of the op-0 entry (ld ignored); n_inf * M * (d+1) doubles
+ *   surrogate 0: the reference's code (5-index Hutchinson on the shifted argument; round16 as scasml_gp_gram_compat: bit 0 = every entry a
+ *   float16 value, bit 2 = the float16 op sequence on float16 rows); 1: the operators it documents (idx_h, round16 ignored).
+ * The as-coded rows are the per-pair arithmetic of scasml_gp_gram_compat: at the collocation points themselves they ARE the Gram's rows. */
+int scasml_gp_cross_rows(int32_t d, double a, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy, const int32_t *idx_h,
+                         int32_t round16, int32_t surrogate, int32_t op, const float *x_inf, int64_t n_inf, int64_t ld_inf, double *out,
+                         int64_t ld, void *stream);
 
 /* ------------------------------------------------------------------ block-row distributed Gram / Cholesky / solves
  * For collocation sets whose K(phi, phi) does not fit one GPU (BASELINE configs[4]: 1e5 points, M = 350 000, 980 GB float64)

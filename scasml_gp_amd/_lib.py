@@ -8,7 +8,7 @@ MAX_Q = 6
 MAX_DIM = 252
 GP_TILE = 32
 DIST_BLOCK = 256
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 MODE_MLP, MODE_GENERATE, MODE_ACCUMULATE = 0, 1, 2
 RNG_COMPAT_CRN = 1
@@ -76,7 +76,7 @@ SIGNATURES = {
     "scasml_gp_eval": (C.c_int, [C.POINTER(GpModel), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "scasml_gp_eval_sites": (C.c_int, [C.POINTER(GpModel), C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "scasml_plan_site_kinds": (C.c_int, [C.POINTER(Plan), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
-    "scasml_plan_deal_units": (C.c_int32, [C.POINTER(Plan), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "scasml_plan_deal_units": (C.c_int32, [C.POINTER(Plan), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "scasml_gp_gradient": (C.c_int, [C.POINTER(GpModel), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "scasml_gp_gram": (C.c_int, [C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "scasml_gp_newton_b": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
@@ -97,6 +97,11 @@ SIGNATURES = {
                                              C.c_void_p, C.c_void_p]),
     "scasml_gp_eval_compat_sites": (C.c_int, [C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                               C.c_int32, C.c_float, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "scasml_gp_eval_compat_site_list": (C.c_int, [C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                                  C.c_int32, C.c_float, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                                  C.c_void_p, C.c_void_p]),
+    "scasml_gp_cross_rows": (C.c_int, [C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "scasml_gp_gram_rows": (C.c_int, [C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int64,
                                       C.c_void_p, C.c_int64, C.c_void_p]),
     "scasml_gp_gram_compat_rows": (C.c_int, [C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64,

@@ -275,6 +275,116 @@ __global__ void gp_gram_compat_rows_kernel(int d, double a, const float *x_dom, 
     }
 }
 
+// ---------------------------------------------------------------------------------- cross-kernel rows (models/GP.py:271-411, 630-651)
+// The feature rows of ONE operator `ox` (0 = I, 1 = Lap, 2 = dt, 3 = div, applied in x) at ARBITRARY points x_inf against every collocation
+// point: kernel_x_t_phi (ox = 0), laplacian_x_t_ / dt_x_t_ / div_x_t_kernel_x_t_phi -- the matrices the reference materialises for predict and
+// compute_PDE_loss (the hot path contracts them on the fly: gp_eval_compat_kernel, gp_eval_compat_mfma.hip).  Columns in the Gram's order
+// [u(dom), u(bdy), Lap(dom), dt(dom), div(dom)].  surrogate 0: the reference's code (pair_geometry + compat_blocks, as the Gram rows); 1: the
+// operators it documents (exact Laplacian, no rounding).
+__device__ __forceinline__ void exact_blocks(int d, double a, double kap, double rho2, double S, double rt, double (&P)[4][4]) {
+    const double a2 = a * a, lap = a2 * rho2 - a * d;
+    P[0][0] = kap;
+    P[0][1] = P[1][0] = lap * kap;
+    P[0][2] = a * rt * kap;
+    P[2][0] = -a * rt * kap;
+    P[0][3] = a * S * kap;
+    P[3][0] = -a * S * kap;
+    P[2][2] = (a - a2 * rt * rt) * kap;
+    P[2][3] = P[3][2] = -a2 * rt * S * kap;
+    P[3][3] = (a * d - a2 * S * S) * kap;
+    P[2][1] = -a * rt * lap * kap;
+    P[1][2] = a * rt * lap * kap;
+    P[3][1] = -(a * S * lap - 2.0 * a2 * S) * kap;
+    P[1][3] = (a * S * lap - 2.0 * a2 * S) * kap;
+    P[1][1] = (a2 * a2 * rho2 * rho2 - (2.0 * d + 4.0) * a2 * a * rho2 + ((double)d * d + 2.0 * d) * a2) * kap;
+}
+
+__global__ void gp_cross_rows_kernel(int d, double a, const float *x_dom, int n_dom, const float *x_bdy, int n_bdy, CompatIdx ix, int r16, int surrogate,
+                                     int ox, const float *x_inf, int64_t n_inf, int64_t ld_inf, double *out, int64_t ld) {
+    const int N = n_dom + n_bdy;
+    const int64_t i = (int64_t)blockIdx.y * blockDim.y + threadIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_inf || j >= N) return;
+    const float *xi = x_inf + i * ld_inf;
+    const float *yj = j < n_dom ? x_dom + (int64_t)j * (d + 1) : x_bdy + (int64_t)(j - n_dom) * (d + 1);
+    double P[4][4];
+    if (surrogate == 1) {
+        double r2 = 0.0, S = 0.0;
+        for (int k = 0; k < d; ++k) {
+            const double r = (double)xi[k] - (double)yj[k];
+            r2 = fma(r, r, r2);
+            S += r;
+        }
+        const double rt = (double)xi[d] - (double)yj[d];
+        exact_blocks(d, a, exp(-0.5 * a * fma(rt, rt, r2)), r2, S, rt, P);
+    } else {
+        PairGeom g;
+        pair_geometry(d, a, ix, [&](int k) { return (double)xi[k]; }, [&](int k) { return (double)yj[k]; }, g);
+        compat_blocks(d, a, g, r16 & 1, P);
+        if ((r16 & 4) && row_is_f16(d, [&](int k) { return (double)xi[k]; })) {      // float16 rows on float16 collocation points (the caller vouches for those)
+            f16_graph_blocks(d, a, [&](int k) { return xi[k]; }, [&](int k) { return yj[k]; }, P);
+            if (r16 & 8) {
+                const int D = d + 1;
+                P[0][1] = f16_graph_hutchinson(d, a, ix, [&](int k) { return xi[k]; }, [&](int k) { return yj[(k + 1) % D]; });
+                P[1][0] = f16_graph_hutchinson(d, a, ix, [&](int k) { return xi[(k + 1) % D]; }, [&](int k) { return yj[k]; });
+            }
+        }
+    }
+    const int nops_j = j < n_dom ? 4 : 1;
+    for (int oy = 0; oy < nops_j; ++oy) {
+        const int64_t col = oy == 0 ? j : (int64_t)N + (int64_t)(oy - 1) * n_dom + j;
+        out[i * ld + col] = P[ox][oy];
+    }
+}
+
+// dx_t_kernel_x_t_phi (models/GP.py:296-324): the gradient in x of the FIRST feature row -- out[i][col][k] = d/dx_k of (kappa, lap_y kappa,
+// dt_y kappa, div_y kappa)(x_i, y_j), k <= d with the time derivative last; autodiff passes through the entries' float16 casts, so these are the
+// derivatives of the un-rounded entries, each rounded once (.astype(float16), :324).  As coded, with r = x - y, r1 = x - y' and
+// sg1 = sum_j (a^2 r1_{i_j}^2 - a):  d kappa = -a r_k kappa0;  d(dt_y) = (a [k = d] - a^2 r_t r_k) kappa0;  d(div_y) = (a [k < d] - a^2 S r_k) kappa0;
+// d(lap_y) = h kappa1 r1_k (2 a^2 [k in idx] - a sg1).  Documented: d(lap_y) = (2 a^2 r_k [k < d] - a r_k (a^2 rho^2 - a d)) kappa0.
+__global__ void gp_cross_grad_rows_kernel(int d, double a, const float *x_dom, int n_dom, const float *x_bdy, int n_bdy, CompatIdx ix, int r16,
+                                          int surrogate, const float *x_inf, int64_t n_inf, int64_t ld_inf, double *out, int64_t M) {
+    const int N = n_dom + n_bdy, D = d + 1;
+    const int64_t i = (int64_t)blockIdx.y * blockDim.y + threadIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_inf || j >= N) return;
+    const float *xi = x_inf + i * ld_inf;
+    const float *yj = j < n_dom ? x_dom + (int64_t)j * D : x_bdy + (int64_t)(j - n_dom) * D;
+    double r2 = 0.0, S = 0.0, r2s = 0.0;
+    for (int k = 0; k < D; ++k) {
+        const double r = (double)xi[k] - (double)yj[k], r1 = (double)xi[k] - (double)yj[(k + 1) % D];
+        r2 = fma(r, r, r2);
+        r2s = fma(r1, r1, r2s);
+        if (k < d) S += r;
+    }
+    const double rt = (double)xi[d] - (double)yj[d];
+    const double kap0 = exp(-0.5 * a * r2), kap1 = exp(-0.5 * a * r2s), a2 = a * a, h = (double)d / kMC;
+    double sg1 = 0.0;
+    for (int q = 0; q < kMC; ++q) {
+        const double r1 = (double)xi[ix.i[q]] - (double)yj[ix.i[q] + 1];
+        sg1 += a2 * r1 * r1 - a;
+    }
+    const double lap = a2 * (r2 - rt * rt) - a * d;
+    const int on = surrogate == 1 ? 0 : (r16 & 1);
+    double *o = out + (i * M + j) * D;
+    for (int k = 0; k < D; ++k) o[k] = round16(-a * ((double)xi[k] - (double)yj[k]) * kap0, on);
+    if (j >= n_dom) return;
+    double *oL = out + (i * M + N + j) * D, *ot = out + (i * M + N + n_dom + j) * D, *oS = out + (i * M + N + 2 * (int64_t)n_dom + j) * D;
+    for (int k = 0; k < D; ++k) {
+        const double r = (double)xi[k] - (double)yj[k];
+        ot[k] = round16(((k == d ? a : 0.0) - a2 * rt * r) * kap0, on);
+        oS[k] = round16(((k < d ? a : 0.0) - a2 * S * r) * kap0, on);
+        if (surrogate == 1) {
+            oL[k] = ((k < d ? 2.0 * a2 * r : 0.0) - a * r * lap) * kap0;
+        } else {
+            bool in_idx = false;
+            for (int q = 0; q < kMC; ++q) in_idx |= ix.i[q] == k;
+            const double r1 = (double)xi[k] - (double)yj[(k + 1) % D];
+            oL[k] = round16(h * kap1 * r1 * ((in_idx ? 2.0 * a2 : 0.0) - a * sg1), on);
+        }
+    }
+}
+
 // diagonal of K + nugget I rounded to float16 (kernel_phi_phi_perturb.astype(float16), models/GP.py:268): the entries of K are
 // float16 values already, so only the diagonal moves
 __global__ void round16_diag_kernel(double *A, int64_t M, int64_t lda, double nugget) {
@@ -515,6 +625,33 @@ extern "C" int scasml_gp_gram_compat_rows(int32_t d, double a, const float *x_do
         r = stop;
     }
     return check_launch("gp_gram_compat_rows launch");
+}
+
+extern "C" int scasml_gp_cross_rows(int32_t d, double a, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy, const int32_t *idx_h,
+                                    int32_t round16, int32_t surrogate, int32_t op, const float *x_inf, int64_t n_inf, int64_t ld_inf, double *out,
+                                    int64_t ld, void *stream) {
+    if (!x_dom || !out || !x_inf || (n_bdy > 0 && !x_bdy)) return fail(SCASML_ERR_ARG, "gp_cross_rows: null argument");
+    const int64_t M = 4 * (int64_t)n_dom + n_bdy;
+    if (d < 1 || d > SCASML_MAX_DIM || n_dom < 1 || n_bdy < 0 || n_inf < 0 || ld_inf < d + 1) return fail(SCASML_ERR_ARG, "gp_cross_rows: bad sizes");
+    if (surrogate != 0 && surrogate != 1) return fail(SCASML_ERR_ARG, "gp_cross_rows: surrogate must be 0 (as coded) or 1 (documented operators)");
+    if (op < 0 || op > 4) return fail(SCASML_ERR_ARG, "gp_cross_rows: op must be 0 (I), 1 (Lap), 2 (dt), 3 (div) or 4 (gradient of the I row)");
+    if (op < 4 && ld < M) return fail(SCASML_ERR_ARG, "gp_cross_rows: ld %lld < M = %lld", (long long)ld, (long long)M);
+    CompatIdx ix = {{0, 0, 0, 0, 0}};
+    if (surrogate == 0) {
+        if (d < kMC) return fail(SCASML_ERR_ARG, "gp_cross_rows: the as-coded surrogate needs d >= %d", kMC);
+        if (int rc = check_idx(idx_h, d, ix, "gp_cross_rows")) return rc;
+    }
+    if (n_inf == 0) return 0;
+    const int N = n_dom + n_bdy;
+    const int64_t gy = (n_inf + 15) / 16;
+    if (gy > 65535) return fail(SCASML_ERR_UNSUPPORTED, "gp_cross_rows: at most %d rows per call", 65535 * 16);
+    if (op == 4)
+        hipLaunchKernelGGL(gp_cross_grad_rows_kernel, dim3((N + 15) / 16, (unsigned)gy), dim3(16, 16), 0, (hipStream_t)stream, d, a, x_dom, n_dom, x_bdy,
+                           n_bdy, ix, round16, surrogate, x_inf, n_inf, ld_inf, out, M);
+    else
+        hipLaunchKernelGGL(gp_cross_rows_kernel, dim3((N + 15) / 16, (unsigned)gy), dim3(16, 16), 0, (hipStream_t)stream, d, a, x_dom, n_dom, x_bdy, n_bdy,
+                           ix, round16, surrogate, op, x_inf, n_inf, ld_inf, out, ld);
+    return check_launch("gp_cross_rows launch");
 }
 
 extern "C" int scasml_round16_diag(double *A, int64_t M, int64_t lda, double nugget, void *stream) {

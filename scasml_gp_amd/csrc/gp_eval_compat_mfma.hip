@@ -66,6 +66,8 @@ struct GpCompatArgs {
     int32_t round_out;        // u_hat and eps_PDE leave as float16 values (predict / compute_PDE_loss .astype(float16), models/GP.py:671, 769)
     const uint8_t *site_kinds;
     int64_t rows_per_site;
+    const int32_t *site_order;   // scasml_gp_eval_compat_site_list: the sites to evaluate, in launch order (a 32-row wavefront tile is one site); null: all rows
+    int32_t n_listed;
 };
 
 // round two float32 to float16 (RNE) in one instruction; R16 = false keeps them (development / parity of the formulas)
@@ -326,12 +328,31 @@ __global__ __launch_bounds__(256, BPC) void gp_eval_compat_mfma_kernel(const GpC
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int col = lane & 31, half = lane >> 5;
     const int64_t blk = blockIdx.x;
-    const int64_t p0 = (blk * WPB + wv) * 32;
+    int64_t p0 = (blk * WPB + wv) * 32;
     const int n_tiles = g.n_pad / 32;
     const int nb0 = g.first_bdy_tile < n_tiles ? g.first_bdy_tile : n_tiles;
 
+    // Site list (scasml_gp_eval_compat_site_list): the grid covers the LISTED sites only, in the list's order -- a sample-sharded rank launches no
+    // workgroup over the sites of other ranks (85 % of the grid returned at once on each of 8 ranks), and the host lists the sites by falling cost,
+    // so that the grid's last, partly filled round of workgroups is made of the cheapest ones.  rows_per_site is a multiple of 32 here: a wave is one site.
+    int form_listed = -1;
+    if (g.site_order) {
+        const int64_t wps = g.rows_per_site >> 5;
+        bool all_u = true, all_ud = true;
+        for (int w = 0; w < WPB; ++w) {                     // the form is a property of the workgroup: from the sites of its four waves
+            const int64_t vs = (blk * WPB + w) / wps;
+            if (vs >= g.n_listed) continue;
+            const int k = g.site_kinds ? g.site_kinds[g.site_order[vs]] : 0;
+            if (!(k == 1 || k == 3)) all_u = false;
+            if (!(k == 1 || k == 3 || k == 4)) all_ud = false;
+        }
+        form_listed = all_u ? 1 : (all_ud ? 2 : 0);
+        const int64_t vw = blk * WPB + wv, vs = vw / wps;
+        p0 = vs < g.n_listed ? (int64_t)g.site_order[vs] * g.rows_per_site + (vw - vs * wps) * 32 : g.n_inf;   // past the list: shadow rows, never stored
+    }
+
     // Monte-Carlo sample sharding: a workgroup that lies wholly inside sites of other ranks has nothing to do
-    if (g.site_kinds && g.rows_per_site >= 32) {
+    if (!g.site_order && g.site_kinds && g.rows_per_site >= 32) {
         const int64_t b0 = blk * WPB * 32;
         if (b0 < g.n_inf) {
             const int64_t b1 = (b0 + WPB * 32 < g.n_inf ? b0 + WPB * 32 : g.n_inf) - 1;
@@ -344,7 +365,9 @@ __global__ __launch_bounds__(256, BPC) void gp_eval_compat_mfma_kernel(const GpC
     // The form is a property of the WORKGROUP (all four waves walk the same stage sequence, because a stage is staged by all of
     // them): full unless every row of the workgroup lies in sites that need less.
     int form = 0;
-    if (g.site_kinds && g.rows_per_site >= 32) {
+    if (g.site_order) {
+        form = form_listed;
+    } else if (g.site_kinds && g.rows_per_site >= 32) {
         const int64_t b0 = blk * WPB * 32;
         const int64_t b1 = (b0 + WPB * 32 < g.n_inf ? b0 + WPB * 32 : g.n_inf) - 1;
         if (b0 < g.n_inf) {
@@ -664,8 +687,9 @@ static int launch_compat(const GpCompatArgs &g, hipStream_t s) {
     constexpr size_t lds_bytes = SCASML_COMPAT_NSLOT * (size_t)(KS * 256 + kStageTail) * sizeof(float);
     constexpr int BPC_REGS = REGS <= 128 ? 4 : (REGS <= 164 ? 3 : 2), BPC_LDS = (int)(160 * 1024 / lds_bytes);
     constexpr int BPC = BPC_REGS < BPC_LDS ? BPC_REGS : BPC_LDS;
-    const int64_t waves = (g.n_inf + 31) / 32;
+    const int64_t waves = g.site_order ? (int64_t)g.n_listed * (g.rows_per_site >> 5) : (g.n_inf + 31) / 32;
     const int64_t blocks = (waves + 3) / 4;
+    if (blocks == 0) return 0;
     if (blocks > 0x7FFFFFFF) return fail(SCASML_ERR_UNSUPPORTED, "gp_eval_compat_sites: too many points");
     static_assert(lds_bytes * BPC <= 160 * 1024, "LDS slots exceed 160 KiB");
     auto kern = gp_eval_compat_mfma_kernel<KS, BPC, R16, PLANES>;
@@ -722,9 +746,35 @@ extern "C" int scasml_gp_compat_pack_mfma(int32_t d, float a, const float *x_dom
     return check_launch("gp_compat_pack_mfma launch");
 }
 
+static int eval_compat_sites(int32_t d, float a, float sigma_eq, float mu_eq, int32_t eq_id, const float *model, int32_t n_dom,
+                             int32_t n_bdy, const int32_t *idx_h, int32_t round16, float x_bound, const float *points, int64_t n_inf,
+                             int64_t rows_per_site, const uint8_t *site_kinds, const int32_t *site_order, int32_t n_listed, float *out4, float *lap,
+                             void *stream);
+
 extern "C" int scasml_gp_eval_compat_sites(int32_t d, float a, float sigma_eq, float mu_eq, int32_t eq_id, const float *model, int32_t n_dom,
                                            int32_t n_bdy, const int32_t *idx_h, int32_t round16, float x_bound, const float *points, int64_t n_inf,
                                            int64_t rows_per_site, const uint8_t *site_kinds, float *out4, float *lap, void *stream) {
+    return eval_compat_sites(d, a, sigma_eq, mu_eq, eq_id, model, n_dom, n_bdy, idx_h, round16, x_bound, points, n_inf, rows_per_site, site_kinds, nullptr,
+                             0, out4, lap, stream);
+}
+
+extern "C" int scasml_gp_eval_compat_site_list(int32_t d, float a, float sigma_eq, float mu_eq, int32_t eq_id, const float *model, int32_t n_dom,
+                                               int32_t n_bdy, const int32_t *idx_h, int32_t round16, float x_bound, const float *points, int64_t n_inf,
+                                               int64_t rows_per_site, const uint8_t *site_kinds, const int32_t *site_order, int32_t n_listed,
+                                               float *out4, float *lap, void *stream) {
+    if (!site_order || n_listed < 0) return fail(SCASML_ERR_ARG, "gp_eval_compat_site_list: null or negative site list");
+    if (rows_per_site < 32 || (rows_per_site & 31)) return fail(SCASML_ERR_ARG, "gp_eval_compat_site_list: rows_per_site must be a positive multiple of 32");
+    if (n_inf % rows_per_site) return fail(SCASML_ERR_ARG, "gp_eval_compat_site_list: n_inf must be a whole number of sites");
+    if (n_listed > n_inf / rows_per_site) return fail(SCASML_ERR_ARG, "gp_eval_compat_site_list: %d listed sites, the buffer holds %lld", n_listed, (long long)(n_inf / rows_per_site));
+    if (n_listed == 0) return 0;
+    return eval_compat_sites(d, a, sigma_eq, mu_eq, eq_id, model, n_dom, n_bdy, idx_h, round16, x_bound, points, n_inf, rows_per_site, site_kinds, site_order,
+                             n_listed, out4, lap, stream);
+}
+
+static int eval_compat_sites(int32_t d, float a, float sigma_eq, float mu_eq, int32_t eq_id, const float *model, int32_t n_dom,
+                             int32_t n_bdy, const int32_t *idx_h, int32_t round16, float x_bound, const float *points, int64_t n_inf,
+                             int64_t rows_per_site, const uint8_t *site_kinds, const int32_t *site_order, int32_t n_listed, float *out4, float *lap,
+                             void *stream) {
     if (n_inf == 0) return 0;
     if (!model || !points || !out4 || n_inf < 0) return fail(SCASML_ERR_ARG, "gp_eval_compat_sites: bad argument");
     if (d < kHutch || d > SCASML_MAX_DIM || n_dom < 1 || n_bdy < 0) return fail(SCASML_ERR_ARG, "gp_eval_compat_sites: bad sizes");
@@ -753,6 +803,8 @@ extern "C" int scasml_gp_eval_compat_sites(int32_t d, float a, float sigma_eq, f
     g.round_out = (round16 & 2) ? 1 : 0;
     g.site_kinds = site_kinds;
     g.rows_per_site = rows_per_site;
+    g.site_order = site_order;
+    g.n_listed = n_listed;
     hipStream_t s = (hipStream_t)stream;
     if (round16 & 1) {
         if (round16 & 4) return fail(SCASML_ERR_ARG, "gp_eval_compat_sites: round16 bit 2 (one point plane) is the geometry mode's option, not the as-coded form's");

@@ -210,9 +210,12 @@ struct Walker {
         const float4 *base = reinterpret_cast<const float4 *>(a.points + (int64_t)site * a.Bs * a.kp);
         return base[row_off4];
     }
+    __device__ __forceinline__ bool mine_at(int un) const {   // wave-uniform: scalar load
+        return a.owner ? (int)a.owner[un] == a.rank : (un % a.world) == a.rank;
+    }
     __device__ __forceinline__ bool owned(bool top) {
         if (!top || a.world == 1) return true;
-        const bool mine = a.owner ? (int)a.owner[unit] == a.rank : (unit % a.world) == a.rank;   // wave-uniform: scalar load
+        const bool mine = mine_at(unit);
         ++unit;
         return mine;
     }
@@ -256,7 +259,26 @@ struct Walker {
             // compat_crn: the children of every node k draw their terminal normals where the k = 0 children do
             // (MLP.py:167-168,178: one fixed key per uz_solve call, so calls of equal shape share their draws)
             const uint32_t c_plus = cbase + o + 1u, c_minus = c_plus + s_l;
+            // sample sharding, quadrature paths: the draws of nodes other ranks own are replayed only up to the LAST node of this path that
+            // this rank owns an addend of (every rank used to walk every path to its end: 35 steps per root at n = rho = 3, 5 % of a whole
+            // step's draws on each of 8 ranks)
+            int klast = q - 1;
+            if constexpr (TOP && VAR == 0 && MODE != SCASML_MODE_ACCUMULATE) {
+                if (a.world > 1) {
+                    constexpr int per = L > 0 ? 2 : 1;
+                    klast = -1;
+                    for (int k = 0; k < q; ++k)
+                        if (mine_at(unit + k * per) || (L > 0 && mine_at(unit + k * per + 1))) klast = k;
+                }
+            }
             for (int k = 0; k < q; ++k) {
+                if constexpr (TOP && VAR == 0 && MODE != SCASML_MODE_ACCUMULATE) {
+                    if (k > klast) {                             // nothing of this rank's further along the path
+                        o += (uint32_t)(q - k) * (1u + s_l + s_lm);
+                        unit += (q - k) * (L > 0 ? 2 : 1);
+                        break;
+                    }
+                }
                 const uint32_t site = base + o;
                 o += 1;
                 // Monte-Carlo sample sharding: the units dealt to ranks are the two ADDENDS a node (l, m, k) of the root call contributes to the root's

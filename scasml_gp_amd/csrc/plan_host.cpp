@@ -52,56 +52,114 @@ static void site_kinds_rec(const scasml_plan *p, int n, uint8_t *&out) {
     }
 }
 
-// cost of the subtree of a level-n call, in the units of scasml_plan_deal_units (Euler-Maruyama site 1, terminal site 0.6)
-static double subtree_cost(const scasml_plan *p, int n) {
+// What a site costs, relative to an Euler-Maruyama site of a level-0 term whose surrogate values are all consumed (kind 0): {kind 0, kind 4
+// (u_hat and div only), kind 3 (terminal: u_hat only), one replayed path step (quadrature paths: the draws of a node another rank owns)}.
+// Defaults: the figures of ABI <= 6 (any Euler-Maruyama site 1, terminal site 0.6, replay free).  Measured at the headline shape with the as-coded
+// surrogate (profiles/r06_sample_sharding_rank_times.txt): GP evaluation 37.1 / 21.8 / 17.0 us per site of 16384 roots + 3.4 us of GENERATE and
+// ACCUMULATE per site -> {1, 0.62, 0.50, 0.04}; the host passes the weights of the surrogate in use (solvers/_picard.py site_cost).
+struct SiteCost {
+    double full, udiv, term, replay;
+};
+static SiteCost site_cost_of(const double *w) {
+    SiteCost c{1.0, 1.0, 0.6, 0.0};
+    if (w) c = SiteCost{w[0], w[1], w[2], w[3]};
+    return c;
+}
+
+// cost of the subtree of a level-n call (below the root call every site has one owner: no replay, no shared node points)
+static double subtree_cost(const scasml_plan *p, int n, const SiteCost &w) {
     if (n == 0) return 0.0;
-    double c = 0.6 * p->mg[n];
+    double c = w.term * p->mg[n];
     for (int l = 0; l < n; ++l) {
         const scasml_term &t = p->term[n][l];
-        c += (double)t.mc * t.q * (1.0 + subtree_cost(p, l) + (l > 0 ? subtree_cost(p, l - 1) : 0.0));
+        c += (double)t.mc * t.q * ((l > 0 ? w.udiv : w.full) + subtree_cost(p, l, w) + (l > 0 ? subtree_cost(p, l - 1, w) : 0.0));
     }
     return c;
 }
 
-extern "C" int32_t scasml_plan_deal_units(const scasml_plan *plan_h, int32_t world, uint8_t *owner_h, int32_t capacity, double *load_h) {
+extern "C" int32_t scasml_plan_deal_units(const scasml_plan *plan_h, int32_t world, const double *site_cost_h, uint8_t *owner_h, int32_t capacity,
+                                          double *load_h) {
     if (!plan_h || !owner_h || plan_h->n < 1 || plan_h->n > SCASML_MAX_LEVEL) return fail(SCASML_ERR_ARG, "plan_deal_units: bad argument");
     if (world < 1 || world > 255) return fail(SCASML_ERR_ARG, "plan_deal_units: world must be 1..255");
+    const SiteCost w = site_cost_of(site_cost_h);
+    if (!(w.full > 0.0) || !(w.udiv > 0.0) || !(w.term > 0.0) || !(w.replay >= 0.0)) return fail(SCASML_ERR_ARG, "plan_deal_units: site costs must be positive (replay >= 0)");
     const int n = plan_h->n;
     int64_t units = plan_h->mg[n];
     // units past the terminal samples: per node (l, m, k) its "+" addend (the node and the level-l subtree) and, for l > 0, its "-" addend (the
     // level-(l-1) subtree) -- enumerated node by node, "+" first, exactly as Walker::level() asks owned()
     for (int l = 0; l < n; ++l) units += (int64_t)plan_h->term[n][l].mc * plan_h->term[n][l].q * (l > 0 ? 2 : 1);
     if (units > capacity) return fail(SCASML_ERR_ARG, "plan_deal_units: %lld units exceed the capacity %d", (long long)units, capacity);
-    // unit costs in enumeration order; the levels come in blocks of equal cost, the most expensive level last
-    std::vector<double> cost, load;
+    // unit costs in enumeration order; the levels come in blocks of equal cost, the most expensive level last.  Two costs depend on WHO gets a unit:
+    // a "-" addend on another rank than its node's "+" addend makes that rank evaluate the node's point too (scasml_plan_site_kinds keeps it for
+    // either owner), and on the quadrature paths a rank replays the draws of a path up to the LAST node it owns an addend of (Walker::level stops
+    // there; the steps of nodes it owns are in the node's cost already)
+    const bool replays = plan_h->variant == 0 && w.replay > 0.0 && world > 1;
+    int64_t paths = 0;
+    for (int l = 0; l < n; ++l) paths += plan_h->term[n][l].mc;
+    std::vector<double> cost, load, node;
+    std::vector<int32_t> path, knode, last, own;
     std::vector<char> done;
     try {
         cost.assign((size_t)units, 0.0);
+        node.assign((size_t)units, 0.0);     // > 0 on "-" addends: what the node's own point costs whoever does not hold the "+" addend already
+        path.assign((size_t)units, -1);      // sample path of the unit's node (terminal samples: none) and the node's position on it
+        knode.assign((size_t)units, 0);
         load.assign((size_t)world, 0.0);
         done.assign((size_t)units, 0);
+        last.assign((size_t)(world * paths), -1);   // per (rank, path): last node the rank owns an addend of, and how many nodes it owns
+        own.assign((size_t)(world * paths), 0);
     } catch (const std::bad_alloc &) {
         return fail(SCASML_ERR_ARG, "plan_deal_units: out of host memory for %lld units", (long long)units);
     }
     int64_t u = 0;
-    for (int m = 0; m < plan_h->mg[n]; ++m) cost[u++] = 0.6;
+    int32_t pid = 0;
+    for (int m = 0; m < plan_h->mg[n]; ++m) cost[u++] = w.term;
     for (int l = 0; l < n; ++l) {
         const scasml_term &t = plan_h->term[n][l];
-        const double cp = 1.0 + subtree_cost(plan_h, l), cm = l > 0 ? subtree_cost(plan_h, l - 1) : 0.0;
-        for (int m = 0; m < t.mc * t.q; ++m) {
-            cost[u++] = cp;
-            if (l > 0) cost[u++] = cm;
-        }
+        const double nw = l > 0 ? w.udiv : w.full;
+        const double cp = nw + subtree_cost(plan_h, l, w), cm = l > 0 ? subtree_cost(plan_h, l - 1, w) : 0.0;
+        for (int m = 0; m < t.mc; ++m, ++pid)
+            for (int k = 0; k < t.q; ++k) {
+                path[u] = pid, knode[u] = k;
+                cost[u++] = cp;
+                if (l > 0) {
+                    path[u] = pid, knode[u] = k;
+                    node[u] = nw;
+                    cost[u++] = cm;
+                }
+            }
     }
-    for (int64_t k = 0; k < units; ++k) {           // longest processing time first (ties: lower unit index, lower rank)
+    // what rank r pays on top of the unit's own cost
+    auto extra = [&](int64_t i, int r, bool commit) {
+        double e = 0.0;
+        const bool with_plus = node[i] > 0.0 && owner_h[i - 1] == r;      // a "-" addend next to its "+" partner (dealt before it: it costs more)
+        if (node[i] > 0.0 && !with_plus) e += node[i];
+        if (replays && path[i] >= 0) {
+            int32_t &la = last[(size_t)r * paths + path[i]], &ow = own[(size_t)r * paths + path[i]];
+            const int32_t la2 = knode[i] > la ? knode[i] : la, ow2 = ow + (with_plus ? 0 : 1);
+            e += w.replay * ((la2 + 1 - ow2) - (la + 1 - ow));
+            if (commit) la = la2, ow = ow2;
+        }
+        return e;
+    };
+    for (int64_t k = 0; k < units; ++k) {           // longest processing time first (ties: lower unit index)
         int64_t best = -1;
         for (int64_t i = 0; i < units; ++i)
             if (!done[i] && (best < 0 || cost[i] > cost[best])) best = i;
+        // the rank that leaves the largest load lowest; among those the one that pays least for the unit, then the one that ends lowest (a unit
+        // that costs its partner's rank nothing is not moved to a rank where it costs a second node point, however idle that rank is)
+        double top = 0.0;
+        for (int j = 0; j < world; ++j) top = load[j] > top ? load[j] : top;
         int r = 0;
-        for (int j = 1; j < world; ++j)
-            if (load[j] < load[r]) r = j;
+        double span_r = 0.0, pay_r = 0.0, end_r = 0.0;
+        for (int j = 0; j < world; ++j) {
+            const double pay = cost[best] + extra(best, j, false), e = load[j] + pay, span = e > top ? e : top;
+            const bool better = j == 0 || span < span_r || (span == span_r && (pay < pay_r || (pay == pay_r && e < end_r)));
+            if (better) r = j, span_r = span, pay_r = pay, end_r = e;
+        }
         done[best] = 1;
         owner_h[best] = (uint8_t)r;
-        load[r] += cost[best];
+        load[r] += cost[best] + extra(best, r, true);
     }
     if (load_h)
         for (int j = 0; j < world; ++j) load_h[j] = load[j];

@@ -188,9 +188,10 @@ class GP(object):
         self._eval_rows(pts, pts.shape[0], 0, None, out, x_bound=max(xb, 2.0) if xb > 0 else 0.0)
         return out
 
-    def _eval_rows(self, pts, n_rows, rows_per_site, kinds, out4, x_bound=0.0):
+    def _eval_rows(self, pts, n_rows, rows_per_site, kinds, out4, x_bound=0.0, order=None):
         """(u_hat, div u_hat, eps_PDE, dt u_hat) of the first n_rows point rows into out4: the one place the solvers and
-        predict / compute_PDE_loss reach the evaluation kernels (kinds: per-site byte of scasml_plan_site_kinds or None)."""
+        predict / compute_PDE_loss reach the evaluation kernels (kinds: per-site byte of scasml_plan_site_kinds or None; order: device int32
+        list of the sites to evaluate, in launch order -- the as-coded matrix-core kernel then launches over those sites only)."""
         lib = _lib.load()
         if self.right_vector is None:
             raise _lib.ScasmlError("GP is not trained: call GPsolver(x_domain, x_boundary) first")
@@ -198,6 +199,13 @@ class GP(object):
             a = 1.0 / float(self.sigma) ** 2
             xb = x_bound if x_bound > 0 else 2.0
             if self.compat_eval == "mfma" and self._compat_model is not None and 0.7213 * a * xb * xb * (self.d + 1) <= 3.0e4:
+                if order is not None and kinds is not None and rows_per_site % 32 == 0 and n_rows % rows_per_site == 0:
+                    _lib.check(lib.scasml_gp_eval_compat_site_list(
+                        self.d, a, float(self.equation.sigma()), float(self.equation.mu()), int(self.equation.eq_id), _lib.ptr(self._compat_model),
+                        self.N_domain, self.N_boundary, self.laplacian_idx.ctypes.data_as(C.c_void_p), int(self.eval_round16), float(x_bound), _lib.ptr(pts),
+                        n_rows, rows_per_site, _lib.ptr(kinds), _lib.ptr(order), int(order.numel()), _lib.ptr(out4), None, _lib.stream_ptr()),
+                        "gp_eval_compat_site_list")
+                    return
                 _lib.check(lib.scasml_gp_eval_compat_sites(
                     self.d, a, float(self.equation.sigma()), float(self.equation.mu()), int(self.equation.eq_id), _lib.ptr(self._compat_model),
                     self.N_domain, self.N_boundary, self.laplacian_idx.ctypes.data_as(C.c_void_p), int(self.eval_round16), float(x_bound), _lib.ptr(pts), n_rows,

@@ -92,7 +92,7 @@ class PicardEngine:
         key = (n, par, world)
         if key not in self._owners:
             torch = _lib.require_gpu()
-            host, load = deal_units(self.plan(n, par), world)
+            host, load = deal_units(self.plan(n, par), world, site_cost(self.gp))
             self._owners[key] = (host, torch.from_numpy(host).cuda(), load)
         return self._owners[key]
 
@@ -108,6 +108,19 @@ class PicardEngine:
             owner = self.unit_owners(n, par, world)[0].ctypes.data_as(C.c_void_p) if world > 1 and n > 0 else None
             _lib.check(_lib.load().scasml_plan_site_kinds(C.byref(plan), rank, world, owner, host.ctypes.data_as(C.c_void_p)), "plan_site_kinds")
             self._kinds[key] = torch.from_numpy(host).cuda()
+        return self._kinds[key]
+
+    def site_order(self, n, par, rank=0, world=1):
+        """Device int32 list of the sites this rank evaluates (kind != 2), by falling cost of their evaluation -- kind 0 (everything consumed),
+        4 (u_hat and div), then 3 and 1 (u_hat) -- and by site index within a kind: the launch order of scasml_gp_eval_compat_site_list."""
+        key = ("order", n, par, rank, world)
+        if key not in self._kinds:
+            torch = _lib.require_gpu()
+            k = self.site_kinds(n, par, rank, world).cpu().numpy()
+            rank_of = np.array([0, 2, 9, 2, 1], dtype=np.int64)          # kind -> position in the launch order
+            mine = np.nonzero(k != 2)[0]
+            order = mine[np.argsort(rank_of[k[mine]], kind="stable")].astype(np.int32)
+            self._kinds[key] = torch.from_numpy(np.ascontiguousarray(order)).cuda()
         return self._kinds[key]
 
     def path_bound(self, x_max=None, plan=None):
@@ -178,6 +191,7 @@ class PicardEngine:
         pts, vals = self._buffers(stride * ppr, kp)   # rows of un-owned units and padding rows are never written: their (finite,
         # stale) content is evaluated or skipped by the GP kernel and never read back by ACCUMULATE
         kinds = self.site_kinds(n, par, rank, world) if n > 0 else None
+        order = self.site_order(n, par, rank, world) if n > 0 else None
         # roots outside the training cube widen the bound instead of silently breaking it (host arrays: measured before the upload;
         # device tensors: one reduction per tensor version, not per solve)
         x_bound = self.path_bound(self._root_bound(x, x_max, x is x_t) if B else None, plan)
@@ -190,7 +204,7 @@ class PicardEngine:
                 _lib.check(self._timed("picard_generate", lambda: lib.scasml_picard_tree(
                     C.byref(prob), C.byref(plan), _lib.MODE_GENERATE, _lib.ptr(xc), nb, stride, rng_c,
                     _lib.ptr(pts), None, None, None, s)), "picard_tree(generate)")
-                self._timed("gp_eval", lambda: self.gp._eval_rows(pts, stride * ppr, stride, kinds, vals, x_bound=x_bound))
+                self._timed("gp_eval", lambda: self.gp._eval_rows(pts, stride * ppr, stride, kinds, vals, x_bound=x_bound, order=order))
                 _lib.check(self._timed("picard_accumulate", lambda: lib.scasml_picard_tree(
                     C.byref(prob), C.byref(plan), _lib.MODE_ACCUMULATE, _lib.ptr(xc), nb, stride, rng_c,
                     _lib.ptr(pts), _lib.ptr(vals), _lib.ptr(ob), _lib.ptr(ub), s)), "picard_tree(accumulate)")
@@ -259,14 +273,37 @@ class PicardEngine:
         return tables.reference_evaluation_count(self.variant, n, par, self.gp is not None, float(self.equation.T))
 
 
-def deal_units(plan, world):
-    """Host side of scasml_plan_deal_units: (owner uint8 per unit, load per rank)."""
+# What a tree site costs a rank, relative to an Euler-Maruyama site of a level-0 term (all of the surrogate's outputs consumed): {that site,
+# a level l > 0 site (u_hat and div u_hat only), a terminal site (u_hat only), one replayed path step} -- scasml_plan_deal_units' site_cost_h.
+# Measured at the headline shape on one MI355X (profiles/r06_sample_sharding_rank_times.txt): the evaluation kernel alone with every site declared of
+# one kind, plus 3.4 us of GENERATE + ACCUMULATE per site of 16384 roots.  No surrogate: every site is one path step.
+SITE_COST = {"reference": (1.0, 0.62, 0.50, 0.04),            # gp_eval_compat_mfma (as coded): 37.1 / 21.8 / 17.0 us per site
+             "reference-geometry": (1.0, 0.62, 0.50, 0.06),   # the same geometries per kind, cheaper epilogues
+             "documented": (1.0, 0.75, 0.50, 0.10),           # gp_eval_bf16: one geometry, the epilogue shrinks with what is consumed
+             None: (1.0, 1.0, 1.0, 0.5)}
+
+
+def site_cost(gp):
+    if gp is None:
+        return SITE_COST[None]
+    if gp.compat == "reference":
+        return SITE_COST["reference-geometry" if getattr(gp, "eval_geometry", False) else "reference"]
+    return SITE_COST["documented"]
+
+
+def deal_units(plan, world, cost=None):
+    """Host side of scasml_plan_deal_units: (owner uint8 per unit, load per rank); cost: the four relative site costs (site_cost) or None for
+    the ABI's defaults."""
     lib = _lib.load()
     n = plan.n
     units = int(plan.mg[n]) + sum(int(plan.term[n][l].mc) * int(plan.term[n][l].q) * (2 if l else 1) for l in range(n))   # terminal samples + the addends of the nodes
     owner = np.zeros(max(units, 1), dtype=np.uint8)
     load = np.zeros(world, dtype=np.float64)
-    got = lib.scasml_plan_deal_units(C.byref(plan), world, owner.ctypes.data_as(C.c_void_p), units, load.ctypes.data_as(C.c_void_p))
+    w = np.ascontiguousarray(cost, dtype=np.float64) if cost is not None else None
+    if w is not None and w.shape != (4,):
+        raise ValueError("site costs: four numbers (level-0 site, level l > 0 site, terminal site, replayed step)")
+    got = lib.scasml_plan_deal_units(C.byref(plan), world, w.ctypes.data_as(C.c_void_p) if w is not None else None,
+                                     owner.ctypes.data_as(C.c_void_p), units, load.ctypes.data_as(C.c_void_p))
     if got != units:
         raise _lib.ScasmlError("plan_deal_units failed (%d): %s" % (got, lib.scasml_last_error().decode()))
     return owner[:units].copy(), load

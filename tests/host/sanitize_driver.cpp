@@ -76,16 +76,19 @@ int main() {
             for (int world : {1, 2, 3, 8, 255}) {
                 std::vector<uint8_t> owner((size_t)units);
                 std::vector<double> load((size_t)world);
-                CHECK(scasml_plan_deal_units(&p, world, owner.data(), units, load.data()) == units);
+                {
+                    const double measured[4] = {1.0, 0.62, 0.50, 0.04};      // the as-coded surrogate's site costs (replay charged on the quadrature paths)
+                    CHECK(scasml_plan_deal_units(&p, world, (world & 1) ? measured : nullptr, owner.data(), units, load.data()) == units);
+                }
                 for (uint8_t o : owner) CHECK(o < world);
-                CHECK(scasml_plan_deal_units(&p, world, owner.data(), units - 1, load.data()) == SCASML_ERR_ARG);   // capacity one short: refused
+                CHECK(scasml_plan_deal_units(&p, world, nullptr, owner.data(), units - 1, load.data()) == SCASML_ERR_ARG);   // capacity one short: refused
                 for (int rank = 0; rank < world && rank < 4; ++rank) {
                     CHECK(scasml_plan_site_kinds(&p, rank, world, owner.data(), kinds.data()) == 0);
                     CHECK(scasml_plan_site_kinds(&p, rank, world, nullptr, kinds.data()) == 0);
                 }
             }
-            CHECK(scasml_plan_deal_units(&p, 0, kinds.data(), units, nullptr) == SCASML_ERR_ARG);
-            CHECK(scasml_plan_deal_units(&p, 256, kinds.data(), units, nullptr) == SCASML_ERR_ARG);
+            CHECK(scasml_plan_deal_units(&p, 0, nullptr, kinds.data(), units, nullptr) == SCASML_ERR_ARG);
+            CHECK(scasml_plan_deal_units(&p, 256, nullptr, kinds.data(), units, nullptr) == SCASML_ERR_ARG);
             CHECK(scasml_plan_site_kinds(&p, 2, 2, nullptr, kinds.data()) == SCASML_ERR_ARG);
         }
     // an inconsistent plan (sites that do not match the terms) is refused before anything past the buffer is written
@@ -98,7 +101,7 @@ int main() {
         p.n = SCASML_MAX_LEVEL + 1;
         CHECK(scasml_points_per_root(&p) == -1);
         CHECK(scasml_plan_site_kinds(&p, 0, 1, nullptr, kinds.data()) == SCASML_ERR_ARG);
-        CHECK(scasml_plan_deal_units(nullptr, 1, kinds.data(), 1, nullptr) == SCASML_ERR_ARG);
+        CHECK(scasml_plan_deal_units(nullptr, 1, nullptr, kinds.data(), 1, nullptr) == SCASML_ERR_ARG);
     }
     CHECK(strlen(scasml_last_error()) > 0);
     printf("host sanitizer driver ok\n");

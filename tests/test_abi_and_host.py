@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_struct_layouts_and_version(lib):
-    assert lib.scasml_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.scasml_abi_version() == _lib.ABI_VERSION == 7
     for which, st in enumerate((_lib.Problem, _lib.Rng, _lib.Term, _lib.Plan, _lib.GpModel)):
         assert lib.scasml_sizeof(which) == C.sizeof(st)
     assert C.sizeof(_lib.Plan) < 3900          # travels by value in the kernarg segment (4 KiB)
@@ -199,22 +199,31 @@ def test_site_kinds_partition_the_tree_under_sample_sharding(lib, variant, n, pa
 
 
 def test_units_are_dealt_by_cost(lib):
-    """scasml_plan_deal_units: every unit gets an owner, the loads add up to the tree's cost, and longest-first dealing
-    beats round-robin where the units are unequal.  The figures quoted in DESIGN.md section 6."""
-    from scasml_gp_amd.solvers._picard import deal_units
+    """scasml_plan_deal_units: every unit gets an owner, the loads add up to the tree's cost plus what sharding adds (a node point evaluated by
+    the two owners of its addends, replayed path steps), and longest-first dealing balances unequal units.  The figures quoted in DESIGN.md section 6."""
+    from scasml_gp_amd.solvers._picard import deal_units, SITE_COST
     from scasml_gp_amd.parallel import sample_units
 
     quad = tables.build_plan("quad", 3, 3, 0.5, False)
+    whole = deal_units(quad, 1)[1]
+    # default costs (ABI <= 6) = Euler-Maruyama sites + 0.6 x terminal sites: 665 sites at n = rho = 3, 234 of them terminal
+    assert abs(whole.sum() - (665 - 234 + 0.6 * 234)) < 1e-9
     owner, load = deal_units(quad, 2)
     # units: 27 terminal samples + the addends of the NODES of the sample paths: 5 x 4 nodes at level 0 (one addend each), 3 x 3 at level 1
     # and 2 x 3 at level 2 (a "+" and a "-" addend each: the level-l and the level-(l-1) subtree)
     assert len(owner) == sample_units(quad) == 27 + 20 + 2 * 9 + 2 * 6 == 77 and set(owner) == {0, 1}
-    # cost = Euler-Maruyama sites + 0.6 x terminal sites: 665 sites at n = rho = 3, 234 of them terminal
-    assert abs(load.sum() - (665 - 234 + 0.6 * 234)) < 1e-9
-    assert load.max() / load.mean() < 1.01
-    for world in (3, 4, 6, 8):                       # the largest addend is 58 sites of 665: eight ranks balance to 1 % (whole paths as units: 3.19)
-        lw = deal_units(quad, world)[1]
-        assert lw.max() / lw.mean() < 1.01, (world, lw)
+    assert 0 <= load.sum() - whole.sum() <= 15 + 1e-9 and load.max() / load.mean() < 1.01     # at most the 15 nodes with two addends are evaluated twice
+    for cost in (None, SITE_COST["reference"], SITE_COST["documented"], SITE_COST[None]):
+        w1 = deal_units(quad, 1, cost)[1].sum()
+        for world in (2, 3, 4, 6, 8):                # the largest addend is 79 sites of 665: eight ranks balance to 1 % (whole paths as units: 3.19)
+            ow, lw = deal_units(quad, world, cost)
+            assert lw.max() / lw.mean() < (1.012 if cost is not SITE_COST[None] else 1.03) and lw.sum() < 1.05 * w1, (cost, world, lw)   # (replay is charged after the dealing)
+            # the zero-cost "-" addends of the nine level-1 nodes (their subtree is uz(0) = 0) stay with the node's "+" addend: no second evaluation
+            first = 27 + 20
+            assert all(ow[first + 2 * i] == ow[first + 2 * i + 1] for i in range(9))
+    # the measured weights of the as-coded surrogate: a level l > 0 site costs 0.62, a terminal site 0.50 of a level-0 site; replay 0.04 per step
+    o8, l8 = deal_units(quad, 8, SITE_COST["reference"])
+    assert abs(deal_units(quad, 1, SITE_COST["reference"])[1][0] - (380 + 0.62 * 51 + 0.50 * 234)) < 1e-9 and l8.max() / l8.mean() < 1.006
     small = tables.build_plan("quad", 2, 2, 0.5, False)
     assert len(deal_units(small, 2)[0]) == 16 and deal_units(small, 2)[1].max() / deal_units(small, 2)[1].mean() < 1.05
     fh = tables.build_plan("fh", 4, 3, 0.5, False)
@@ -222,11 +231,44 @@ def test_units_are_dealt_by_cost(lib):
     assert len(o4) == 81 + 81 + 2 * (27 + 9 + 3) == 240 and l4.max() / l4.mean() < 1.01
     o8, l8 = deal_units(fh, 8)
     assert 1.15 < l8.max() / l8.mean() < 1.25        # three level-3 "+" addends of 15 % of the tree each over eight ranks (whole samples: 1.43)
+    l1 = deal_units(fh, 1)[1]
     for world in (1, 2, 3, 8, 255):
         o, l = deal_units(fh, world)
-        assert o.max() < world and abs(l.sum() - l4.sum()) < 1e-9
-    assert lib.scasml_plan_deal_units(C.byref(fh), 256, o.ctypes.data_as(C.c_void_p), 240, None) == -1
-    assert lib.scasml_plan_deal_units(C.byref(fh), 2, o.ctypes.data_as(C.c_void_p), 10, None) == -1
+        assert o.max() < world and 0 <= l.sum() - l1.sum() <= 39 + 1e-9      # full history draws a node directly: nothing replayed
+    bad = np.array([1.0, 0.0, 0.5, 0.0])
+    assert lib.scasml_plan_deal_units(C.byref(fh), 2, bad.ctypes.data_as(C.c_void_p), o.ctypes.data_as(C.c_void_p), 240, None) == -1
+    assert lib.scasml_plan_deal_units(C.byref(fh), 256, None, o.ctypes.data_as(C.c_void_p), 240, None) == -1
+    assert lib.scasml_plan_deal_units(C.byref(fh), 2, None, o.ctypes.data_as(C.c_void_p), 10, None) == -1
+
+
+def test_bench_chooses_the_sample_ranks_by_predicted_efficiency():
+    """bench.py's north-star leg: the number of sample ranks is the largest divisor of the rank count whose PREDICTED strong-scaling efficiency --
+    the slowest rank's share of the measured unsharded step plus a fixed cost plus the stated all-reduce cost -- reaches the minimum
+    (VERDICT r5 item 1b).  Host logic only: the dealing and the arithmetic of the table."""
+    import types
+    import bench
+    from scasml_gp_amd.solvers._picard import deal_units, SITE_COST
+    args = types.SimpleNamespace(allreduce_busbw_gbs=100.0, allreduce_latency_us=40.0, min_sample_efficiency=0.9)
+    gp = types.SimpleNamespace(compat="reference", eval_geometry=False)
+    quad = tables.build_plan("quad", 3, 3, 0.5, False)
+    eng = types.SimpleNamespace(plan=lambda n, par: quad, gp=gp)
+    table = bench.sample_split_table(eng, 3, 3, 8, 21.7, 1 << 14, 100, args)
+    assert [r["sample_ranks"] for r in table] == [1, 2, 4, 8] and [r["root_groups"] for r in table] == [8, 4, 2, 1]
+    assert table[0]["predicted_efficiency"] == 1.0 and table[0]["allreduce_ms_stated"] == 0.0
+    # 8 sample ranks: 6.6 MB over 8 ranks at the stated 100 GB/s + 40 us = 0.156 ms; the slowest rank's share of 21.7 ms by the dealt load
+    l8, w1 = deal_units(quad, 8, SITE_COST["reference"])[1], deal_units(quad, 1, SITE_COST["reference"])[1][0]
+    assert abs(table[3]["allreduce_ms_stated"] - (0.040 + 1.75 * (1 << 14) * 101 * 4 / 100e9 * 1e3)) < 1e-3
+    assert abs(table[3]["modelled_rank_ms"] - (21.7 * l8.max() / w1 + bench.SAMPLE_RANK_FIXED_MS)) < 1e-3
+    assert abs(table[3]["predicted_efficiency"] - 21.7 / (8 * (table[3]["modelled_rank_ms"] + table[3]["allreduce_ms_stated"]))) < 1e-3
+    assert all(table[i]["predicted_efficiency"] >= table[i + 1]["predicted_efficiency"] for i in range(3))      # every further split costs
+    assert 0.85 < table[3]["predicted_efficiency"] < 0.95 and table[2]["predicted_efficiency"] > 0.9
+    # full history n = 4 on eight ranks: three addends hold 15 % of the tree each -- eight sample ranks are predicted below 0.8, four above 0.9
+    fh = tables.build_plan("fh", 4, 3, 0.5, False)
+    tfh = bench.sample_split_table(types.SimpleNamespace(plan=lambda n, par: fh, gp=gp), 4, 3, 8, 53.5, 1 << 14, 100, args)
+    assert tfh[3]["predicted_efficiency"] < 0.8 < 0.9 < tfh[2]["predicted_efficiency"]
+    # a step that is all fixed cost (96 roots): nothing beyond the roots split is predicted to pay
+    tiny = bench.sample_split_table(eng, 3, 3, 4, 0.12, 96, 100, args)
+    assert max(r["sample_ranks"] for r in tiny if r["predicted_efficiency"] >= 0.9) == 1
 
 
 @pytest.fixture(scope="module")

@@ -146,6 +146,54 @@ def test_what_a_site_consumes_does_not_depend_on_the_form_its_workgroup_ran():
             assert np.array_equal(part32[sl, 1], full32[sl, 1])
 
 
+@pytest.mark.parametrize("rows,round16", [(32, 3), (96, 3), (128, 3), (160, 6)])
+def test_a_site_list_gives_every_listed_row_the_same_bits_in_any_order(rows, round16):
+    """scasml_gp_eval_compat_site_list (ABI 7): the grid covers the listed sites only, in the list's order.  A listed row gets what
+    scasml_gp_eval_compat_sites gives it -- bit for bit in the as-coded mode, whatever the order and whichever sites share its workgroup (96-
+    and 160-row sites: workgroups straddle sites that are neighbours in the LIST, not in the buffer) -- rows of sites not listed stay untouched,
+    and malformed lists are refused before a launch."""
+    import torch
+    from scasml_gp_amd import _lib
+    d, idx, nd, nb = 20, [11, 17, 12, 6, 4], 100, 33
+    gp, _, _ = _setup(d, idx, nd, nb, seed=6)
+    kinds = [0, 1, 3, 4, 0, 4, 1, 2, 3, 0, 4]
+    X = _test_points(d, rows * len(kinds), seed=10)
+    base, _ = _raw(gp, X, round16=round16, kinds=kinds, rows_per_site=rows)
+    lib = _lib.load()
+    pts = gp._points_device(X)[0]
+    kd = torch.from_numpy(np.asarray(kinds, dtype=np.uint8)).cuda()
+
+    def run(order, n_inf=None, rps=rows, n_listed=None):
+        out4 = torch.full((pts.shape[0], 4), -7.0, dtype=torch.float32, device="cuda")
+        od = torch.from_numpy(np.asarray(order, dtype=np.int32)).cuda()
+        rc = lib.scasml_gp_eval_compat_site_list(
+            gp.d, 1.0 / float(gp.sigma) ** 2, float(gp.equation.sigma()), float(gp.equation.mu()), int(gp.equation.eq_id), _lib.ptr(gp._compat_model),
+            gp.N_domain, gp.N_boundary, gp.laplacian_idx.ctypes.data_as(C.c_void_p), round16, 0.0, _lib.ptr(pts), pts.shape[0] if n_inf is None else n_inf, rps,
+            _lib.ptr(kd), _lib.ptr(od), len(order) if n_listed is None else n_listed, _lib.ptr(out4), None, _lib.stream_ptr())
+        return rc, out4.cpu().numpy().astype(np.float64)
+
+    mine = [s for s, k in enumerate(kinds) if k != 2]
+    by_cost = sorted(mine, key=lambda s: {0: 0, 4: 1, 3: 2, 1: 2}[kinds[s]])           # the engine's launch order
+    for order in (mine, by_cost, mine[::-1], [9, 2], [5]):
+        rc, got = run(order)
+        assert rc == 0
+        for s, k in enumerate(kinds):
+            sl = slice(s * rows, (s + 1) * rows)
+            if s not in order:
+                assert (got[sl] == -7.0).all(), (order, s)                             # not listed: not written
+                continue
+            if round16 & 1:
+                assert np.array_equal(got[sl, 0], base[sl, 0]), (order, s, k)          # u_hat: every form
+                if k in (0, 4):
+                    assert np.array_equal(got[sl, 1], base[sl, 1]), (order, s, k)
+                if k == 0:
+                    assert np.array_equal(got[sl], base[sl]), (order, s)
+            else:                                                                      # geometry mode: the forms order their sums differently
+                assert np.allclose(got[sl, 0], base[sl, 0], rtol=0, atol=2e-5), (order, s, k)
+    assert run(mine, n_listed=0)[0] == 0 and (run(mine, n_listed=0)[1] == -7.0).all()      # an empty list: nothing launched
+    assert run(mine, rps=rows + 1)[0] == -1 and run(mine, n_inf=pts.shape[0] - 16)[0] == -1 and run(mine, n_listed=len(kinds) + 1)[0] == -1
+
+
 @pytest.mark.parametrize("d,idx,nd,nb", CASES)
 def test_geometry_mode_factored_sums_in_every_site_form(d, idx, nd, nb):
     """compat="reference-geometry" (round16 bit 0 off): the factored epilogue, per site form.  Every form's outputs against the float64
