@@ -723,6 +723,23 @@ def path_roofline(wl, kernel_ms):
     return roof
 
 
+def xl_solver_roofline(flops, gp_ms):
+    """The evaluation kernel of configs[4]'s solver half (gp_eval_compat_mfma_kernel<16, 2, true, 2>: 16 K-steps, 625 collocation tiles, a 34.6 MB model):
+    achieved from this run's HIP events; traffic and the vector + matrix sum model from the PMC passes of tools/xl_solver_counters.sh, quoted only
+    for the same kernel source."""
+    ach = flops / (gp_ms * 1e-3) / 1e12
+    roof = {"kernel": "gp_eval_compat_mfma_kernel<16, 2, true, 2>", "bound": "valu+mfma (sum model)", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "flops_per_launch": flops, "avg_launch_ms": round(gp_ms, 3), "traffic": None}
+    path = os.path.join(ROOT, "profiles", "r06_gp_eval_pmc_d250.json")
+    if os.path.exists(path):
+        pj = json.load(open(path))
+        if pj.get("source_sha1") == kernel_source_sha1(GP_EVAL_SOURCES["reference"]):
+            roof.update({"traffic": pj["hbm_bytes_per_launch"], "l2_hit_rate": round(pj["l2_hit_rate"], 3), "sum_model": pj["sum_model"],
+                         "mfma_pipe_busy_frac": round(pj["mfma_pipe_busy_frac"], 3), "valu_active_frac": round(pj["valu_active_frac"], 3),
+                         "traffic_source": "profiles/r06_gp_eval_pmc_d250.json (separate rocprofv3 --pmc passes on this kernel source; FETCH_SIZE doubled, Infinity-Cache hits counted)"})
+    return roof
+
+
 def gp_train_block(d, n_dom, n_bdy, compat=None, reps=2, keep=None):
     """GP training stages (models/GP.py:182-268, 487-604) with their rooflines: Gram, Cholesky (M^3/3 flop), K_p^-1 from the
     factor (2 M^3 / 3), the Newton iteration; HIP events per stage.  The first of two passes warms code objects and the allocator."""
@@ -784,6 +801,7 @@ def gp_train_blocks(args, gp, ranks, others):
                            "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
                            "gp_eval_algorithmic_tflops": round(flops / (kms["gp_eval"] * 1e-3) / 1e12, 1),
                            "gp_eval_frac_of_fp16_mfma_peak": round(flops / (kms["gp_eval"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                           "roofline": xl_solver_roofline(flops, kms["gp_eval"]),
                            "note": "16 K-steps of 16 per x.y product (d = 250) and 20 000 collocation rows per point: 1.36e10 (point, row) pairs per step, "
                                    "as many as the headline's"})
     return blocks

@@ -28,10 +28,19 @@ class OracleGP:
     # ---------------------------------------------------------------- pair geometry
     def _pairs(self, X, Y):
         X = np.asarray(X, dtype=np.float64)
+        Y0 = Y
         Y = np.asarray(Y, dtype=np.float64)
-        diff2 = (X * X).sum(1)[:, None] + (Y * Y).sum(1)[None, :] - 2.0 * X @ Y.T
-        rt = X[:, -1][:, None] - Y[:, -1][None, :]
-        S = X[:, :-1].sum(1)[:, None] - Y[:, :-1].sum(1)[None, :]
+        # the collocation side (row norms, coordinate sums) is kept per array: same numbers, computed once (a solver calls this point by point)
+        cache = self.__dict__.setdefault("_pcache", {})
+        hit = cache.get(id(Y0))
+        if hit is None or hit[0] is not Y0:
+            if len(cache) > 8:
+                cache.clear()
+            hit = cache[id(Y0)] = (Y0, Y, (Y * Y).sum(1), Y[:, :-1].sum(1), np.ascontiguousarray(Y[:, -1]))
+        _, Y, y2, ys, yt = hit
+        diff2 = (X * X).sum(1)[:, None] + y2[None, :] - 2.0 * X @ Y.T
+        rt = X[:, -1][:, None] - yt[None, :]
+        S = X[:, :-1].sum(1)[:, None] - ys[None, :]
         rho2 = diff2 - rt * rt
         kap = np.exp(-self.a * diff2 / 2.0)                 # models/GP.py:41-43
         return kap, rho2, S, rt

@@ -100,19 +100,31 @@ class OracleGPCompat(OracleGP):
     def _geom(self, X, Y, which):
         """kappa, S, r_D and the (n, m, 5) Hutchinson components of r in geometry ``which``."""
         X = np.asarray(X, dtype=np.float64)
+        Y0 = Y
         Y = np.asarray(Y, dtype=np.float64)
         d = self.d
+        cols = self.idx if which != "al" else self.idx + 1          # aligned: shifted index i = coordinate i+1
         if which == "xs":
             X = shift(X)
-        elif which == "ys":
-            Y = shift(Y)
-        diff2 = (X * X).sum(1)[:, None] + (Y * Y).sum(1)[None, :] - 2.0 * X @ Y.T
+        # the collocation side of a pair geometry does not change between calls (a solver evaluates the surrogate point by point): its shifted
+        # copy, row norms, coordinate sums and Hutchinson columns are kept per (array, geometry) -- same numbers, computed once
+        key = (id(Y0), which)
+        hit = self._ycache.get(key) if hasattr(self, "_ycache") else None
+        if hit is None or hit[0] is not Y0:
+            Ys = shift(Y) if which == "ys" else Y
+            hit = (Y0, Ys, (Ys * Ys).sum(1), Ys[:, :d].sum(1), np.ascontiguousarray(Ys[:, d]), np.ascontiguousarray(Ys[:, cols]))
+            if not hasattr(self, "_ycache"):
+                self._ycache = {}
+            if len(self._ycache) > 8:
+                self._ycache.clear()
+            self._ycache[key] = hit
+        _, Y, y2, ys, yD, ycols = hit
+        diff2 = (X * X).sum(1)[:, None] + y2[None, :] - 2.0 * X @ Y.T
         diff2 = np.maximum(diff2, 0.0)
         kap = np.exp(-self.a * diff2 / 2.0)
-        S = X[:, :d].sum(1)[:, None] - Y[:, :d].sum(1)[None, :]
-        rD = X[:, d][:, None] - Y[:, d][None, :]
-        cols = self.idx if which != "al" else self.idx + 1          # aligned: shifted index i = coordinate i+1
-        ri = X[:, cols][:, None, :] - Y[:, cols][None, :, :]
+        S = X[:, :d].sum(1)[:, None] - ys[None, :]
+        rD = X[:, d][:, None] - yD[None, :]
+        ri = X[:, cols][:, None, :] - ycols[None, :, :]
         return kap, S, rD, ri
 
     # ---------------------------------------------------------------- float16 op sequence of kappa and its first derivatives

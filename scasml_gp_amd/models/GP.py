@@ -515,6 +515,122 @@ class GP(object):
     def compute_PDE_loss(self, x_t_infer):
         raise NotImplementedError
 
+    # ------------------------------------------------------------------ the cross-kernel builders of the reference's class surface
+    # (models/GP.py:41-179, 271-411, 630-651).  The hot path never materialises these matrices -- predict / compute_PDE_loss contract them on the
+    # fly -- but callers of the reference's methods find them here, as host views over scasml_gp_cross_rows.  With compat="reference" the entries
+    # are float16 VALUES (returned as float16, like the reference's .astype(jnp.float16)); with compat=None float64, not rounded.
+    _OPS = {"I": 0, "lap": 1, "dt": 2, "div": 3}
+
+    def _cross(self, op, x_t_infer, x_t_domain, x_t_boundary):
+        """(N_inf, M) rows of operator `op` (or, op = 4, the (N_inf, M, d+1) gradient of the op-0 rows) against the given collocation sets."""
+        torch = _lib.require_gpu()
+        lib = _lib.load()
+        was_numpy = not isinstance(x_t_infer, torch.Tensor)
+        f16_rows = (np.asarray(x_t_infer).dtype == np.float16) if was_numpy else x_t_infer.dtype == torch.float16
+
+        def dev(x):
+            t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(x), dtype=np.float32))
+            t = t.to(device="cuda", dtype=torch.float32).contiguous().reshape(-1, self.d + 1)
+            return t
+        xi, xd = dev(x_t_infer), dev(x_t_domain)
+        xb = dev(x_t_boundary) if x_t_boundary is not None and len(x_t_boundary) else torch.zeros((0, self.d + 1), dtype=torch.float32, device="cuda")
+        nd, nb, ni = xd.shape[0], xb.shape[0], xi.shape[0]
+        if nd < 1:
+            raise ValueError("the cross-kernel builders need at least one domain point")
+        M = 4 * nd + nb
+        as_coded = self.compat == "reference"
+        r16 = 1 if as_coded else 0
+        if as_coded and self.f16_graph and f16_rows:
+            colloc = torch.cat([xd, xb])
+            if bool((colloc.half().float() == colloc).all()):          # float16 rows on float16 collocation points: the reference's float16 op sequence
+                r16 |= 4 | self._f16_extra
+        shape = (ni, M, self.d + 1) if op == 4 else (ni, M)
+        out = torch.empty(shape, dtype=torch.float64, device="cuda")
+        if ni:
+            rows_per_call = 65535 * 16
+            for lo in range(0, ni, rows_per_call):
+                n = min(rows_per_call, ni - lo)
+                _lib.check(lib.scasml_gp_cross_rows(self.d, 1.0 / float(self.sigma) ** 2, _lib.ptr(xd), nd, _lib.ptr(xb) if nb else None, nb,
+                                                    self.laplacian_idx.ctypes.data_as(C.c_void_p) if as_coded else None, r16, 0 if as_coded else 1, op,
+                                                    _lib.ptr(xi[lo:]), n, self.d + 1, _lib.ptr(out[lo:]), M, _lib.stream_ptr()), "gp_cross_rows")
+        if as_coded:
+            out = out.to(torch.float16)                               # exact: the entries are float16 values
+        return out.cpu().numpy() if was_numpy else out
+
+    def kernel_x_t_phi(self, x_t_infer, x_t_domain, x_t_boundary):
+        '''K(x_t, phi): (N_infer, 4 N_domain + N_boundary), columns [kappa(dom), kappa(bdy), lap_y kappa, dt_y kappa, div_y kappa] (models/GP.py:271-294).'''
+        return self._cross(0, x_t_infer, x_t_domain, x_t_boundary)
+
+    def dx_t_kernel_x_t_phi(self, x_t_infer, x_t_domain, x_t_boundary):
+        '''Gradient of K(x_t, phi) in x_t: (N_infer, 4 N_domain + N_boundary, n_input), time derivative last (models/GP.py:296-324).'''
+        return self._cross(4, x_t_infer, x_t_domain, x_t_boundary)
+
+    def laplacian_x_t_kernel_x_t_phi(self, x_t_infer, x_t_domain, x_t_boundary):
+        '''The Laplacian feature rows (as coded: the 5-index Hutchinson sum on the shifted argument) (models/GP.py:326-354).'''
+        return self._cross(1, x_t_infer, x_t_domain, x_t_boundary)
+
+    def dt_x_t_kernel_x_t_phi(self, x_t_infer, x_t_domain, x_t_boundary):
+        '''The time-derivative feature rows (models/GP.py:356-383).'''
+        return self._cross(2, x_t_infer, x_t_domain, x_t_boundary)
+
+    def div_x_t_kernel_x_t_phi(self, x_t_infer, x_t_domain, x_t_boundary):
+        '''The divergence feature rows (models/GP.py:385-411).'''
+        return self._cross(3, x_t_infer, x_t_domain, x_t_boundary)
+
+    def kernel_x_t_phi_single(self, x_t):
+        '''K(x_t, phi) for one point against the fitted collocation sets: (4 N_domain + N_boundary,) (models/GP.py:630-651).'''
+        if getattr(self, "x_t_domain", None) is None:
+            raise _lib.ScasmlError("no collocation points yet: call GPsolver / kernel_phi_phi / load_right_vector first")
+        torch = _lib.require_gpu()
+        row = x_t.reshape(1, -1) if isinstance(x_t, torch.Tensor) else np.asarray(x_t).reshape(1, -1)
+        return self._cross(0, row, self.x_t_domain, self.x_t_boundary)[0]
+
+    def _pair(self, opx, opy, x_t, y_t):
+        """(L^opx_x L^opy_y kappa)(x_t, y_t) for single vectors: y_t plays a one-point domain set, whose row holds all four y-operators."""
+        torch = _lib.require_gpu()
+        x = x_t.reshape(1, -1) if isinstance(x_t, torch.Tensor) else np.asarray(x_t).reshape(1, -1)
+        y = y_t.reshape(1, -1) if isinstance(y_t, torch.Tensor) else np.asarray(y_t).reshape(1, -1)
+        if opx == "grad":
+            g = self._cross(4, x, y, None)[0, 0]
+            return g
+        return self._cross(self._OPS[opx], x, y, None)[0, {"I": 0, "lap": 1, "dt": 2, "div": 3}[opy]]
+
+    def kappa(self, x_t, y_t):
+        '''K(x_t, y_t) for single vectors (models/GP.py:41-43).'''
+        return self._pair("I", "I", x_t, y_t)
+
+    def kappa_kernel(self, x_t, y_t):
+        '''(N_x, N_y) kernel matrix (models/GP.py:45-53).'''
+        return self._cross(0, x_t, y_t, None)[:, :len(y_t)]
+
+    def dx_t_kappa(self, x_t, y_t):
+        '''Gradient of kappa in x_t, (n_input,) (models/GP.py:55-57).'''
+        return self._pair("grad", None, x_t, y_t)
+
+    def dy_t_kappa(self, x_t, y_t):
+        '''Gradient of kappa in y_t = -gradient in x_t (models/GP.py:65-67).'''
+        return -self._pair("grad", None, x_t, y_t)
+
+
+def _pair_method(name, opx, opy, cite):
+    def method(self, x_t, y_t):
+        return self._pair(opx, opy, x_t, y_t)
+    method.__name__ = name
+    method.__doc__ = "(L^%s_x L^%s_y kappa)(x_t, y_t) for single vectors (models/GP.py:%s)." % (opx, opy, cite)
+    return method
+
+
+# the derivative kernels of the reference's class surface, by (operator in x, operator in y): one host view each
+for _name, _ox, _oy, _cite in (
+        ("dt_x_t_kappa", "dt", "I", "59-63"), ("dt_y_t_kappa", "I", "dt", "69-73"), ("div_x_kappa", "div", "I", "75-79"), ("div_y_kappa", "I", "div", "81-85"),
+        ("laplacian_x_t_kappa", "lap", "I", "87-95"), ("laplacian_y_t_kappa", "I", "lap", "97-105"), ("dt_x_t_dt_y_t_kappa", "dt", "dt", "107-111"),
+        ("dt_x_t_div_y_kappa", "dt", "div", "113-117"), ("dt_x_t_laplacian_y_t_kappa", "dt", "lap", "119-127"), ("div_x_dt_y_t_kappa", "div", "dt", "129-133"),
+        ("div_x_div_y_kappa", "div", "div", "135-139"), ("div_x_laplacian_y_t_kappa", "div", "lap", "141-149"),
+        ("laplacian_x_t_dt_y_t_kappa", "lap", "dt", "151-159"), ("laplacian_x_t_div_y_kappa", "lap", "div", "161-169"),
+        ("laplacian_x_t_laplacian_y_t_kappa", "lap", "lap", "171-179")):
+    setattr(GP, _name, _pair_method(_name, _ox, _oy, _cite))
+del _name, _ox, _oy, _cite
+
 
 class GP_Semilinear(GP):
     '''The surrogate for any registered equation of the family u_t + mu div u + sigma^2/2 Lap u + f(u, sum z) = 0

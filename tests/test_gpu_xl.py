@@ -238,3 +238,55 @@ def test_block_row_path_at_world_1_equals_the_single_gpu_gram_and_factor(factore
     assert float((got - want).abs().max()) <= 1e-11 * float(want.abs().max())
     del ch
     torch.cuda.empty_cache()
+
+
+def test_config4_solver_half_at_twenty_thousand_collocation_points():
+    """BASELINE configs[4] staged, its SOLVER half: ScaSML n = rho = 3 at d = 250 on the as-coded surrogate FITTED on 16 667 + 3 333
+    collocation points (M = 70 001, 19 Newton steps) -- the widest instantiation of the matrix-core evaluation kernel (16 K-steps) against 625 collocation
+    tiles (a 34 MB packed model: past an XCD's L2).  Two roots against the oracle carrying the device's right_vector, every element accounted for
+    (tests/_explained_parity.py); then 1024 roots through the size-independent properties.  Reference: solvers/ScaSML.py:149-284, models/GP.py:630-769."""
+    import torch
+    from oracle.equation import GradDependentNonlinear
+    from oracle.gp_compat import OracleGPCompat
+    from oracle.mlp import PicardOracle
+    from _explained_parity import assert_explained
+    from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
+    from scasml_gp_amd.solvers.ScaSML import ScaSML
+    torch.cuda.empty_cache()
+    eq, dom, bdy = _points()
+    gp = GP_Grad_Dependent_Nonlinear(eq)
+    gp.GPsolver(dom, bdy, GN_steps=20)
+    assert gp.phi_dim == M_XL and gp._compat_model is not None and gp.loss_history[-1] < gp.loss_history[0] and gp.grad_norms[-1] < 1e-3 * gp.grad_norms[0]
+    gp._L_pad = gp.cholesky_phi_phi_perturb = None           # the 39 GB factor is not needed past the fit
+    torch.cuda.empty_cache()
+    solver = ScaSML(eq, gp, seed=4)
+    eng = solver._engine
+    state = np.random.get_state()
+    np.random.seed(77)
+    xt = np.concatenate(eq.generate_test_data(1, 1)).astype(np.float32)
+    np.random.set_state(state)
+    got, _, _ = eng.solve(3, 3, xt, stream_id=3)
+    got = got.cpu().numpy().astype(np.float64)
+    oeq = GradDependentNonlinear(D + 1)
+    ogp = OracleGPCompat(oeq, gp.laplacian_idx, round_factor=False)
+    ogp.x_t_domain, ogp.x_t_boundary = np.asarray(dom, dtype=np.float64), np.asarray(bdy, dtype=np.float64)
+    ogp.N_domain, ogp.N_boundary, ogp.phi_dim = N_DOM, N_BDY, M_XL
+    ogp.right_vector = gp.right_vector
+    want = PicardOracle(oeq, "quad", gp=ogp, seed=4, stream=3).uz_solve(3, 3, xt)
+    again = assert_explained(eng, 3, 3, xt, 0, 3, want)
+    assert np.array_equal(again, got) and np.abs(got[:, 0] - want[:, 0]).max() < 6e-4
+    # 1024 roots (the --gp-train-xl bench leg's shape): finite, clipped at the uncertainty, deterministic, and a slice alone reproduces its rows bit for bit
+    g = np.random.default_rng(1234)
+    xb = torch.from_numpy(np.concatenate([g.uniform(-0.5, 0.5, (1024, D)), g.uniform(0.0, 0.5, (1024, 1))], axis=1).astype(np.float32)).cuda()
+    full, uhat, _ = eng.solve(3, 3, xb, stream_id=9)
+    assert full.shape == (1024, D + 1) and bool(torch.isfinite(full).all()) and bool(torch.isfinite(uhat).all())
+    assert float(full.abs().max()) <= float(eq.uncertainty) * (1 + 1e-6)
+    again_b, uhat_b, _ = eng.solve(3, 3, xb, stream_id=9)
+    assert torch.equal(again_b, full) and torch.equal(uhat_b, uhat)
+    part, uh, _ = eng.solve(3, 3, xb[500:533], root0=500, stream_id=9)
+    assert torch.equal(part, full[500:533]) and torch.equal(uh, uhat[500:533])
+    total = None
+    for r in range(4):                                         # the north-star split over four sample ranks, walked in turn
+        p, _, _ = eng.solve(3, 3, xb[:256], rank=r, world=4, stream_id=9)
+        total = p.clone() if total is None else total + p
+    assert torch.allclose(eng.finalize_partials(total), full[:256], atol=2e-5, rtol=1e-5)
