@@ -412,7 +412,11 @@ int scasml_gp_cross_rows(int32_t d, double a, const float *x_dom, int32_t n_dom,
  *                          block row tri_row0 + lb * tri_stride, column block cb is global block column tri_col0 + cb -- and the
  *                          64 x 64 tiles strictly above the block diagonal are skipped
  *   scasml_trsm_right_lt   X (rows x nb, ldx) <- X * L^-T, L lower triangular nb x nb (ldl), nb % 32 == 0: the panel solve
- *   scasml_gemv_sub        trans == 0: y (rows) -= A (rows x cols, lda) x (cols);  trans != 0: y (cols) -= A^T x (rows) */
+ *   scasml_gemv_sub        trans == 0: y (rows) -= A (rows x cols, lda) x (cols);  trans != 0: y (cols) -= A^T x (rows): one writer per column up
+ *                          to 1024 rows, beyond that 64-row groups combined with atomics (the last bits depend on their order)
+ *   scasml_gemv_t_sub_ordered   (ABI 7) y (cols) -= A^T x (rows) for any number of rows, bitwise reproducible: at most 64 row groups write their
+ *                          partial sums to `scratch` (scasml_gemv_t_ordered_scratch(rows, cols) doubles, the caller's) and one pass adds them in
+ *                          fixed order -- the K_p v sweep of the Newton-CG fit (scasml_gp_amd/dist_gp.py matvec) */
 #define SCASML_DIST_BLOCK 256
 int scasml_gp_gram_rows(int32_t d, double a, const float *x_dom, int32_t n_dom, const float *x_bdy, int32_t n_bdy,
                         int64_t row0, int32_t nrows, int64_t ncols, double *out, int64_t ld, void *stream);
@@ -424,6 +428,9 @@ int scasml_gemm_nt_sub(double *C, int64_t ldc, int64_t rows, int64_t cols, const
                        int64_t ldb, int64_t K, int64_t tri_row0, int64_t tri_stride, int64_t tri_col0, void *stream);
 int scasml_trsm_right_lt(const double *L, int64_t ldl, int64_t nb, double *X, int64_t ldx, int64_t rows, void *stream);
 int scasml_gemv_sub(const double *A, int64_t lda, int64_t rows, int64_t cols, const double *x, double *y, int trans, void *stream);
+int64_t scasml_gemv_t_ordered_scratch(int64_t rows, int64_t cols);
+int scasml_gemv_t_sub_ordered(const double *A, int64_t lda, int64_t rows, int64_t cols, const double *x, double *y, double *scratch,
+                              int64_t scratch_elems, void *stream);
 
 #ifdef __cplusplus
 }

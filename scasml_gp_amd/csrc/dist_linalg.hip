@@ -166,17 +166,56 @@ __global__ __launch_bounds__(256) void gemv_sub_kernel(const double *A, int64_t 
     if (lane == 0) y[row] -= acc;
 }
 
-// y[c] -= sum_r A[r][c] x[r]: one thread per column, rows split over blockIdx.y, partial sums combined with atomics
+// y[c] -= sum_r A[r][c] x[r]: a workgroup takes 64 columns (one per lane: a row's 512 bytes are one coalesced read) and its four waves interleaved
+// row slices, four independent accumulators each -- sixteen rows in flight per workgroup (one thread per column walking its rows alone was latency
+// bound: 0.4 ms for a 1024-row sweep, 55 of the 61 ms of a distributed solve at M = 70 001) -- combined through LDS in a FIXED association.
+// Rows beyond `rows_per_block` are split over blockIdx.y and those partial sums meet in atomics (scasml_gemv_sub beyond 1024 rows).
+__device__ __forceinline__ double gemv_t_columns(const double *A, int64_t lda, int64_t rb, int64_t re, int64_t c, bool live, const double *x) {
+    __shared__ double part[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (live) {
+        int64_t r = rb + wv;
+        for (; r + 12 < re; r += 16) {
+            a0 = fma(A[r * lda + c], x[r], a0);
+            a1 = fma(A[(r + 4) * lda + c], x[r + 4], a1);
+            a2 = fma(A[(r + 8) * lda + c], x[r + 8], a2);
+            a3 = fma(A[(r + 12) * lda + c], x[r + 12], a3);
+        }
+        for (; r < re; r += 4) a0 = fma(A[r * lda + c], x[r], a0);
+    }
+    part[wv][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    return (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+
 __global__ __launch_bounds__(256) void gemv_t_sub_kernel(const double *A, int64_t lda, int64_t rows, int64_t cols, const double *x, double *y,
                                                          int64_t rows_per_block) {
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
+    const int64_t c = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
     const int64_t rb = (int64_t)blockIdx.y * rows_per_block;
     const int64_t re = rb + rows_per_block < rows ? rb + rows_per_block : rows;
-    double acc = 0.0;
-    for (int64_t r = rb; r < re; ++r) acc = fma(A[r * lda + c], x[r], acc);
-    if (gridDim.y == 1) y[c] -= acc;     // single writer: deterministic (the distributed solves use 256-row blocks)
+    const double acc = gemv_t_columns(A, lda, rb, re, c, c < cols, x);
+    if (threadIdx.x >= 64 || c >= cols) return;
+    if (gridDim.y == 1) y[c] -= acc;     // single writer: deterministic (the distributed solves sweep at most 1024 rows per launch)
     else atomicAdd(&y[c], -acc);
+}
+
+// the same product with the row groups' partial sums written to a scratch buffer and added in FIXED order: bitwise reproducible between runs
+// (the atomic path's last bits depend on the order the row groups retire in)
+__global__ __launch_bounds__(256) void gemv_t_partial_kernel(const double *A, int64_t lda, int64_t rows, int64_t cols, const double *x, double *partial,
+                                                             int64_t rows_per_block) {
+    const int64_t c = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int64_t rb = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t re = rb + rows_per_block < rows ? rb + rows_per_block : rows;
+    const double acc = gemv_t_columns(A, lda, rb, re, c, c < cols, x);
+    if (threadIdx.x < 64 && c < cols) partial[(int64_t)blockIdx.y * cols + c] = acc;
+}
+__global__ __launch_bounds__(256) void gemv_t_reduce_kernel(const double *partial, int64_t groups, int64_t cols, double *y) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    double acc = 0.0;
+    for (int64_t g = 0; g < groups; ++g) acc += partial[g * cols + c];
+    y[c] -= acc;
 }
 
 }  // namespace scasml
@@ -230,6 +269,27 @@ extern "C" int scasml_trsm_right_lt(const double *L, int64_t ldl, int64_t nb, do
     return check_launch("trsm_right_lt launch");
 }
 
+extern "C" int64_t scasml_gemv_t_ordered_scratch(int64_t rows, int64_t cols) {
+    if (rows < 0 || cols < 0) return -1;
+    const int64_t rpb = rows <= 64 * 64 ? 64 : (rows + 63) / 64;      // at most 64 row groups
+    const int64_t groups = rows ? (rows + rpb - 1) / rpb : 0;
+    return groups * cols;
+}
+
+extern "C" int scasml_gemv_t_sub_ordered(const double *A, int64_t lda, int64_t rows, int64_t cols, const double *x, double *y, double *scratch,
+                                         int64_t scratch_elems, void *stream) {
+    if (!A || !x || !y || rows < 0 || cols < 0 || lda < cols) return fail(SCASML_ERR_ARG, "gemv_t_sub_ordered: bad argument");
+    if (rows == 0 || cols == 0) return 0;
+    const int64_t need = scasml_gemv_t_ordered_scratch(rows, cols);
+    if (!scratch || scratch_elems < need) return fail(SCASML_ERR_ARG, "gemv_t_sub_ordered: scratch holds %lld doubles, %lld needed", (long long)scratch_elems, (long long)need);
+    const int64_t rpb = rows <= 64 * 64 ? 64 : (rows + 63) / 64;
+    const int64_t groups = (rows + rpb - 1) / rpb;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gemv_t_partial_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)groups), dim3(256), 0, s, A, lda, rows, cols, x, scratch, rpb);
+    hipLaunchKernelGGL(gemv_t_reduce_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, scratch, groups, cols, y);
+    return check_launch("gemv_t_sub_ordered launch");
+}
+
 extern "C" int scasml_gemv_sub(const double *A, int64_t lda, int64_t rows, int64_t cols, const double *x, double *y, int trans, void *stream) {
     if (!A || !x || !y || rows < 0 || cols < 0 || lda < cols) return fail(SCASML_ERR_ARG, "gemv_sub: bad argument");
     if (rows == 0 || cols == 0) return 0;
@@ -237,10 +297,10 @@ extern "C" int scasml_gemv_sub(const double *A, int64_t lda, int64_t rows, int64
     if (!trans) {
         hipLaunchKernelGGL(gemv_sub_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, A, lda, rows, cols, x, y);
     } else {
-        const int64_t rpb = rows <= 512 ? rows : 64;
+        const int64_t rpb = rows <= 1024 ? rows : 64;     // up to 1024 rows (a group of four block rows of the distributed substitutions): one writer per column
         const int64_t gy = (rows + rpb - 1) / rpb;
         if (gy > 65535) return fail(SCASML_ERR_UNSUPPORTED, "gemv_sub: too many rows for one launch");
-        hipLaunchKernelGGL(gemv_t_sub_kernel, dim3((unsigned)((cols + 255) / 256), (unsigned)gy), dim3(256), 0, s, A, lda, rows, cols, x, y, rpb);
+        hipLaunchKernelGGL(gemv_t_sub_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)gy), dim3(256), 0, s, A, lda, rows, cols, x, y, rpb);
     }
     return check_launch("gemv_sub launch");
 }

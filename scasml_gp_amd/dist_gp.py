@@ -20,10 +20,13 @@ Right-looking factorisation, per block column k (1367 steps at M = 350 000):
 Collective volume: the panel of step k reaches every rank once, M^2 / 2 * 8 B = 490 GB per rank over the whole run -- over
 xGMI rings (7 links x ~50 GB/s effective each way) a few seconds against ~60 s of FP64 MFMA work (M^3 / 3 = 1.4e16 flop / 8 GPUs).
 
-Substitutions (K_p^-1 z is two of them; the explicit inverse the single-GPU path forms is never built): the diagonal blocks are
-replicated (they were broadcast in step 1), the right-hand side is replicated.  Forward: per block k the owner's up-to-date
-b_k is broadcast (2 KB), everyone solves y_k and updates its own rows.  Backward: owner(i) folds x_i into a local
-accumulator over its whole block row (one transposed gemv), one all-reduce of 256 doubles per block gives the right-hand side.
+Substitutions (K_p^-1 z is two of them; the explicit inverse the single-GPU path forms is never built) walk the block rows in GROUPS of
+four (1024 rows): the diagonal SUPER-block L_GG of a group is assembled on every rank once after factor() (one all-reduce of 8 MB per
+group) and inverted, so a group costs ONE collective of 1024 doubles and three launches instead of four collectives and ~16 launches:
+forward -- the owners' up-to-date pieces of b_G meet in one all-reduce, y_G = L_GG^-1 b_G is one 1024 x 1024 product on every rank,
+one gemv takes L_{>G,G} y_G off the rank's later rows; backward -- one all-reduce sums the ranks' accumulators for the group's
+columns, x_G = L_GG^-T t_G, and the group's owners fold x_G into their accumulators over the columns before the group.  A solve is
+2 ceil(nblk / 4) collectives (M = 350 000: 684 instead of 2 736) and reads the triangle twice.
 
 Newton (models/GP.py:501-588) without K_p^-1 and without the (3 N_dom)^2 Hessian (500 GB at this size): the damped Newton
 system (H + 1e-4 I) delta = -g is solved INEXACTLY by conjugate gradients with H v = 2 J^T K_p^-1 J v + second-derivative
@@ -42,6 +45,7 @@ import numpy as np
 from . import _lib
 
 BLK = _lib.DIST_BLOCK
+GROUP = 4          # block rows per substitution step (1024 rows: the transposed sweeps stay one-writer-per-column, i.e. bitwise reproducible)
 
 
 class Comm:
@@ -141,7 +145,8 @@ class DistCholesky:
         self.mine = owned_blocks(self.nblk, self.comm.rank, self.comm.world)
         self.R = None
         self.diag = [None] * self.nblk          # replicated 256 x 256 diagonal factors
-        self.ninv = None                        # -L_kk^-1 of each, made by the first solve() (_neg_inverse_blocks)
+        self.ninv = None                        # -L_GG^-1 of every group of GROUP diagonal blocks, made by the first solve() (_neg_inverse_groups)
+        self._scratch = None                    # partial sums of the ordered transposed sweep (matvec)
         self._mine_dev = None
         self.info = torch.zeros(1, dtype=torch.int32, device="cuda")
         self.bad = torch.zeros(1, dtype=torch.float64, device="cuda")   # blocks this rank found not positive definite (scasml_cholesky resets info per call)
@@ -171,11 +176,13 @@ class DistCholesky:
         cnt = (nblk - 1 + world - 1) // world                 # blocks per rank in the widest column panel (step k = 0)
         out = {"M": M, "block_rows": nblk, "owned_block_rows": owned,
                "panel_R": owned * BLK * Mp * 8,                # build(): this rank's block rows, full width (columns beyond the block's own stay zero)
-               "diag_factors": 2 * nblk * blk,                 # factor(): every diagonal factor, replicated (broadcast in step 1); solve(): -L_kk^-1 of each
+               # factor(): every diagonal factor, replicated (broadcast in step 1); solve(): -L_GG^-1 of every group of GROUP block rows, replicated
+               # (and the transposes of those inverses: both substitution directions are row-major products)
+               "diag_factors": nblk * blk + 2 * ((nblk + GROUP - 1) // GROUP) * GROUP * GROUP * blk,
                "collocation_f32": (n_dom + n_bdy) * (d + 1) * 4,
                # factor(), per step: the send buffer, the gathered panel and its reordered copy; with look-ahead the panels of steps k and k + 1 coexist
                "panel_exchange_peak": cnt * blk + world * cnt * blk + 2 * (nblk - 1) * blk,
-               "vectors": 6 * Mp * 8}                          # solve() / matvec(): right-hand side, y, x, accumulator, local rows, output
+               "vectors": 6 * Mp * 8 + 64 * Mp * 8}            # solve() / matvec(): right-hand side, y, x, accumulator, local rows, output; the 64 row groups' partial sums of the ordered sweep
         out["total"] = sum(v for k, v in out.items() if k not in ("M", "block_rows", "owned_block_rows"))
         return out
 
@@ -296,61 +303,85 @@ class DistCholesky:
             self._mine_dev = torch.as_tensor(self.mine, device="cuda", dtype=torch.long)
         return self._mine_dev
 
-    def _neg_inverse_blocks(self):
-        """-L_kk^-1 of every (replicated) diagonal factor, made once after factor(): a substitution step's 256 x 256 triangular solve of ONE vector
-        is then a single 256 x 256 product (scasml_gemv_sub: y -= (-L^-1) b) instead of the sixteen launches of the blocked scasml_trsm_lower --
-        the substitutions are chains of 2 x nblk dependent steps, i.e. launch-latency bound (M = 70 001: 107 -> 40 ms per solve)."""
+    def _groups(self):
+        return [(g0, min(g0 + GROUP, self.nblk)) for g0 in range(0, self.nblk, GROUP)]
+
+    def _neg_inverse_groups(self):
+        """-L_GG^-1 of every diagonal SUPER-block (GROUP block rows = 1024 rows), replicated, made once after factor(): each block row of the
+        super-block comes from its owner through one all-reduce per group (zeros from everyone else), then one blocked triangular solve against -I.
+        A substitution step over a whole group is then a single 1024 x 1024 product: the chains are launch- and collective-latency bound
+        (M = 70 001, one rank: 548 collectives and ~2 200 launches per solve with per-block steps)."""
         torch = _lib.require_gpu()
         if self.ninv is None:
-            lib, s = self.lib, _lib.stream_ptr()
-            ninv = torch.zeros((self.nblk, BLK, BLK), dtype=torch.float64, device="cuda")
-            ninv.diagonal(dim1=1, dim2=2).fill_(-1.0)
-            for k in range(self.nblk):
-                _lib.check(lib.scasml_trsm_lower(_lib.ptr(self.diag[k]), BLK, _lib.ptr(ninv[k]), BLK, 0, s), "trsm(diag^-1)")
-            self.ninv = ninv
+            lib, s, cm = self.lib, _lib.stream_ptr(), self.comm
+            w, rank = cm.world, cm.rank
+            out = []
+            for g0, g1 in self._groups():
+                n = (g1 - g0) * BLK
+                LG = torch.zeros((n, n), dtype=torch.float64, device="cuda")
+                for k in range(g0, g1):
+                    if k % w == rank:
+                        slot = (k - rank) // w
+                        LG[(k - g0) * BLK:(k - g0 + 1) * BLK, :(k - g0 + 1) * BLK] = self.R[slot * BLK:(slot + 1) * BLK, g0 * BLK:(k + 1) * BLK]
+                cm.all_reduce(LG)
+                LG = torch.tril(LG).contiguous()
+                NI = torch.zeros((n, n), dtype=torch.float64, device="cuda")
+                NI.diagonal().fill_(-1.0)
+                _lib.check(lib.scasml_trsm_lower(_lib.ptr(LG), n, _lib.ptr(NI), n, 0, s), "trsm(group^-1)")
+                out.append((NI, NI.T.contiguous()))     # and its transpose: the backward step is then a row-major product too (one wave per row)
+            self.ninv = out
         return self.ninv
 
     def solve(self, b):
-        """x = (L L^T)^-1 b for a replicated b (length M; a CUDA float64 tensor); returns x replicated."""
+        """x = (L L^T)^-1 b for a replicated b (length M; a CUDA float64 tensor); returns x replicated.  Bitwise reproducible between runs."""
         torch = _lib.require_gpu()
         lib, s, cm = self.lib, _lib.stream_ptr(), self.comm
-        R, Mp, nb, w, rank = self.R, self.Mp, self.nblk, cm.world, cm.rank
-        ninv = self._neg_inverse_blocks()
+        R, Mp, w, rank = self.R, self.Mp, cm.world, cm.rank
+        ninv, groups = self._neg_inverse_groups(), self._groups()
         bp = torch.zeros(Mp, dtype=torch.float64, device="cuda")
         bp[:self.M] = b
         loc = self._local_rows(bp)
-        rhs = torch.empty(Mp, dtype=torch.float64, device="cuda")   # block k: the up-to-date right-hand side of step k, replicated by the broadcast
+        rhs = torch.zeros(Mp, dtype=torch.float64, device="cuda")   # group G: the up-to-date right-hand side of its step, replicated by the all-reduce
         y = torch.zeros(Mp, dtype=torch.float64, device="cuda")
-        for k in range(nb):                                    # forward: L y = b, right-looking
-            owner = k % w
-            bk, yk = rhs[k * BLK:(k + 1) * BLK], y[k * BLK:(k + 1) * BLK]
-            if rank == owner:
-                slot = (k - rank) // w
-                bk.copy_(loc[slot * BLK:(slot + 1) * BLK])
-            cm.broadcast(bk, owner)
-            _lib.check(lib.scasml_gemv_sub(_lib.ptr(ninv[k]), BLK, BLK, BLK, _lib.ptr(bk), _lib.ptr(yk), 0, s), "gemv(diag^-1)")   # y_k = L_kk^-1 b_k
-            s0 = self._slot0(k)
+        for gi, (g0, g1) in enumerate(groups):                 # forward: L y = b, right-looking, a group of block rows per step
+            n = (g1 - g0) * BLK
+            seg, yG = rhs[g0 * BLK:g1 * BLK], y[g0 * BLK:g1 * BLK]
+            for k in range(g0, g1):                            # the owners' pieces (zeros elsewhere: the sum is a copy)
+                if k % w == rank:
+                    slot = (k - rank) // w
+                    seg[(k - g0) * BLK:(k - g0 + 1) * BLK].copy_(loc[slot * BLK:(slot + 1) * BLK])
+            cm.all_reduce(seg)
+            _lib.check(lib.scasml_gemv_sub(_lib.ptr(ninv[gi][0]), n, n, n, _lib.ptr(seg), _lib.ptr(yG), 0, s), "gemv(group^-1)")   # y_G = L_GG^-1 b_G
+            s0 = self._slot0(g1 - 1)
             rows = (len(self.mine) - s0) * BLK
             if rows:
-                _lib.check(lib.scasml_gemv_sub(self._ptr(R, s0 * BLK, k * BLK, Mp), Mp, rows, BLK, _lib.ptr(yk),
+                _lib.check(lib.scasml_gemv_sub(self._ptr(R, s0 * BLK, g0 * BLK, Mp), Mp, rows, n, _lib.ptr(yG),
                                                C.c_void_p(loc.data_ptr() + 8 * s0 * BLK), 0, s), "gemv_sub")
         x = torch.zeros(Mp, dtype=torch.float64, device="cuda")
-        acc = torch.zeros(Mp, dtype=torch.float64, device="cuda")   # this rank's share of -sum_{i > k} L_ik^T x_i, all k
-        for k in range(nb - 1, -1, -1):                        # backward: L^T x = y
-            tk, xk = rhs[k * BLK:(k + 1) * BLK], x[k * BLK:(k + 1) * BLK]
-            tk.copy_(acc[k * BLK:(k + 1) * BLK])
-            cm.all_reduce(tk)
-            tk.add_(y[k * BLK:(k + 1) * BLK])
-            _lib.check(lib.scasml_gemv_sub(_lib.ptr(ninv[k]), BLK, BLK, BLK, _lib.ptr(tk), _lib.ptr(xk), 1, s), "gemv^T(diag^-1)")   # x_k = L_kk^-T t_k
-            if k % w == rank and k > 0:                        # fold x_k into the accumulator over this block row's columns < k
-                slot = (k - rank) // w
-                _lib.check(lib.scasml_gemv_sub(self._ptr(R, slot * BLK, 0, Mp), Mp, BLK, k * BLK, _lib.ptr(xk), _lib.ptr(acc), 1, s), "gemv_sub^T")
+        acc = torch.zeros(Mp, dtype=torch.float64, device="cuda")   # this rank's share of -sum_{i > G} L_iG^T x_i, all groups
+        for gi in range(len(groups) - 1, -1, -1):              # backward: L^T x = y
+            g0, g1 = groups[gi]
+            n = (g1 - g0) * BLK
+            tG, xG = rhs[g0 * BLK:g1 * BLK], x[g0 * BLK:g1 * BLK]
+            tG.copy_(acc[g0 * BLK:g1 * BLK])
+            cm.all_reduce(tG)
+            tG.add_(y[g0 * BLK:g1 * BLK])
+            _lib.check(lib.scasml_gemv_sub(_lib.ptr(ninv[gi][1]), n, n, n, _lib.ptr(tG), _lib.ptr(xG), 0, s), "gemv(group^-T)")   # x_G = L_GG^-T t_G
+            if g0 > 0:                                         # the group's owners fold x_G into their accumulators over the columns before the group
+                mine_in = [k for k in range(g0, g1) if k % w == rank]
+                if w == 1:                                     # one rank: the group's block rows are one contiguous piece of the stack
+                    _lib.check(lib.scasml_gemv_sub(self._ptr(R, g0 * BLK, 0, Mp), Mp, n, g0 * BLK, _lib.ptr(xG), _lib.ptr(acc), 1, s), "gemv_sub^T")
+                else:
+                    for k in mine_in:
+                        slot = (k - rank) // w
+                        _lib.check(lib.scasml_gemv_sub(self._ptr(R, slot * BLK, 0, Mp), Mp, BLK, g0 * BLK, _lib.ptr(x[k * BLK:(k + 1) * BLK]),
+                                                       _lib.ptr(acc), 1, s), "gemv_sub^T")
         return x[:self.M].clone()
 
     def matvec(self, v):
-        """K_p v = L (L^T v) for a replicated v (length M): TWO launches over the rank's whole stacked panel (its strict upper part is zero after
+        """K_p v = L (L^T v) for a replicated v (length M): TWO sweeps over the rank's whole stacked panel (its strict upper part is zero after
         factor(), so the full width can be swept: twice the bytes of the triangle, one launch instead of one per block row) and two collectives
-        of Mp doubles.  The transposed sweep combines its row groups with atomics: the last bits depend on their order."""
+        of Mp doubles.  The transposed sweep adds its row groups' partial sums in fixed order (scasml_gemv_t_sub_ordered): bitwise reproducible."""
         torch = _lib.require_gpu()
         lib, s, cm = self.lib, _lib.stream_ptr(), self.comm
         R, Mp = self.R, self.Mp
@@ -359,7 +390,11 @@ class DistCholesky:
         vp[:self.M] = v
         acc = torch.zeros(Mp, dtype=torch.float64, device="cuda")          # -(L^T v), summed over ranks
         if rows:
-            _lib.check(lib.scasml_gemv_sub(_lib.ptr(R), Mp, rows, Mp, _lib.ptr(self._local_rows(vp)), _lib.ptr(acc), 1, s), "gemv_sub^T")
+            need = int(lib.scasml_gemv_t_ordered_scratch(rows, Mp))
+            if self._scratch is None or self._scratch.numel() < need:
+                self._scratch = torch.empty(need, dtype=torch.float64, device="cuda")
+            _lib.check(lib.scasml_gemv_t_sub_ordered(_lib.ptr(R), Mp, rows, Mp, _lib.ptr(self._local_rows(vp)), _lib.ptr(acc), _lib.ptr(self._scratch),
+                                                     self._scratch.numel(), s), "gemv_t_sub_ordered")
         cm.all_reduce(acc)
         out = torch.zeros(Mp, dtype=torch.float64, device="cuda")
         if rows:
@@ -395,9 +430,15 @@ class DistributedGP:
 
     def fit(self, x_t_domain, x_t_boundary, GN_steps=20, cg_tol=1e-10, cg_max=400, progress=None):
         """cg_tol: relative residual at which the inner conjugate-gradient solve of a Newton step stops.  1e-10 (default) reproduces the dense
-        Newton iterates of the single-GPU path step for step; "adaptive" is the inexact-Newton forcing term min(1e-2, |grad_k| / |grad_0|)
-        (Eisenstat-Walker): early steps are solved loosely, the last ones tightly -- the same minimiser to the stopping rule's accuracy
-        (models/GP.py:521: |grad| < 1e-5) in about a third of the products.
+        Newton iterates of the single-GPU path step for step (right_vector to 2.6e-14, identical float16 predictions at M = 70 001), and every
+        product is bitwise reproducible between runs (substitutions and K_p v add in fixed order).  "adaptive" is the inexact-Newton forcing term
+        min(1e-2, |grad_k| / |grad_0|) (Eisenstat-Walker): early steps are solved loosely, the last ones tightly -- the same loss to six digits and
+        the same stopping rule (models/GP.py:521: |grad| < 1e-5) in about half of the products.  Its right_vector is NOT the dense path's to
+        the last digits: measured 3.2e-3 (relative, max norm) at M = 2940 and at M = 70 001 alike, predictions up to one float16 ulp (4.9e-4) off.
+        The cause is the surrogate as coded, not the minimisation: z4 = float16(time_der_rep(sol)) (models/GP.py:719), so a sol that differs in its
+        eighth digit rounds a few of the N entries of z4 the other way, and K_p^-1 amplifies those float16 ulps; one more tightly solved Newton step
+        does not remove it (measured: 5.5e-3 after it).  Only iterates that follow the dense path to 1e-14 -- the default tolerance -- round alike.
+        Opt-in, for fits where a right_vector within the reference's own rounding noise is acceptable (tests/test_gpu_dist_gp.py bounds it).
         progress: optional callable(str), told about every Newton step (long fits on a shared box must show signs of life)."""
         torch = _lib.require_gpu()
         lib, s = _lib.load(), _lib.stream_ptr()
@@ -492,7 +533,7 @@ class DistributedGP:
             # matrix with the float16-rounded diagonal, in the memory of the first
             _lib.check(lib.scasml_round16(C.c_void_p(b.data_ptr() + 8 * (2 * N + Nb)), N, s), "round16")
             ch.R = None
-            ch.diag, ch.ninv = [None] * ch.nblk, None
+            ch.diag, ch.ninv, ch._scratch = [None] * ch.nblk, None, None
             torch.cuda.empty_cache()
             ch2 = DistCholesky(d, 1.0 / float(gp.sigma) ** 2, x_t_domain, x_t_boundary, gp.nugget, self.comm, compat_idx=compat_idx,
                                round_diag=True, f16_graph=graph, f16_extra=getattr(gp, "_f16_extra", 0)).build().factor()

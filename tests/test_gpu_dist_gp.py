@@ -208,8 +208,8 @@ def _worker_rccl(rank, world, port, case, q):
         same = bool(torch.equal(ahead.R, plain.R))                   # collectives through RCCL on two streams vs none at all: the same factor
         b = torch.from_numpy(np.random.default_rng(0).standard_normal(ahead.M)).cuda()
         same = same and bool(torch.equal(ahead.solve(b), plain.solve(b)))
-        mv = plain.matvec(b)                                          # (its transposed sweep adds row groups with atomics: last bits vary)
-        same = same and float((ahead.matvec(b) - mv).abs().max()) <= 1e-12 * float(mv.abs().max())
+        mv = plain.matvec(b)                                          # the transposed sweep adds its row groups in fixed order: bit for bit,
+        same = same and bool(torch.equal(ahead.matvec(b), mv)) and bool(torch.equal(plain.matvec(b), mv))   # between the two objects and between two calls
         del ahead, plain
         gp = GP_Grad_Dependent_Nonlinear(eq)
         fit = DistributedGP(gp, cm)
@@ -279,7 +279,8 @@ def test_one_rank_under_rccl_issues_every_collective_of_the_distributed_fit():
     (_, backend, same, calls_factor, calls, rv_err, pred_err, dsteps), = _run(1, "rccl", 900, worker=_worker_rccl)
     assert backend == "nccl" and same
     assert calls_factor["broadcast"] == 28 and calls_factor["all_gather"] == 27 and calls_factor["all_reduce"] == 1, calls_factor
-    assert calls["broadcast"] > 1000 and calls["all_reduce"] > 1000, calls          # the substitutions of every CG product
+    # the substitutions of every CG product: 2 x 7 group steps (four block rows each) per solve, one all-reduce each -- no broadcast beyond the factorisations'
+    assert calls["all_reduce"] > 1000 and calls["broadcast"] == 3 * 28, calls      # (three factorisations went through this Comm)
     assert rv_err <= 1e-6 and pred_err <= 2.0 ** -10 and dsteps == 0, (rv_err, pred_err, dsteps)
 
 
@@ -300,5 +301,10 @@ def test_inexact_newton_reaches_the_same_fit_in_fewer_products():
     assert sum(f_loose.cg_iterations) < 0.6 * sum(f_tight.cg_iterations), (f_loose.cg_iterations, f_tight.cg_iterations)
     assert loose.grad_norms[-1] < 1e-5 or len(loose.loss_history) == 21
     assert abs(loose.loss_history[-1] - one.loss_history[-1]) <= 1e-7 * one.loss_history[-1]
+    # right_vector: NOT the dense path's to the last digits -- z4 = float16(time_der_rep(sol)) (models/GP.py:719) rounds a few entries the
+    # other way for a sol that differs in the eighth digit, and K_p^-1 amplifies those ulps (measured 3.2e-3 here and at M = 70 001); bounded, so
+    # that a regression of the forcing term shows, and the predictions below stay within one float16 ulp
+    rel = np.abs(loose.right_vector - one.right_vector).max() / np.abs(one.right_vector).max()
+    assert 1e-12 < rel <= 1e-2, rel
     X = np.concatenate(eq.generate_test_data(200, 40))
     assert np.abs(loose.predict(X).astype(np.float64) - one.predict(X).astype(np.float64)).max() <= 2.0 ** -10      # float16 values: within an ulp
