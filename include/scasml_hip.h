@@ -39,8 +39,13 @@ enum { SCASML_ERR_ARG = -1, SCASML_ERR_UNSUPPORTED = -2, SCASML_ERR_HIP = -3 };
  *   0  equations/equations.py:232-417 `Grad_Dependent_Nonlinear`: f = sigma*u*sum(z), g = 1 - 1/(1+exp(t+sum x)),
  *      mu = -1/d - sigma^2/2, sigma = 0.25
  *   1  `Cubic_Reaction_Diffusion` (no reference counterpart): f = -u (1-u) (1 + (sigma^2 d/2)(1-2u)), mu = 0, same g;
- *      exact solution 1 - 1/(1+exp(t+sum x)) */
-enum { SCASML_EQ_GRAD_DEPENDENT_NONLINEAR = 0, SCASML_EQ_CUBIC_REACTION_DIFFUSION = 1 };
+ *      exact solution 1 - 1/(1+exp(t+sum x))
+ * and, ABI 7, one step wider for the solvers without a surrogate -- f(u, sum_i z_i, sum_i z_i^2), one more xor-shuffle sum per evaluation of f:
+ *   2  `Quadratic_Gradient_Reaction_Diffusion`: f = -u (1-u) (1 + (sigma^2 d/2)(1-2u)) + (|z|^2 - sigma^2 d (u (1-u))^2), mu = 0, same g and
+ *      exact solution (the |z|^2 term vanishes on the travelling wave).  scasml_picard_tree in SCASML_MODE_MLP only (MLP, MLP_full_history,
+ *      Philox stream): ScaSML's defect f(u_hat + u, sigma grad u_hat + z) - f(u_hat, sigma grad u_hat) would need the surrogate's FULL gradient at
+ *      every tree site, where the fused evaluation delivers div u_hat; the GP kernels refuse this id. */
+enum { SCASML_EQ_GRAD_DEPENDENT_NONLINEAR = 0, SCASML_EQ_CUBIC_REACTION_DIFFUSION = 1, SCASML_EQ_QUADRATIC_GRADIENT_REACTION_DIFFUSION = 2 };
 
 typedef struct {
     int32_t d;        /* spatial dimension (n_input - 1)                                    */

@@ -79,6 +79,22 @@ class CubicReactionDiffusion(_SemilinearBase):
         return -w * v, -(1 - 2 * u) * v + 2 * c * w, z, 2 * v + 4 * c * (1 - 2 * u), z, z
 
 
+class QuadraticGradientReactionDiffusion(CubicReactionDiffusion):
+    """The family one step wider -- f(u, sum z, |z|^2) -- for the surrogate-free solvers (no reference counterpart):
+        f = -u (1 - u) (1 + c (1 - 2u)) + (|z|^2 - sigma^2 d (u (1 - u))^2),   mu = 0,   same terminal condition.
+    On the travelling wave z_i = sigma u (1 - u): the added term vanishes and logistic(t + sum x) stays exact."""
+    eq_id = 2
+
+    def f(self, x_t, u, z):
+        u, z = np.asarray(u, dtype=np.float64), np.asarray(z, dtype=np.float64)
+        s, d = self.sigma(), self.d
+        w = u * (1 - u)
+        return -w * (1 + (s * s * d / 2) * (1 - 2 * u)) + (np.sum(z * z, axis=1, keepdims=True) - s * s * d * w * w)
+
+    def f_parts(self, u, sz):
+        raise NotImplementedError("f depends on |z|^2")
+
+
 def sample_points(rng, d, n_dom, n_bdy, t0=0.0, T=0.5, radius=0.5):
     """Stand-in for deepxde ``GeometryXTime.random_points / random_boundary_points``
     (equations.py:387-417): interior points uniform in the

@@ -16,6 +16,7 @@ RNG_COMPAT_F16 = 2
 RNG_JAX_STREAM = 4
 EQ_GRAD_DEPENDENT_NONLINEAR = 0
 EQ_CUBIC_REACTION_DIFFUSION = 1
+EQ_QUADRATIC_GRADIENT_REACTION_DIFFUSION = 2      # f(u, sum z, |z|^2): surrogate-free Picard kernels only
 
 
 class Problem(C.Structure):

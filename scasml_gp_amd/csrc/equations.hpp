@@ -26,6 +26,7 @@ struct EqDef;
 // ---- 0: Grad_Dependent_Nonlinear (equations/equations.py:232-417): f = sigma u s, g = 1 - 1 / (1 + exp(T + sum x))
 template <>
 struct EqDef<SCASML_EQ_GRAD_DEPENDENT_NONLINEAR> {
+    static constexpr bool kGradSquare = false;   // f sees the gradient through sum_i z_i only
     template <class T>
     static __host__ __device__ __forceinline__ T f(T u, T s, T sigma, T d) {
         (void)d;
@@ -47,6 +48,7 @@ struct EqDef<SCASML_EQ_GRAD_DEPENDENT_NONLINEAR> {
 //         c = sigma^2 d / 2, mu = 0, same terminal condition; exact solution logistic(t + sum x)
 template <>
 struct EqDef<SCASML_EQ_CUBIC_REACTION_DIFFUSION> {
+    static constexpr bool kGradSquare = false;
     template <class T>
     static __host__ __device__ __forceinline__ T f(T u, T s, T sigma, T d) {
         (void)s;
@@ -66,6 +68,26 @@ struct EqDef<SCASML_EQ_CUBIC_REACTION_DIFFUSION> {
     }
 };
 
+// ---- 2: Quadratic_Gradient_Reaction_Diffusion (no reference counterpart; oracle/equation.py): the family one step wider, f(u, s1, s2) with
+//         s2 = sum_i z_i^2 = |z|^2 -- f = -u (1 - u) (1 + c (1 - 2u)) + (s2 - sigma^2 d (u (1 - u))^2); on the travelling wave z_i = sigma u (1 - u),
+//         so the added term vanishes and logistic(t + sum x) stays exact.  Picard kernels without a surrogate only (scasml_hip.h).
+template <>
+struct EqDef<SCASML_EQ_QUADRATIC_GRADIENT_REACTION_DIFFUSION> {
+    static constexpr bool kGradSquare = true;
+    template <class T>
+    static __host__ __device__ __forceinline__ T f2(T u, T s1, T s2, T sigma, T d) {
+        (void)s1;
+        const T c = T(0.5) * sigma * sigma * d, w = u * (T(1) - u);
+        return -w * (T(1) + c * (T(1) - T(2) * u)) + (s2 - sigma * sigma * d * w * w);
+    }
+    static __device__ __forceinline__ float4 phi(float4 x) { return x; }
+    static __device__ __forceinline__ float G(float sum_phi, float T) {
+        return 1.0f - __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((T + sum_phi) * 1.44269504088896341f));
+    }
+};
+
+// equations every kernel family covers (Picard tree in all modes, GP training, fused evaluation) / those of the surrogate-free Picard tree alone
+inline bool eq_mlp_only(int eq_id) { return eq_id == SCASML_EQ_QUADRATIC_GRADIENT_REACTION_DIFFUSION; }
 inline bool eq_known(int eq_id) { return eq_id == SCASML_EQ_GRAD_DEPENDENT_NONLINEAR || eq_id == SCASML_EQ_CUBIC_REACTION_DIFFUSION; }
 
 // run `stmt` with EQ bound to the compile-time id

@@ -93,7 +93,9 @@ extern "C" int scasml_picard_tree(const scasml_problem *prob, const scasml_plan 
     if (!x_t) return fail(SCASML_ERR_ARG, "picard_tree: x_t is null");
     if (prob->d < 1 || prob->d > SCASML_MAX_DIM)
         return fail(SCASML_ERR_UNSUPPORTED, "picard_tree: d=%d outside 1..%d", prob->d, SCASML_MAX_DIM);
-    if (!eq_known(prob->eq_id)) return fail(SCASML_ERR_UNSUPPORTED, "picard_tree: unknown equation id %d", prob->eq_id);
+    if (!eq_known(prob->eq_id) && !eq_mlp_only(prob->eq_id)) return fail(SCASML_ERR_UNSUPPORTED, "picard_tree: unknown equation id %d", prob->eq_id);
+    if (eq_mlp_only(prob->eq_id) && (mode != SCASML_MODE_MLP || (rng.flags & SCASML_RNG_JAX_STREAM)))
+        return fail(SCASML_ERR_UNSUPPORTED, "picard_tree: equation id %d (f of |z|^2) runs in SCASML_MODE_MLP on the Philox stream only", prob->eq_id);
     if (plan->variant != 0 && plan->variant != 1) return fail(SCASML_ERR_ARG, "picard_tree: variant %d", plan->variant);
     if (plan->n < 0 || plan->n > SCASML_MAX_LEVEL)
         return fail(SCASML_ERR_UNSUPPORTED, "picard_tree: level n=%d outside 0..%d", plan->n, SCASML_MAX_LEVEL);
@@ -150,6 +152,10 @@ extern "C" int scasml_picard_tree(const scasml_problem *prob, const scasml_plan 
     const int64_t blocks = (waves + 3) / 4;
     if (blocks > 0x7FFFFFFF) return fail(SCASML_ERR_UNSUPPORTED, "picard_tree: batch too large");
     const dim3 grid((unsigned)blocks);
+    if (eq_mlp_only(prob->eq_id)) {
+        constexpr int EQ2 = SCASML_EQ_QUADRATIC_GRADIENT_REACTION_DIFFUSION;
+        return plan->variant == 0 ? launch_level<0, SCASML_MODE_MLP, EQ2>(a, plan->n, grid, s) : launch_level<1, SCASML_MODE_MLP, EQ2>(a, plan->n, grid, s);
+    }
     int rc = SCASML_ERR_UNSUPPORTED;
     SCASML_EQ_SWITCH(prob->eq_id, rc = (plan->variant == 0 ? launch_mode<0, EQ>(a, mode, plan->n, grid, s) : launch_mode<1, EQ>(a, mode, plan->n, grid, s)));
     return rc;

@@ -235,7 +235,11 @@ struct Walker {
     __device__ __forceinline__ float f_eval(float uc, float4 zc, float4 gp) const {
         const float sz = dim_sum(zc);
         const float fd = (float)a.d;
-        if constexpr (MODE == SCASML_MODE_ACCUMULATE) {
+        if constexpr (EqDef<EQ>::kGradSquare) {                   // f(u, sum z, |z|^2): one more sum over the dims (surrogate-free modes only)
+            static_assert(MODE != SCASML_MODE_ACCUMULATE, "an f of |z|^2 needs the surrogate's full gradient per site: not in the fused evaluation");
+            const float v = EqDef<EQ>::f2(uc, sz, dim_sum(mul4(zc, zc)), a.sigma, fd);
+            return a.f16 ? r16(v) : v;
+        } else if constexpr (MODE == SCASML_MODE_ACCUMULATE) {
             const float sg = a.sigma * gp.y;
             const float v1 = EqDef<EQ>::f(uc + gp.x, sg + sz, a.sigma, fd), v2 = EqDef<EQ>::f(gp.x, sg, a.sigma, fd);
             return a.f16 ? r16(r16(v1) - r16(v2)) : v1 - v2;      // generator(...).astype(float16) twice, then float16 - float16 (equations.py:304, ScaSML.py:45-47)

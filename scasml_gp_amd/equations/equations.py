@@ -216,3 +216,27 @@ class Cubic_Reaction_Diffusion(_LogisticWave):
         w, v = u * (1 - u), 1 + c * (1 - 2 * u)
         z = np.zeros_like(u)
         return -w * v, -(1 - 2 * u) * v + 2 * c * w, z, 2 * v + 4 * c * (1 - 2 * u), z, z
+
+
+class Quadratic_Gradient_Reaction_Diffusion(_LogisticWave):
+    """A third registered equation, one step wider than the family above (no reference counterpart): f(u, sum_i z_i, sum_i z_i^2),
+        u_t + sigma^2/2 Lap u - u (1 - u) (1 + c (1 - 2u)) + (|z|^2 - sigma^2 d (u (1 - u))^2) = 0,   c = sigma^2 d / 2,  z = sigma grad u,
+    mu = 0; on the travelling wave z_i = sigma u (1 - u), so the gradient term vanishes and 1 - 1/(1 + exp(t + sum x)) stays the exact solution.
+    Kernels: the surrogate-free Picard tree (MLP, MLP_full_history) -- one more xor-shuffle sum per evaluation of f.  ScaSML on it would need the
+    surrogate's FULL gradient at every tree site (the fused evaluation delivers div u_hat): refused, as the GP fit is (its collocation operator is
+    a function of (u, Lap u, div u) alone, models/GP.py:705-719)."""
+    eq_id = _lib.EQ_QUADRATIC_GRADIENT_REACTION_DIFFUSION
+    surrogate_free_only = True
+
+    def mu(self, x_t=0):
+        return 0.0
+
+    def f(self, x_t, u, z):
+        u, z = np.asarray(u, dtype=np.float64), np.asarray(z, dtype=np.float64)
+        s, d = self.sigma(), self.n_input - 1
+        w = u * (1 - u)
+        return -w * (1 + (s * s * d / 2) * (1 - 2 * u)) + (np.sum(z * z, axis=1, keepdims=True) - s * s * d * w * w)
+
+    def f_parts(self, u, sz):
+        raise NotImplementedError("Quadratic_Gradient_Reaction_Diffusion: f depends on |z|^2, not on sum z alone: no (u, sum z) form (and no GP collocation operator)")
+

@@ -282,10 +282,15 @@ class GP(object):
 
     def loss_function(self, sol, rhs_f=None, bdy_g=None, L=None):
         '''The Newton objective |L^-1 b(sol)|^2 with b = [z1, g(x_bdy), z3, F(sol) + rhs_f, z5] (models/GP.py:430-444), on the device: b by
-        scasml_gp_newton_b, one blocked triangular solve against the factor of kernel_phi_phi (``L``: another lower factor of the same order;
-        default the one held).  Returns a float64 scalar (the reference casts the value to float16 for its log).'''
+        scasml_gp_newton_b, one blocked triangular solve against the factor of kernel_phi_phi.  ``L`` (optional): another factor of the same order.
+        The reference solves ``jnp.linalg.solve(L, b)`` with its own factor, the DENSE U sqrt(S + nugget) of the SVD (:260-266, 439): a factor that
+        is not lower triangular is therefore accepted too -- |L^-1 b|^2 = b^T (L L^T)^-1 b, evaluated through the Cholesky factor of L L^T (the
+        triangular solve reads the lower triangle only and would silently ignore the rest).  Returns a float64 scalar (the reference casts the
+        value to float16 for its log).'''
         torch = _lib.require_gpu()
         lib = _lib.load()
+        if getattr(self, "N_domain", None) is None or getattr(self, "x_t_boundary", None) is None:
+            raise _lib.ScasmlError("no collocation points: call kernel_phi_phi(x_domain, x_boundary) or GPsolver first (N_domain and x_t_boundary are set there)")
         if getattr(self, "_L_pad", None) is None and L is None:
             raise _lib.ScasmlError("no factor: call kernel_phi_phi(x_domain, x_boundary) or GPsolver first")
         N, Nb, M = self.N_domain, self.N_boundary, self.phi_dim
@@ -298,8 +303,18 @@ class GP(object):
         if L is None:
             Lp = self._L_pad
         else:
+            Lg = torch.as_tensor(np.asarray(L.detach().cpu() if isinstance(L, torch.Tensor) else L, dtype=np.float64), device="cuda")
+            if Lg.shape != (M, M):
+                raise ValueError("L has shape %s, expected (%d, %d)" % (tuple(Lg.shape), M, M))
             Lp = torch.eye(_round_up(M, 32), dtype=torch.float64, device="cuda")
-            Lp[:M, :M] = torch.as_tensor(np.asarray(L, dtype=np.float64), device="cuda")
+            if bool((torch.triu(Lg, 1) != 0).any()):          # a general factor (the reference's own is U sqrt(S)): the Cholesky factor of L L^T
+                Lp[:M, :M] = Lg @ Lg.T
+                info = torch.zeros(1, dtype=torch.int32, device="cuda")
+                _lib.check(lib.scasml_cholesky(_lib.ptr(Lp), Lp.shape[0], 0.0, _lib.ptr(info), s), "cholesky(L L^T)")
+                if int(info.item()) != 0:
+                    raise ValueError("L L^T is not positive definite")
+            else:
+                Lp[:M, :M] = Lg
         Mp = Lp.shape[0]
         b = torch.zeros((Mp, 1), dtype=torch.float64, device="cuda")
         _lib.check(lib.scasml_gp_newton_b(int(self.equation.eq_id), int(self.d), float(self.equation.sigma()), float(self.equation.mu()), _lib.ptr(sol_d),
@@ -334,8 +349,9 @@ class GP(object):
         _gp_newton_system).'''
         torch = _lib.require_gpu()
         lib = _lib.load()
-        if getattr(self.equation, "eq_id", None) is None:
-            raise NotImplementedError("no HIP Newton kernels for equation %s" % type(self.equation).__name__)
+        if getattr(self.equation, "eq_id", None) is None or getattr(self.equation, "surrogate_free_only", False):
+            raise NotImplementedError("no HIP Newton kernels for equation %s%s" % (type(self.equation).__name__, " (its f depends on |z|^2: the collocation operator of "
+                                      "models/GP.py:705-719 is a function of (u, Lap u, div u) alone)" if getattr(self.equation, "eq_id", None) is not None else ""))
         Kp = self.kernel_phi_phi(x_t_domain, x_t_boundary)
         if self.compat != "reference":
             del Kp

@@ -28,6 +28,9 @@ class PicardEngine:
             compat_rng, compat_f16 = "jax", True
         if getattr(equation, "eq_id", None) is None:
             raise NotImplementedError("no HIP kernels for equation %s (eq_id unset)" % type(equation).__name__)
+        if getattr(equation, "surrogate_free_only", False) and (gp is not None or reference_mode or compat_rng == "jax"):
+            raise NotImplementedError("equation %s has an f of |z|^2: its kernels are the surrogate-free Picard tree on the Philox stream (MLP, MLP_full_history); "
+                                      "ScaSML would need the surrogate's full gradient at every tree site" % type(equation).__name__)
         self.equation = equation
         self.variant = variant
         self.gp = gp

@@ -30,6 +30,60 @@ def test_plain_mlp_on_the_second_equation_matches_oracle(variant, d, n, par, B):
     assert np.all(np.abs(got - want) <= 2e-5 + 1e-4 * np.abs(want)), np.abs(got - want).max()
 
 
+@pytest.mark.parametrize("variant,d,n,par,B", [("quad", 20, 2, 2, 64), ("quad", 20, 3, 3, 24), ("quad", 100, 3, 3, 6), ("quad", 250, 2, 2, 5), ("fh", 20, 3, 3, 40),
+                                               ("fh", 100, 4, 3, 5), ("quad", 3, 3, 3, 9)])
+def test_plain_mlp_on_an_f_of_the_squared_gradient_matches_oracle(variant, d, n, par, B):
+    """The family one step wider: f(u, sum z, |z|^2) -- Quadratic_Gradient_Reaction_Diffusion, eq_id 2 -- through the surrogate-free
+    Picard kernels against the oracle, which hands f the full z (equations/equations.py:130-144 is the reference's f(x_t, u, z))."""
+    from oracle.equation import QuadraticGradientReactionDiffusion
+    from oracle.mlp import PicardOracle
+    from scasml_gp_amd.equations.equations import Quadratic_Gradient_Reaction_Diffusion
+    from scasml_gp_amd.solvers.MLP import MLP
+    from scasml_gp_amd.solvers.MLP_full_history import MLP_full_history
+    xt = np.concatenate(_points(d, B - B // 4, B // 4, 11))
+    eq = Quadratic_Gradient_Reaction_Diffusion(d + 1)
+    oeq = QuadraticGradientReactionDiffusion(d + 1)
+    ora = PicardOracle(oeq, variant, seed=3, stream=0)
+    if variant == "quad":
+        got, want = MLP(eq, seed=3).uz_solve(n, par, xt), ora.uz_solve(n, par, xt)
+    else:
+        got, want = MLP_full_history(eq, seed=3).uz_solve(n, None, xt, par), ora.uz_solve(n, par, xt)
+    assert np.all(np.abs(got - want) <= 2e-5 + 1e-4 * np.abs(want)), np.abs(got - want).max()
+    # the |z|^2 term is live: the cubic equation (the same f without it) gives another answer on the same draws
+    from oracle.equation import CubicReactionDiffusion
+    other = PicardOracle(CubicReactionDiffusion(d + 1), variant, seed=3, stream=0).uz_solve(n, par, xt)
+    assert np.abs(other - want).max() > 1e-3
+    # host view of f against the oracle's, and the travelling wave is a solution: f(u, sigma grad u) = -(u_t + sigma^2/2 Lap u) on it
+    u, z = np.random.default_rng(0).uniform(0, 1, (7, 1)), np.random.default_rng(1).normal(size=(7, d))
+    assert np.allclose(eq.f(xt[:7], u, z), oeq.f(xt[:7], u, z))
+    h = eq.exact_solution(xt.astype(np.float64))
+    hp = h * (1 - h)
+    s = eq.sigma()
+    assert np.allclose(eq.f(xt, h, s * hp * np.ones((1, d))), -(hp + 0.5 * s * s * d * hp * (1 - 2 * h)), atol=1e-12)
+
+
+def test_an_f_of_the_squared_gradient_is_refused_where_the_full_gradient_would_be_needed():
+    import ctypes as C
+    from scasml_gp_amd import _lib, tables
+    from scasml_gp_amd.equations.equations import Quadratic_Gradient_Reaction_Diffusion
+    from scasml_gp_amd.models.GP import GP_Semilinear
+    from scasml_gp_amd.solvers.MLP import MLP
+    from scasml_gp_amd.solvers.ScaSML import ScaSML
+    eq = Quadratic_Gradient_Reaction_Diffusion(21)
+    with pytest.raises(NotImplementedError):
+        ScaSML(eq, object())
+    with pytest.raises(NotImplementedError):
+        MLP(eq, compat_rng="jax")
+    dom, bdy = _points(20, 40, 12, 2)
+    with pytest.raises((NotImplementedError, _lib.ScasmlError)):
+        GP_Semilinear(eq, compat=None).GPsolver(dom, bdy)
+    lib = _lib.load()
+    prob = _lib.Problem(20, 2, 0.5, 0.0, 0.25, 1.0)
+    plan = tables.build_plan("quad", 1, 1, 0.5, True)
+    rc = lib.scasml_picard_tree(C.byref(prob), C.byref(plan), _lib.MODE_GENERATE, C.c_void_p(8), 4, 0, _lib.Rng(0, 0, 0, 0, 1, 0, 0), C.c_void_p(8), None, None, None, None)
+    assert rc == -2 and b"SCASML_MODE_MLP" in lib.scasml_last_error()
+
+
 @pytest.mark.parametrize("d,nd,nb", [(20, 120, 40), (6, 40, 12)])
 def test_gp_training_and_residual_on_the_second_equation_match_oracle(d, nd, nb):
     from oracle.equation import CubicReactionDiffusion

@@ -115,6 +115,18 @@ def test_training_matches_oracle(d, nd, nb):
     assert abs(gp.loss_function(sol, rhs_f=0.25 * np.ones(N)) - want) <= 1e-9 * want
     with pytest.raises(ValueError):
         gp.loss_function(np.zeros(3 * N + 1))
+    # the reference's own factor is the DENSE U sqrt(S + nugget) of the SVD (models/GP.py:260-266), not a triangular one: the same K_p, the same loss
+    Kp = L @ L.T
+    U, S, _ = np.linalg.svd(Kp)
+    dense = U * np.sqrt(S)[None, :]
+    assert np.abs(np.triu(dense, 1)).max() > 1e-3 and np.allclose(dense @ dense.T, Kp, rtol=1e-10, atol=1e-12)
+    assert abs(gp.loss_function(sol, L=dense) - gp.loss_function(sol)) <= 1e-7 * gp.loss_function(sol)
+    with pytest.raises(ValueError):
+        gp.loss_function(sol, L=L[:-1, :-1])
+    from scasml_gp_amd import _lib
+    from scasml_gp_amd.models.GP import GP_Grad_Dependent_Nonlinear
+    with pytest.raises(_lib.ScasmlError):                     # a factor handed to an object that has no collocation points yet: a clear error, not AttributeError
+        GP_Grad_Dependent_Nonlinear(gp.equation, compat=gp.compat).loss_function(sol, L=L)
 
 
 @pytest.mark.parametrize("f16_colloc", [False, True])
