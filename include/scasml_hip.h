@@ -271,6 +271,15 @@ int scasml_plan_site_kinds(const scasml_plan *plan_h, int32_t rank, int32_t worl
  * load_h[0 .. world) with the cost dealt to every rank.  Philox is keyed by tree site, so the sum over ranks does not depend on the dealing. */
 int32_t scasml_plan_deal_units(const scasml_plan *plan_h, int32_t world, const double *site_cost_h, uint8_t *owner_h, int32_t capacity, double *load_h);
 
+/* Host only: the workgroup -> tile map of the 128 x 128 FP64 update kernels (the trailing update of scasml_cholesky, the substitution
+ * updates of scasml_cholesky_inverse / scasml_trsm_*, scasml_gemm_nt_sub; models/GP.py:260-267, 599 are what they replace).  Workgroups
+ * b and b + 8 share an XCD's L2, 32 at a time: the 1-D grid deals every XCD super-tiles of 8 x 4 tiles (8 row panels + 4 column panels
+ * feed 32 tiles).  tri != 0 (needs nti == ntj): the super-tiles of the lower triangle only.  scasml_tile_order_blocks: workgroups to
+ * launch (< 0 on error); scasml_tile_order: 1 and the tile of workgroup `block` in ti_h / tj_h (tiles above the diagonal of a triangular
+ * launch are returned and skipped by the kernel), 0 (and -1, -1) when that workgroup has none, < 0 on error. */
+int64_t scasml_tile_order_blocks(int64_t nti, int64_t ntj, int32_t tri);
+int scasml_tile_order(int64_t block, int64_t nti, int64_t ntj, int32_t tri, int64_t *ti_h, int64_t *tj_h);
+
 /* Full gradient of the posterior mean, n_inf x (d+1), time last: GP.compute_gradient (:673-687). */
 int scasml_gp_gradient(const scasml_gp_model *gp_h, const float *points, int64_t n_inf,
                        float *grad, void *stream);

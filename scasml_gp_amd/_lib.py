@@ -78,6 +78,8 @@ SIGNATURES = {
     "scasml_gp_eval_sites": (C.c_int, [C.POINTER(GpModel), C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "scasml_plan_site_kinds": (C.c_int, [C.POINTER(Plan), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "scasml_plan_deal_units": (C.c_int32, [C.POINTER(Plan), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "scasml_tile_order_blocks": (C.c_int64, [C.c_int64, C.c_int64, C.c_int32]),
+    "scasml_tile_order": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "scasml_gp_gradient": (C.c_int, [C.POINTER(GpModel), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "scasml_gp_gram": (C.c_int, [C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "scasml_gp_newton_b": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),

@@ -9,7 +9,10 @@
 //   scasml_gemm_nt_sub     C -= A B^T              (FP64 MFMA, v_mfma_f64_16x16x4_f64, 64 x 64 tile per workgroup)
 //   scasml_trsm_right_lt   X <- X L^-T             (the panel solve of the right-looking factorisation)
 //   scasml_gemv_sub        y -= A x  or  y -= A^T x  (the block steps of the distributed substitutions)
+#include <stdlib.h>
+
 #include "common.hpp"
+#include "f64_tile_dma.hpp"
 
 namespace scasml {
 
@@ -38,7 +41,9 @@ __global__ __launch_bounds__(64 * WS * WS) void gemm_nt_sub_kernel(double *C, in
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double (*Pa)[TBX][kLDP] = reinterpret_cast<double (*)[TBX][kLDP]>(smem);
     double (*Pb)[TBX][kLDP] = reinterpret_cast<double (*)[TBX][kLDP]>(smem + 2 * TBX * kLDP);
-    const int64_t r0 = (int64_t)blockIdx.y * TBX, c0 = (int64_t)blockIdx.x * TBX;
+    int64_t ti = blockIdx.y, tj = blockIdx.x;
+    if (WS == 4 && !super_tile_of_block(blockIdx.x, (rows + TBX - 1) / TBX, (cols + TBX - 1) / TBX, false, ti, tj)) return;   // 1-D grid, super-tile order (common.hpp)
+    const int64_t r0 = ti * TBX, c0 = tj * TBX;
     if (tri.stride > 0 && tri.col0 + c0 / SCASML_DIST_BLOCK > tri.row0 + (r0 / SCASML_DIST_BLOCK) * tri.stride) return;   // block-uniform
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int wr = (wv / WS) * 32, wc = (wv % WS) * 32;
@@ -131,6 +136,20 @@ __global__ __launch_bounds__(64 * WS * WS) void gemm_nt_sub_kernel(double *C, in
                 const int64_t r = r0 + wr + 16 * i + l4 + 4 * e, c = c0 + wc + 16 * j + l15;
                 if (r < rows && c < cols) C[r * ldc + c] -= acc[i][j][e];
             }
+}
+
+// The 128 x 128 tile with LDS-DMA operand staging (f64_tile_dma.hpp): the large trailing updates of the distributed factorisation.
+// Same results as gemm_nt_sub_kernel<4>, bit for bit (same summation order); that kernel stays for operands the DMA cannot take
+// (odd leading dimensions, bases off 16 bytes).
+__global__ __launch_bounds__(kDmaThreads) void gemm_nt_sub_dma_kernel(double *C, int64_t ldc, int64_t rows, int64_t cols, const double *A, int64_t lda,
+                                                                      const double *B, int64_t ldb, int64_t K, TriMap tri) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    int64_t ti, tj;
+    if (!super_tile_of_block(blockIdx.x, (rows + kDmaTile - 1) / kDmaTile, (cols + kDmaTile - 1) / kDmaTile, false, ti, tj)) return;
+    const int64_t r0 = ti * kDmaTile, c0 = tj * kDmaTile;
+    if (tri.stride > 0 && tri.col0 + c0 / SCASML_DIST_BLOCK > tri.row0 + (r0 / SCASML_DIST_BLOCK) * tri.stride) return;   // block-uniform
+    const int ra = (int)(rows - r0 < kDmaTile ? rows - r0 : kDmaTile), rb = (int)(cols - c0 < kDmaTile ? cols - c0 : kDmaTile);
+    f64_tile_dma(smem, A + r0 * lda, lda, ra, B + c0 * ldb, ldb, rb, K, C + r0 * ldc + c0, ldc);
 }
 
 // ---------------------------------------------------------------------------------- X <- X L^-T (32 columns at a time)
@@ -232,11 +251,18 @@ extern "C" int scasml_gemm_nt_sub(double *C, int64_t ldc, int64_t rows, int64_t 
     const int tb = big ? 128 : 64;
     const int64_t gx = (cols + tb - 1) / tb, gy = (rows + tb - 1) / tb;
     if (gy > 65535) return fail(SCASML_ERR_UNSUPPORTED, "gemm_nt_sub: too many rows for one launch");
-    if (big) {
+    const bool dma = big && K >= 4 * kDmaNB && lda % 2 == 0 && ldb % 2 == 0 && ((uintptr_t)A | (uintptr_t)B) % 16 == 0 && lda < (1 << 21) && ldb < (1 << 21) &&
+                     ldc < (1 << 21) && !getenv("SCASML_F64_TILE_REGISTER_STAGED");   // (development: the register-staged tile for A/B runs)
+    if (dma) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_sub_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDmaLdsBytes) != hipSuccess)
+            return fail(SCASML_ERR_HIP, "gemm_nt_sub: cannot reserve %zu bytes of LDS", kDmaLdsBytes);
+        hipLaunchKernelGGL(gemm_nt_sub_dma_kernel, dim3(super_tile_grid(gy, gx, false)), dim3(kDmaThreads), kDmaLdsBytes, (hipStream_t)stream, C, ldc, rows, cols, A,
+                           lda, B, ldb, K, tri);
+    } else if (big) {
         constexpr size_t lds = gemm_lds_bytes(4);
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_sub_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return fail(SCASML_ERR_HIP, "gemm_nt_sub: cannot reserve %zu bytes of LDS", lds);
-        hipLaunchKernelGGL(gemm_nt_sub_kernel<4>, dim3((unsigned)gx, (unsigned)gy), dim3(1024), lds, (hipStream_t)stream, C, ldc, rows, cols, A, lda, B, ldb, K, tri);
+        hipLaunchKernelGGL(gemm_nt_sub_kernel<4>, dim3(super_tile_grid(gy, gx, false)), dim3(1024), lds, (hipStream_t)stream, C, ldc, rows, cols, A, lda, B, ldb, K, tri);
     } else {
         constexpr size_t lds = gemm_lds_bytes(2);
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_sub_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

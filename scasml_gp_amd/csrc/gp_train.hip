@@ -6,8 +6,11 @@
 // identity block (chol([[A,0],[0,I]]) = [[L,0],[0,I]]).
 //
 // Block order of K (models/GP.py:251-258): [u(dom), u(bdy), Lap(dom), dt(dom), div(dom)].
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "equations.hpp"
+#include "f64_tile_dma.hpp"
 
 namespace scasml {
 
@@ -91,6 +94,7 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int TB = 64;           // output tile edge of the NT = 2 kernels (grid geometry of the callers)
 constexpr int LDP = NB + 2;      // padded leading dimension: 2 (row LDP + k) mod 64 is distinct over a ds_read_b64 group (16 rows x 2 k)
 constexpr int64_t kOuterRows = 8 * NB;   // outer block of the two-level factorisation / substitutions
+constexpr int64_t kOuterBigRows = 16 * NB;   // outer panel of scasml_cholesky on matrices large enough for the look-ahead
 
 template <int NT>
 struct TileAcc {
@@ -131,12 +135,28 @@ __device__ __forceinline__ void mfma_tile_accumulate(const double (*As)[LDP], co
     }
 }
 
+// Output-tile addressing: ONE 32-bit byte offset per thread -- its place (row wr + l4, column wc + l15) inside the tile; tile rows < 128 and
+// ldc < 2^21, so below 2^32 bytes -- against a scalar base per (i, j, e) fragment element: the accesses take the SGPR-base form and no 64-bit
+// address lives in a VGPR (sixteen of them, hoisted out of the tile loop, spilled in the streamed kernel).
+template <int NT, int WS = 2>
+__device__ __forceinline__ uint32_t tile_thread_offset(int64_t ldc) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t wr = (wv / WS) * (16 * NT), wc = (wv % WS) * (16 * NT);
+    return ((wr + (lane >> 4)) * (uint32_t)ldc + wc + (lane & 15)) * 8u;
+}
+__device__ __forceinline__ double *tile_element(double *C, int64_t ldc, int i, int j, int e, uint32_t toff) {
+    return reinterpret_cast<double *>(reinterpret_cast<char *>(C + (int64_t)(16 * i + 4 * e) * ldc + 16 * j) + toff);
+}
+
 // C -= t (rows x cols valid)
 template <int NT, int WS = 2>
 __device__ __forceinline__ void mfma_tile_subtract(const TileAcc<NT> &t, double *C, int64_t ldc, int64_t rows, int64_t cols) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int wr = (wv / WS) * (16 * NT), wc = (wv % WS) * (16 * NT);
     const int l15 = lane & 15, l4 = lane >> 4;
+    const uint32_t toff = tile_thread_offset<NT, WS>(ldc);
+    constexpr int TBX = 16 * NT * WS;
+    const int nr = rows < TBX ? (int)rows : TBX, nc = cols < TBX ? (int)cols : TBX;   // 32-bit tests: sixteen 64-bit row indices per lane spilled
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -144,7 +164,7 @@ __device__ __forceinline__ void mfma_tile_subtract(const TileAcc<NT> &t, double 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = wr + 16 * i + l4 + 4 * e, c = wc + 16 * j + l15;
-                if (r < rows && c < cols) C[(int64_t)r * ldc + c] -= t.v[i][j][e];
+                if (r < nr && c < nc) *tile_element(C, ldc, i, j, e, toff) -= t.v[i][j][e];
             }
 }
 
@@ -153,28 +173,24 @@ __device__ __forceinline__ void mfma_tile_subtract(const TileAcc<NT> &t, double 
 // and fly under its matrix work, the tail is a subtraction and a store.  Measured at M = 35 008: the guarded read-modify-write
 // tail was 88 ms of a 391 ms factorisation (13 us per 128 x 128 tile against 34 us of matrix work).
 template <int NT, int WS = 2>
-__device__ __forceinline__ void mfma_tile_load_full(TileAcc<NT> &c, const double *C, int64_t ldc) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int wr = (wv / WS) * (16 * NT), wc = (wv % WS) * (16 * NT);
-    const int l15 = lane & 15, l4 = lane >> 4;
+__device__ __forceinline__ void mfma_tile_load_full(TileAcc<NT> &c, double *C, int64_t ldc) {
+    const uint32_t toff = tile_thread_offset<NT, WS>(ldc);
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) c.v[i][j][e] = C[(int64_t)(wr + 16 * i + l4 + 4 * e) * ldc + wc + 16 * j + l15];
+            for (int e = 0; e < 4; ++e) c.v[i][j][e] = *tile_element(C, ldc, i, j, e, toff);
 }
 template <int NT, int WS = 2>
 __device__ __forceinline__ void mfma_tile_store_diff_full(const TileAcc<NT> &c, const TileAcc<NT> &t, double *C, int64_t ldc) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int wr = (wv / WS) * (16 * NT), wc = (wv % WS) * (16 * NT);
-    const int l15 = lane & 15, l4 = lane >> 4;
+    const uint32_t toff = tile_thread_offset<NT, WS>(ldc);
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) C[(int64_t)(wr + 16 * i + l4 + 4 * e) * ldc + wc + 16 * j + l15] = c.v[i][j][e] - t.v[i][j][e];
+            for (int e = 0; e < 4; ++e) *tile_element(C, ldc, i, j, e, toff) = c.v[i][j][e] - t.v[i][j][e];
 }
 
 // The K loop shared by the Cholesky and triangular-solve updates: `fetch(kk, ra, rb)` loads this thread's elements
@@ -415,7 +431,11 @@ template <int NT, int WS>
 __global__ __launch_bounds__(64 * WS * WS) void chol_update_k_kernel(double *A, int64_t M, int64_t J, int64_t K, int64_t R0, int64_t col_end) {
     constexpr int TBX = 16 * NT * WS, THREADS = 64 * WS * WS, PER = TBX * NB / THREADS;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int64_t ti = blockIdx.y, tj = blockIdx.x;
+    int64_t ti = blockIdx.y, tj = blockIdx.x;
+    if (WS == 4) {   // 1-D grid in super-tile order (host_common.hpp)
+        const int64_t nt = (M - R0 + TBX - 1) / TBX;
+        if (!super_tile_of_block(blockIdx.x, nt, nt, true, ti, tj)) return;
+    }
     if (tj > ti) return;
     const int64_t r0 = R0 + ti * TBX, c0 = R0 + tj * TBX;
     if (r0 >= M || c0 >= col_end) return;
@@ -442,6 +462,19 @@ __global__ __launch_bounds__(64 * WS * WS) void chol_update_k_kernel(double *A, 
     }, [&] { if (interior) mfma_tile_load_full<NT, WS>(cin, Ct, M); }, t);
     if (interior) mfma_tile_store_diff_full<NT, WS>(cin, t, Ct, M);
     else mfma_tile_subtract<NT, WS>(t, Ct, M, M - r0, col_end - c0);
+}
+
+// The large trailing updates: the same 128 x 128 tile with its operand panels staged by LDS-DMA, three stages ahead (f64_tile_dma.hpp);
+// results bit-identical to chol_update_k_kernel<2, 4> (same summation order), which stays for matrices whose base is not 16-byte aligned.
+__global__ __launch_bounds__(kDmaThreads) void chol_update_dma_kernel(double *A, int64_t M, int64_t J, int64_t K, int64_t R0, int64_t col_end) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int64_t nt = (M - R0 + kDmaTile - 1) / kDmaTile;
+    int64_t ti, tj;
+    if (!super_tile_of_block(blockIdx.x, nt, nt, true, ti, tj) || tj > ti) return;
+    const int64_t r0 = R0 + ti * kDmaTile, c0 = R0 + tj * kDmaTile;
+    if (r0 >= M || c0 >= col_end) return;
+    const int ra = (int)(M - r0 < kDmaTile ? M - r0 : kDmaTile), rb = (int)(col_end - c0 < kDmaTile ? col_end - c0 : kDmaTile);
+    f64_tile_dma(smem, A + r0 * M + J, M, ra, A + c0 * M + J, M, rb, K, A + r0 * M + c0, M);
 }
 
 // ---------------------------------------------------------------------------------- TRSM
@@ -485,11 +518,13 @@ __global__ __launch_bounds__(256) void trsm_diag_kernel(const double *L, int64_t
 // tri != 0: only tiles on or below the block diagonal (c0 < r0 + TB) are updated -- the lower triangle of a symmetric result
 template <int TRANS, int NT, int WS>
 __global__ __launch_bounds__(64 * WS * WS) void trsm_update_kernel(const double *L, int64_t M, double *B, int64_t nrhs, int64_t J, int64_t K,
-                                                          int64_t rbase, int64_t rend, int tri) {
+                                                          int64_t rbase, int64_t rend, int tri, int64_t ntc) {
     constexpr int TBX = 16 * NT * WS, THREADS = 64 * WS * WS, PER = TBX * NB / THREADS;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int64_t r0 = rbase + (int64_t)blockIdx.y * TBX, c0 = (int64_t)blockIdx.x * TBX;
-    if (r0 >= rend || (tri && c0 >= r0 + TBX)) return;   // block-uniform
+    int64_t ti = blockIdx.y, tj = blockIdx.x;
+    if (WS == 4 && !super_tile_of_block(blockIdx.x, (rend - rbase + TBX - 1) / TBX, ntc, false, ti, tj)) return;   // 1-D grid, super-tile order
+    const int64_t r0 = rbase + ti * TBX, c0 = tj * TBX;
+    if (r0 >= rend || c0 >= nrhs || (tri && c0 >= r0 + TBX)) return;   // block-uniform
     const bool interior = r0 + TBX <= rend && c0 + TBX <= nrhs;   // block-uniform
     double *Ct = B + r0 * nrhs + c0;
     TileAcc<NT> t, cin;
@@ -668,10 +703,17 @@ static void launch_chol_update_ws(double *A, int64_t M, int64_t J, int64_t K, in
     constexpr int TBX = 16 * NT * WS;
     const int64_t nti = (M - R0 + TBX - 1) / TBX, ntj = (col_end - R0 + TBX - 1) / TBX;
     if (nti <= 0 || ntj <= 0) return;
+    if (WS == 4 && K >= 4 * kDmaNB && (uintptr_t)A % 16 == 0 && M < (1 << 21) && !getenv("SCASML_F64_TILE_REGISTER_STAGED")) {   // (development knob: A/B runs)
+        if (!reserve_lds(chol_update_dma_kernel, kDmaLdsBytes)) return;   // reported by check_launch through hipGetLastError
+        hipLaunchKernelGGL(chol_update_dma_kernel, dim3(super_tile_grid(nti, nti, true)), dim3(kDmaThreads), kDmaLdsBytes, s, A, M, J, K, R0, col_end);
+        return;
+    }
     auto kern = chol_update_k_kernel<NT, WS>;
     constexpr size_t lds = tile_lds_bytes<NT, WS>();
-    if (!reserve_lds(kern, lds)) return;   // reported by check_launch through hipGetLastError
-    hipLaunchKernelGGL(kern, dim3((unsigned)ntj, (unsigned)nti), dim3(64 * WS * WS), lds, s, A, M, J, K, R0, col_end);
+    if (!reserve_lds(kern, lds)) return;
+    // WS == 4: the kernel enumerates the lower triangle of nti x nti tiles itself (columns beyond col_end return at once)
+    const dim3 grid = WS == 4 ? dim3(super_tile_grid(nti, nti, true)) : dim3((unsigned)ntj, (unsigned)nti);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WS * WS), lds, s, A, M, J, K, R0, col_end);
 }
 
 template <int NT>
@@ -690,7 +732,8 @@ static void launch_trsm_update_ws(const double *L, int64_t M, double *B, int64_t
     auto kern = trsm_update_kernel<TRANS, NT, WS>;
     constexpr size_t lds = tile_lds_bytes<NT, WS>();
     if (!reserve_lds(kern, lds)) return;
-    hipLaunchKernelGGL(kern, dim3((unsigned)ntc, (unsigned)ntr), dim3(64 * WS * WS), lds, s, L, M, B, nrhs, J, K, rbase, rend, tri);
+    const dim3 grid = WS == 4 ? dim3(super_tile_grid(ntr, ntc, false)) : dim3((unsigned)ntc, (unsigned)ntr);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WS * WS), lds, s, L, M, B, nrhs, J, K, rbase, rend, tri, ntc);
 }
 
 template <int TRANS, int NT>
@@ -755,6 +798,16 @@ struct Lookahead {
     }
 };
 
+// Outer panel (factorisation) / row group (inverse) of a matrix of order M: kOuterRows below the look-ahead size, kOuterBigRows above it,
+// twice that from kOuterHugeFrom rows on (measured, scasml_cholesky: M = 35 008 277 / 279 ms at 512 / 1024 columns, M = 70 016 2007 / 1942 ms).
+constexpr int64_t kOuterHugeFrom = 49152;
+static int64_t outer_rows(int64_t M) {
+    static const int64_t forced = [] { const char *e = getenv("SCASML_CHOL_OUTER"); const int64_t v = e ? atoll(e) : 0; return v >= kOuterRows && v % kOuterRows == 0 ? v : 0; }();   // development
+    if (M < kLookaheadRows) return kOuterRows;
+    if (forced) return forced;
+    return M >= kOuterHugeFrom ? 2 * kOuterBigRows : kOuterBigRows;
+}
+
 extern "C" int scasml_cholesky(double *A, int64_t M, double nugget, int32_t *info_dev, void *stream) {
     if (!A || !info_dev || M < 1) return fail(SCASML_ERR_ARG, "cholesky: bad argument");
     if (M % NB) return fail(SCASML_ERR_UNSUPPORTED, "cholesky: M=%lld is not a multiple of %d (pad with an identity block)", (long long)M, NB);
@@ -764,16 +817,23 @@ extern "C" int scasml_cholesky(double *A, int64_t M, double nugget, int32_t *inf
     if (nugget != 0.0) hipLaunchKernelGGL(add_diag_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, A, M, nugget);
     // two-level right-looking factorisation: columns are eliminated NB at a time inside an outer panel of kOuter
     // columns (updates confined to that panel's columns), then the whole trailing matrix is updated once with K = kOuter
-    constexpr int64_t kOuter = kOuterRows;
+    // Large matrices (the look-ahead path) take outer panels of kOuterBigRows columns, factored as sub-panels of kOuterRows with one K = kOuterRows
+    // update between them: the trailing update's K doubles, i.e. the 256 KB read-modify-write of every 128 x 128 tile of C is paid half as often
+    // (tools/gemm_bench.py, C of 16 384^2: 49 TFLOP/s at K = 256, 59 at K = 512, 61.5 at K = 1024).
+    const int64_t kOuter = outer_rows(M);
     auto factor_panel = [&](int64_t J, int64_t jend, hipStream_t q) {   // columns [J, jend) final, all rows
-        for (int64_t k0 = J; k0 < jend; k0 += NB) {
-            // the diagonal block and the panel stay two launches: refactoring the block inside every panel workgroup (one launch fewer per
-            // step) measured SLOWER, 6.1 against 4.9 ms at M = 4224 (profiles/r05_cholesky_fused_diag_panel.txt)
-            hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(NB, NB), 0, q, A, M, k0, info_dev);
-            const int64_t rest = M - k0 - NB;
-            if (rest <= 0) break;
-            hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)((rest + 255) / 256)), dim3(256), 0, q, A, M, k0);
-            if (k0 + NB < jend) launch_chol_update<2>(A, M, k0, NB, k0 + NB, jend, q);
+        for (int64_t Js = J; Js < jend; Js += kOuterRows) {
+            const int64_t Je = Js + kOuterRows < jend ? Js + kOuterRows : jend;
+            for (int64_t k0 = Js; k0 < Je; k0 += NB) {
+                // the diagonal block and the panel stay two launches: refactoring the block inside every panel workgroup (one launch fewer per
+                // step) measured SLOWER, 6.1 against 4.9 ms at M = 4224 (profiles/r05_cholesky_fused_diag_panel.txt)
+                hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(NB, NB), 0, q, A, M, k0, info_dev);
+                const int64_t rest = M - k0 - NB;
+                if (rest <= 0) break;
+                hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)((rest + 255) / 256)), dim3(256), 0, q, A, M, k0);
+                if (k0 + NB < Je) launch_chol_update<2>(A, M, k0, NB, k0 + NB, Je, q);
+            }
+            if (Je < jend) launch_chol_update<2>(A, M, Js, Je - Js, Je, jend, q);   // sub-panel -> the rest of this outer panel's columns
         }
     };
     if (M < kLookaheadRows) {
@@ -929,12 +989,29 @@ extern "C" int scasml_cholesky_inverse(const double *L, int64_t M, double *A, vo
                 trsm_update<1>(L, M, A, M, J, jend - J, 0, J, J, 1, s);
         }
     } else {   // the same with the chains on the lookahead stream (struct Lookahead): groups of rows instead of panels of columns
+        // groups of outer_rows(M) rows, solved as sub-groups of kOuterRows with one K = kOuterRows update between them (scasml_cholesky's
+        // outer panels): the updates of everything beyond a group run at twice or four times the K, C read and written that much less often
+        const int64_t G = outer_rows(M);
+        auto forward_group = [&](int64_t J, int64_t jend, hipStream_t q) {
+            for (int64_t Js = J; Js < jend; Js += kOuterRows) {
+                const int64_t Je = Js + kOuterRows < jend ? Js + kOuterRows : jend;
+                forward_chain(Js, Je, q);
+                if (Je < jend) trsm_update<0>(L, M, A, M, Js, Je - Js, Je, jend, Je, 0, q);   // sub-group -> the group's later rows
+            }
+        };
+        auto backward_group = [&](int64_t J, int64_t jend, hipStream_t q) {
+            for (int64_t Je = jend; Je > J; Je -= kOuterRows) {
+                const int64_t Js = Je - J > kOuterRows ? Je - kOuterRows : J;
+                backward_chain(Js, Je, q);
+                if (Js > J) trsm_update<1>(L, M, A, M, Js, Je - Js, J, Js, Js, 1, q);         // sub-group -> the group's earlier rows
+            }
+        };
         Lookahead la;
         if (!la.open(s)) return fail(SCASML_ERR_HIP, "cholesky_inverse: cannot create the lookahead stream");
-        for (int64_t J = 0; J < M; J += kOuterRows) {
-            const int64_t jend = J + kOuterRows < M ? J + kOuterRows : M;
-            const int64_t next_end = jend + kOuterRows < M ? jend + kOuterRows : M;
-            forward_chain(J, jend, la.side);
+        for (int64_t J = 0; J < M; J += G) {
+            const int64_t jend = J + G < M ? J + G : M;
+            const int64_t next_end = jend + G < M ? jend + G : M;
+            forward_group(J, jend, la.side);
             la.chain_done();
             if (jend < M) {
                 la.side_waits_for_main();
@@ -947,10 +1024,10 @@ extern "C" int scasml_cholesky_inverse(const double *L, int64_t M, double *A, vo
             }
         }
         la.join();
-        for (int64_t jend = M; jend > 0; jend -= kOuterRows) {
-            const int64_t J = jend > kOuterRows ? jend - kOuterRows : 0;
-            const int64_t prev = J > kOuterRows ? J - kOuterRows : 0;
-            backward_chain(J, jend, la.side);
+        for (int64_t jend = M; jend > 0; jend -= G) {
+            const int64_t J = jend > G ? jend - G : 0;
+            const int64_t prev = J > G ? J - G : 0;
+            backward_group(J, jend, la.side);
             la.chain_done();
             if (J > 0) {
                 la.side_waits_for_main();

@@ -201,6 +201,20 @@ extern "C" int scasml_plan_site_kinds(const scasml_plan *plan_h, int32_t rank, i
 
 extern "C" int32_t scasml_point_stride(int32_t d) { return (d + 4 + 15) / 16 * 16; }
 
+// The tile order of the 128 x 128 FP64 update kernels (host_common.hpp), for inspection and the CPU tests
+extern "C" int64_t scasml_tile_order_blocks(int64_t nti, int64_t ntj, int32_t tri) {
+    if (nti < 1 || ntj < 1 || (tri && nti != ntj)) return fail(SCASML_ERR_ARG, "tile_order_blocks: bad argument");
+    return (int64_t)super_tile_grid(nti, ntj, tri != 0);
+}
+extern "C" int scasml_tile_order(int64_t block, int64_t nti, int64_t ntj, int32_t tri, int64_t *ti_h, int64_t *tj_h) {
+    if (!ti_h || !tj_h || block < 0 || nti < 1 || ntj < 1 || (tri && nti != ntj)) return fail(SCASML_ERR_ARG, "tile_order: bad argument");
+    int64_t ti = -1, tj = -1;
+    const bool live = super_tile_of_block(block, nti, ntj, tri != 0, ti, tj);
+    *ti_h = live ? ti : -1;
+    *tj_h = live ? tj : -1;
+    return live ? 1 : 0;
+}
+
 
 // The 768 x 4 coefficients of the table-driven inverse normal CDF (philox_normal.hpp includes the same file for the kernels).
 static const float kNormalTableHost[][4] = {

@@ -349,6 +349,30 @@ def test_root_bound_is_cached_for_the_callers_tensor_only():
     assert eng._root_bound(own, 7.5, True) == 7.5                             # a host bound wins
 
 
+@pytest.mark.parametrize("nti,ntj,tri", [(1, 1, 1), (7, 7, 1), (9, 9, 1), (33, 33, 1), (274, 274, 1), (5, 5, 0), (33, 11, 0), (9, 130, 0), (274, 91, 0)])
+def test_tile_order_of_the_update_kernels_covers_every_tile_once(lib, nti, ntj, tri):
+    """The 1-D grid of the 128 x 128 FP64 update kernels (host_common.hpp: super-tiles of 8 x 4 tiles per XCD, the lower triangle's only
+    when tri): every tile of the launch belongs to exactly one workgroup, the 32 consecutive workgroups of an XCD (b, b + 8, ...) lie in one
+    super-tile, and workgroups without a tile say so."""
+    nb = lib.scasml_tile_order_blocks(nti, ntj, tri)
+    assert nb > 0 and nb % (8 * 32) == 0
+    ti, tj = C.c_int64(), C.c_int64()
+    owner, supers = {}, {}
+    for b in range(nb):
+        r = lib.scasml_tile_order(b, nti, ntj, tri, C.byref(ti), C.byref(tj))
+        assert r in (0, 1)
+        if r == 0:
+            assert (ti.value, tj.value) == (-1, -1)
+            continue
+        assert (ti.value, tj.value) not in owner
+        owner[(ti.value, tj.value)] = b
+        supers.setdefault((b % 8, b // 8 // 32), set()).add((ti.value // 8, tj.value // 4))
+    want = {(i, j) for i in range(nti) for j in range(ntj) if not tri or j // 4 <= (i // 8) * 2 + 1}   # tiles above the diagonal inside a diagonal super-tile are dealt and skipped by the kernel
+    assert set(owner) == want and {(i, j) for i in range(nti) for j in range(ntj) if not tri or j <= i} <= want
+    assert all(len(v) == 1 for v in supers.values())
+    assert lib.scasml_tile_order_blocks(4, 5, 1) < 0 and lib.scasml_tile_order(0, 4, 4, 0, None, None) < 0
+
+
 def test_distributed_gp_memory_budget_for_configs4():
     """DESIGN.md section 6 prints DistCholesky.budget for BASELINE configs[4] (d = 250, 83 333 + 16 667 collocation points, 8 ranks); the numbers
     are pinned here, and tests/test_gpu_xl.py checks the same function against what the class really allocates at M = 70 001."""

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Development: time scasml_cholesky alone on a synthetic SPD matrix (run time does not depend on the values).
-    python tools/chol_bench.py [M] [reps]        prints ms and TFLOP/s (M^3/3 flops)"""
+    python tools/chol_bench.py [M] [reps] [inverse]       prints ms and TFLOP/s (M^3/3 flops; with `inverse` also K^-1 from the factor, 2 M^3/3)"""
 import os
 import sys
 
@@ -28,3 +28,15 @@ for r in range(reps + 1):
 best = min(ms[1:]) if reps else ms[0]      # reps = 0: ONE cold factorisation (counter passes)
 print("M=%d cholesky %.1f ms (runs %s) = %.1f TFLOP/s FP64" % (M, best, ["%.1f" % m for m in (ms[1:] if reps else ms)], M ** 3 / 3 / best / 1e9), flush=True)
 assert int(info.item()) == 0 or os.environ.get("SCASML_HIP_LIB"), "factorisation failed"
+if len(sys.argv) > 3 and sys.argv[3] == "inverse":
+    Ainv = A0          # the input is no longer needed
+    ms = []
+    for r in range(max(reps, 1) + 1):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(lib.scasml_cholesky_inverse(_lib.ptr(A), M, _lib.ptr(Ainv), s), "cholesky_inverse")
+        e1.record()
+        torch.cuda.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    best = min(ms[1:])
+    print("M=%d inverse from the factor %.1f ms (runs %s) = %.1f TFLOP/s FP64" % (M, best, ["%.1f" % m for m in ms[1:]], 2 * M ** 3 / 3 / best / 1e9), flush=True)

@@ -1,0 +1,386 @@
+// Development microbenchmark: WHERE the time of one 128 x 128 FP64 update tile goes (C -= A B^T on v_mfma_f64_16x16x4_f64, the tile of
+// dist_linalg.hip's gemm_nt_sub_kernel<4> / gp_train.hip's chol_update_k_kernel<2, 4>, interior tiles only).  Every workgroup stamps the
+// 100 MHz real-time counter at its phase boundaries and notes the CU it ran on, so that the per-CU timeline (gaps between consecutive
+// workgroups included) can be rebuilt on the host.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/ubench_f64_tile.hip -o tools/ubench_f64_tile
+//   tools/ubench_f64_tile [n=16384] [K=256] [variant=0]
+// variant 0: the product's tile (C loaded under the last chunk);  1: C loaded at the start of the tile;  2: no C traffic at all (result
+// discarded but for one element);  3: operands not fetched after the first chunk (LDS reused: matrix work + C traffic only)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <map>
+#include <vector>
+
+constexpr int kNB = 32, kLDP = kNB + 2, WS = 4, TBX = 32 * WS, THREADS = 64 * WS * WS, PER = TBX * kNB / THREADS;
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+constexpr int kStamps = 8;
+
+// -DNO_STAMPS: the same kernels without the clock reads and without the waits that exist only to delimit phases (the plain timing)
+#ifdef NO_STAMPS
+__device__ __forceinline__ uint64_t now() { return 0; }
+#define PHASE_WAIT(x)
+#else
+__device__ __forceinline__ uint64_t now() { return __builtin_amdgcn_s_memrealtime(); }
+#define PHASE_WAIT(x) asm volatile(x)
+#endif
+
+template <int VARIANT>
+__global__ __launch_bounds__(THREADS) void tile_kernel(double *C, int64_t ldc, int64_t n, const double *A, int64_t lda, const double *B, int64_t ldb,
+                                                       int64_t K, uint64_t *stamps) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double (*Pa)[TBX][kLDP] = reinterpret_cast<double (*)[TBX][kLDP]>(smem);
+    double (*Pb)[TBX][kLDP] = reinterpret_cast<double (*)[TBX][kLDP]>(smem + 2 * TBX * kLDP);
+    const int64_t nt = n / TBX, bid = blockIdx.x;
+    const int64_t r0 = (bid / nt) * TBX, c0 = (bid % nt) * TBX;
+    uint64_t ts[kStamps];
+    ts[0] = now();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wr = (wv / WS) * 32, wc = (wv % WS) * 32;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    f64x4 acc[2][2], cin[2][2];
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    double ra[PER], rb[PER];
+    auto fetch = [&](int64_t kk) {
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int idx = threadIdx.x + e * THREADS, rr = idx / kNB, cc = idx % kNB;
+            ra[e] = A[(r0 + rr) * lda + kk + cc];
+            rb[e] = B[(c0 + rr) * ldb + kk + cc];
+        }
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int idx = threadIdx.x + e * THREADS, rr = idx / kNB, cc = idx % kNB;
+            Pa[buf][rr][cc] = ra[e];
+            Pb[buf][rr][cc] = rb[e];
+        }
+    };
+    auto accumulate = [&](int cur) {
+#pragma unroll
+        for (int k0 = 0; k0 < kNB; k0 += 4) {
+            double av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i] = Pa[cur][wr + 16 * i + l15][k0 + l4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[j] = Pb[cur][wc + 16 * j + l15][k0 + l4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    double *Ct = C + (r0 + wr + l4) * ldc + c0 + wc + l15;
+    auto load_c = [&] {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cin[i][j][e] = Ct[(int64_t)(16 * i + 4 * e) * ldc + 16 * j];
+    };
+    if (VARIANT == 1) load_c();
+    fetch(0);
+    park(0);
+    __syncthreads();
+    ts[1] = now();   // prologue done: first chunk in LDS
+    int cur = 0;
+    for (int64_t kk = 0; kk + kNB < K; kk += kNB) {
+        if (VARIANT != 3) fetch(kk + kNB);
+        accumulate(cur);
+        if (VARIANT != 3) {
+            park(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+    ts[2] = now();   // K loop but for its last chunk issued
+    if (VARIANT == 0 || VARIANT == 3) load_c();
+    accumulate(cur);
+#ifndef NO_STAMPS
+    asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[1][1][3]));   // the last matrix instructions have delivered
+#endif
+    ts[3] = now();
+    if (VARIANT == 2) {
+        if (acc[0][0][0] + acc[0][1][1] + acc[1][0][2] + acc[1][1][3] == 123.456) Ct[0] = acc[1][1][3];
+    } else {
+        PHASE_WAIT("s_waitcnt vmcnt(0)");
+        ts[4] = now();   // C has arrived
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Ct[(int64_t)(16 * i + 4 * e) * ldc + 16 * j] = cin[i][j][e] - acc[i][j][e];
+    }
+    if (VARIANT == 2) ts[4] = now();
+    ts[5] = now();   // stores issued
+    PHASE_WAIT("s_waitcnt vmcnt(0)");
+    ts[6] = now();   // stores acknowledged
+#ifndef NO_STAMPS
+    if (threadIdx.x == 0) {
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        ts[7] = ((uint64_t)(xcc & 0xf) << 32) | hw;
+        for (int i = 0; i < kStamps; ++i) stamps[bid * kStamps + i] = ts[i];
+    }
+#endif
+}
+
+// ---- variant 4: operands staged by LDS-DMA (global_load_lds_dwordx4), 16 columns of K per stage, four stages in flight ----------------
+// stage = [A rows 0..127][B rows 0..127], a row = 16 doubles = 8 granules of 16 bytes, unpadded (the DMA writes 64 lanes x 16 bytes
+// contiguously: 8 rows per wave instruction); granule g of row r sits in slot g ^ ((r >> 1) & 7), so that the 16 rows x 2 k of a
+// ds_read_b64 pass fall on 64 distinct banks.  Wave w stages rows 8 w .. 8 w + 7 of both operands: two DMA instructions per stage.
+constexpr int kNBD = 16, kStages = 4, kStageBytes = 2 * TBX * kNBD * 8, kOpBytes = TBX * kNBD * 8;
+
+__device__ __forceinline__ void glds16(const void *gsrc_uniform, uint32_t lane_byte_offset, uint32_t lds_byte_addr_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(lane_byte_offset), "s"(gsrc_uniform), "s"(lds_byte_addr_uniform)
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__global__ __launch_bounds__(THREADS) void tile_dma_kernel(double *C, int64_t ldc, int64_t n, const double *A, int64_t lda, const double *B, int64_t ldb,
+                                                           int64_t K, uint64_t *stamps) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int64_t nt = n / TBX, bid = blockIdx.x;
+    const int64_t r0 = (bid / nt) * TBX, c0 = (bid % nt) * TBX;
+    uint64_t ts[kStamps];
+    ts[0] = now();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wvs = __builtin_amdgcn_readfirstlane(wv);
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
+    const int wr = (wv / WS) * 32, wc = (wv % WS) * 32;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    // DMA: this lane's source inside a chunk of either operand
+    const uint32_t drow = 8 * wvs + (lane >> 3), dslot = lane & 7, dgran = dslot ^ ((drow >> 1) & 7);
+    const uint32_t offa = drow * (uint32_t)lda * 8u + dgran * 16u, offb = drow * (uint32_t)ldb * 8u + dgran * 16u;
+    const double *Abase = A + r0 * lda, *Bbase = B + c0 * ldb;
+    auto stage = [&](int64_t c) {   // chunk c -> slot c % kStages
+        const uint32_t dst = lds_base + (uint32_t)(c % kStages) * kStageBytes + (uint32_t)wvs * 1024u;
+        glds16(Abase + c * kNBD, offa, dst);
+        glds16(Bbase + c * kNBD, offb, dst + kOpBytes);
+    };
+    // fragment reads: byte offsets inside a stage, the K step enters by XOR (k0 * 8 flips granule bits 1..2)
+    uint32_t fa[2], fb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const uint32_t ra_ = wr + 16 * i + l15, rb_ = wc + 16 * i + l15;
+        fa[i] = ra_ * 128u + ((((uint32_t)l4 >> 1) ^ ((ra_ >> 1) & 7)) * 16u) + ((uint32_t)l4 & 1) * 8u;
+        fb[i] = kOpBytes + rb_ * 128u + ((((uint32_t)l4 >> 1) ^ ((rb_ >> 1) & 7)) * 16u) + ((uint32_t)l4 & 1) * 8u;
+    }
+    f64x4 acc[2][2], cin[2][2];
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    const char *sm = reinterpret_cast<const char *>(smem);
+    auto compute = [&](int64_t c) {
+        const char *st = sm + (c % kStages) * kStageBytes;
+#pragma unroll
+        for (int k0 = 0; k0 < kNBD; k0 += 4) {
+            double av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const double *>(st + (fa[i] ^ (uint32_t)(k0 * 8)));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const double *>(st + (fb[j] ^ (uint32_t)(k0 * 8)));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    // ldc < 0: the tile stored contiguously (128 x 128 doubles per tile) -- what the strided rows of C cost (DRAM pages, TLB reach)
+    double *Ct = ldc > 0 ? C + (r0 + wr + l4) * ldc + c0 + wc + l15 : C + bid * (TBX * TBX) + (wr + l4) * TBX + wc + l15;
+    if (ldc < 0) ldc = TBX;
+    const int64_t nc = K / kNBD;   // >= 4
+    stage(0);
+    stage(1);
+    stage(2);
+    ts[1] = now();
+    for (int64_t c = 0; c + 2 < nc; ++c) {
+        wait_vm<4>();   // chunk c has landed (this wave's share; chunks c + 1, c + 2 may fly)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (c + 3 < nc) stage(c + 3);   // into the slot chunk c - 1 was read from: every wave is past that
+        compute(c);
+    }
+    ts[2] = now();
+    // chunk nc - 2: chunk nc - 1 may fly; then the output tile's loads, under the last two chunks' matrix work
+    wait_vm<2>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cin[i][j][e] = Ct[(int64_t)(16 * i + 4 * e) * ldc + 16 * j];
+    compute(nc - 2);
+    wait_vm<16>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    compute(nc - 1);
+#ifndef NO_STAMPS
+    asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[1][1][3]));
+#endif
+    ts[3] = now();
+    wait_vm<0>();
+    ts[4] = now();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Ct[(int64_t)(16 * i + 4 * e) * ldc + 16 * j] = cin[i][j][e] - acc[i][j][e];
+    ts[5] = now();
+    PHASE_WAIT("s_waitcnt vmcnt(0)");
+    ts[6] = now();
+#ifndef NO_STAMPS
+    if (threadIdx.x == 0) {
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        ts[7] = ((uint64_t)(xcc & 0xf) << 32) | hw;
+        for (int i = 0; i < kStamps; ++i) stamps[bid * kStamps + i] = ts[i];
+    }
+#endif
+}
+
+__global__ void fill_kernel(double *p, int64_t n, uint32_t seed) {   // non-zero operands: the matrix cores draw less power on zeros
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t h = (uint32_t)i * 2654435761u + seed;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        p[i] = ((double)h / 4294967296.0 - 0.5) * 1e-2;
+    }
+}
+
+#define CHECK(x)                                                                          \
+    do {                                                                                  \
+        hipError_t e_ = (x);                                                              \
+        if (e_ != hipSuccess) {                                                           \
+            fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));                       \
+            return 1;                                                                     \
+        }                                                                                 \
+    } while (0)
+
+template <int V>
+static int run(int64_t n, int64_t K) {
+    double *A, *B, *C;
+    uint64_t *st;
+    const int64_t tiles = (n / TBX) * (n / TBX);
+    CHECK(hipMalloc(&A, n * K * 8));
+    CHECK(hipMalloc(&B, n * K * 8));
+    CHECK(hipMalloc(&C, n * n * 8));
+    CHECK(hipMalloc(&st, tiles * kStamps * 8));
+    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, A, n * K, 1u);
+    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, B, n * K, 2u);
+    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, C, n * n, 3u);
+    const size_t lds = V == 4 ? (size_t)kStages * kStageBytes : (size_t)2 * 2 * TBX * kLDP * 8;
+    auto kern = V == 4 ? tile_dma_kernel : tile_kernel<(V == 4 ? 0 : V)>;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int r = 0; r < 4; ++r) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(THREADS), lds, 0, C, getenv("UBENCH_BLOCKED_C") ? (int64_t)-1 : n, n, A, K, B, K, K, st);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipDeviceSynchronize());
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (r && ms < best) best = ms;
+    }
+    std::vector<uint64_t> h(tiles * kStamps);
+    CHECK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
+    // phase averages (us; the counter runs at 100 MHz) and the per-CU gaps between one workgroup's end and the next one's start
+    double ph[6] = {0, 0, 0, 0, 0, 0};
+    std::map<uint64_t, std::vector<std::pair<uint64_t, uint64_t>>> per_cu;
+    for (int64_t t = 0; t < tiles; ++t) {
+        const uint64_t *s = &h[t * kStamps];
+        for (int i = 0; i < 6; ++i) ph[i] += (double)(s[i + 1] - s[i]) * 0.01;
+        const uint64_t hw = s[7];
+        per_cu[((hw >> 32) << 16) | ((hw >> 8) & 0xff)].push_back({s[0], s[6]});   // (XCC_ID, SE_ID | SH_ID | CU_ID of HW_ID): one label per CU
+    }
+    double gap = 0, span = 0;
+    int64_t gaps = 0;
+    for (auto &kv : per_cu) {
+        auto &v = kv.second;
+        std::sort(v.begin(), v.end());
+        for (size_t i = 1; i < v.size(); ++i) {
+            gap += (double)((int64_t)v[i].first - (int64_t)v[i - 1].second) * 0.01;
+            ++gaps;
+        }
+        span += (double)(v.back().second - v.front().first) * 0.01 / (double)v.size();
+    }
+    printf("variant %d n=%lld K=%lld: %.3f ms = %.1f TFLOP/s, %.2f us per tile slot; labels (CUs seen) %zu\n", V, (long long)n, (long long)K, best,
+           2.0 * n * n * K / best / 1e9, best * 1e3 / ((double)tiles / 256.0), per_cu.size());
+    printf("  per tile, us: prologue %.2f | K loop %.2f | last chunk %.2f | wait for C %.2f | issue stores %.2f | stores acknowledged %.2f | sum %.2f\n",
+           ph[0] / tiles, ph[1] / tiles, ph[2] / tiles, ph[3] / tiles, ph[4] / tiles, ph[5] / tiles,
+           (ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5]) / tiles);
+    printf("  per CU label: mean gap between a workgroup's end and the next one's start %.2f us (%lld gaps); mean (last end - first start) / workgroups %.2f us\n",
+           gaps ? gap / gaps : 0.0, (long long)gaps, span / per_cu.size());
+    hipFree(A); hipFree(B); hipFree(C); hipFree(st);
+    return 0;
+}
+
+
+// variant 4 against variant 0 from the same C: the two sum K in the same order, so the results must agree bit for bit
+static int verify(int64_t n, int64_t K) {
+    double *A, *B, *C0, *C4;
+    uint64_t *st;
+    const int64_t tiles = (n / TBX) * (n / TBX);
+    CHECK(hipMalloc(&A, n * K * 8));
+    CHECK(hipMalloc(&B, n * K * 8));
+    CHECK(hipMalloc(&C0, n * n * 8));
+    CHECK(hipMalloc(&C4, n * n * 8));
+    CHECK(hipMalloc(&st, tiles * kStamps * 8));
+    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, A, n * K, 1u);
+    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, B, n * K, 2u);
+    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, C0, n * n, 3u);
+    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, C4, n * n, 3u);
+    const size_t lds0 = (size_t)2 * 2 * TBX * kLDP * 8, lds4 = (size_t)kStages * kStageBytes;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(tile_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0));
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(tile_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+    hipLaunchKernelGGL(tile_kernel<0>, dim3((unsigned)tiles), dim3(THREADS), lds0, 0, C0, n, n, A, K, B, K, K, st);
+    hipLaunchKernelGGL(tile_dma_kernel, dim3((unsigned)tiles), dim3(THREADS), lds4, 0, C4, n, n, A, K, B, K, K, st);
+    CHECK(hipDeviceSynchronize());
+    std::vector<double> h0(n * n), h4(n * n);
+    CHECK(hipMemcpy(h0.data(), C0, n * n * 8, hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(h4.data(), C4, n * n * 8, hipMemcpyDeviceToHost));
+    double worst = 0, ref = 0;
+    int64_t differ = 0;
+    for (int64_t i = 0; i < n * n; ++i) {
+        const double d = h0[i] > h4[i] ? h0[i] - h4[i] : h4[i] - h0[i];
+        if (d > worst) worst = d;
+        if (d != 0) ++differ;
+        const double a = h0[i] < 0 ? -h0[i] : h0[i];
+        if (a > ref) ref = a;
+    }
+    printf("verify n=%lld K=%lld: max |variant 4 - variant 0| = %.3e (max |C| %.3e), %lld of %lld elements differ\n", (long long)n, (long long)K, worst, ref,
+           (long long)differ, (long long)(n * n));
+    return worst == 0 ? 0 : 3;
+}
+
+int main(int argc, char **argv) {
+    const int64_t n = argc > 1 ? atoll(argv[1]) : 16384, K = argc > 2 ? atoll(argv[2]) : 256;
+    const int v = argc > 3 ? atoi(argv[3]) : 0;
+    if (n % TBX || K % kNB) return 2;
+    switch (v) {
+        case 0: return run<0>(n, K);
+        case 1: return run<1>(n, K);
+        case 2: return run<2>(n, K);
+        case 3: return run<3>(n, K);
+        case 4: return run<4>(n, K);
+        case 5: return verify(n, K);
+    }
+    return 2;
+}
