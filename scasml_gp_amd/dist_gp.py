@@ -17,6 +17,9 @@ Right-looking factorisation, per block column k (1367 steps at M = 350 000):
   3. ONE all-gather assembles the column panel (all blocks (i, k), i > k, in global order: (nb - k - 1) * 512 KB);
   4. every rank updates its trailing block rows with ONE launch: R[suffix, k+1:] -= P_mine P_all^T on the FP64 matrix cores,
      tiles above the block diagonal skipped (scasml_gemm_nt_sub with its triangular map).
+Block columns are eliminated in PAIRS (factor(pair=True), the default): steps 1-3 for column k, step 4 for block column k + 1 alone, steps
+1-3 for column k + 1, then ONE trailing update with K = 512 by both panels -- the same collectives, half the trailing launches, and the
+128 x 128 update tile's fixed cost (the read-modify-write of C) paid once per 512 columns of K.
 Collective volume: the panel of step k reaches every rank once, M^2 / 2 * 8 B = 490 GB per rank over the whole run -- over
 xGMI rings (7 links x ~50 GB/s effective each way) a few seconds against ~60 s of FP64 MFMA work (M^3 / 3 = 1.4e16 flop / 8 GPUs).
 
@@ -181,7 +184,8 @@ class DistCholesky:
                "diag_factors": nblk * blk + 2 * ((nblk + GROUP - 1) // GROUP) * GROUP * GROUP * blk,
                "collocation_f32": (n_dom + n_bdy) * (d + 1) * 4,
                # factor(), per step: the send buffer, the gathered panel and its reordered copy; with look-ahead the panels of steps k and k + 1 coexist
-               "panel_exchange_peak": cnt * blk + world * cnt * blk + 2 * (nblk - 1) * blk,
+               # the two panels of a pair side by side (_pair_chain), again in two generations
+               "panel_exchange_peak": cnt * blk + world * cnt * blk + 2 * (nblk - 1) * blk + 2 * 2 * (nblk - 2) * blk,
                "vectors": 6 * Mp * 8 + 64 * Mp * 8}            # solve() / matvec(): right-hand side, y, x, accumulator, local rows, output; the 64 row groups' partial sums of the ordered sweep
         out["total"] = sum(v for k, v in out.items() if k not in ("M", "block_rows", "owned_block_rows"))
         return out
@@ -256,34 +260,71 @@ class DistCholesky:
                                               C.c_void_p(P.data_ptr() + 8 * (col0 - k - 1) * BLK * BLK), BLK, BLK,
                                               self.mine[s0], w, col0, s), "gemm_nt_sub")
 
-    def factor(self, lookahead=True):
-        """Right-looking blocked Cholesky over the block rows.  With ``lookahead`` the chain of block column k + 1 -- diagonal factor,
-        broadcast, panel solve, all-gather: short dependent kernels and latency-bound collectives -- runs on a second stream while the
-        caller's stream applies panel k to the block columns beyond k + 1 (the single-GPU factorisation gained 8 % from the same
-        reordering).  The only orderings needed: the chain of k + 1 follows the update of block column k + 1 by panel k,
-        and every update by panel k + 1 follows that chain."""
+    def _update_pair(self, k, P2, col0, ncols):
+        """Trailing update by the PAIR of block columns (k, k + 1) on the current stream, block columns [col0, col0 + ncols): ONE product with
+        K = 2 * BLK -- this rank's block rows > k + 1, their column blocks k and k + 1 (adjacent in R), against the two gathered panels side by
+        side (P2: rows of blocks k + 2 .., 2 * BLK columns).  The 128 x 128 tile's read-modify-write of C is paid once per 512 columns of K
+        (scasml_gemm_nt_sub on a C of 16 384^2: 49.5 TFLOP/s at K = 256, 59 at K = 512; profiles/r06_f64_update_tile.txt)."""
+        lib, s, Mp, w = self.lib, _lib.stream_ptr(), self.Mp, self.comm.world
+        s0 = self._slot0(k + 1)
+        rows = (len(self.mine) - s0) * BLK
+        if rows and ncols > 0:
+            _lib.check(lib.scasml_gemm_nt_sub(self._ptr(self.R, s0 * BLK, col0 * BLK, Mp), Mp, rows, ncols * BLK,
+                                              self._ptr(self.R, s0 * BLK, k * BLK, Mp), Mp,
+                                              C.c_void_p(P2.data_ptr() + 8 * (col0 - k - 2) * BLK * 2 * BLK), 2 * BLK, 2 * BLK,
+                                              self.mine[s0], w, col0, s), "gemm_nt_sub")
+
+    def _pair_chain(self, k):
+        """Block columns k and k + 1 on the current stream: panel k, its update of block column k + 1 alone, panel k + 1.  -> the two panels
+        side by side for the block rows > k + 1, or None when nothing lies beyond them."""
+        torch = _lib.require_gpu()
+        Pk = self._panel(k)
+        if Pk is None:
+            return None
+        self._update(k, Pk, k + 1, 1)
+        Pk1 = self._panel(k + 1)
+        if Pk1 is None:
+            return None
+        return torch.cat([Pk[BLK:], Pk1], dim=1)
+
+    def factor(self, lookahead=True, pair=True):
+        """Right-looking blocked Cholesky over the block rows.  ``pair`` (default): block columns are eliminated two at a time and the
+        trailing matrix is updated once per pair with K = 512 (_update_pair); the same collectives as one column at a time, half the
+        trailing launches.  With ``lookahead`` the chain of the next pair -- diagonal factors, broadcasts, panel solves, all-gathers, the one
+        narrow update between its two columns: short dependent kernels and latency-bound collectives -- runs on a second stream while the
+        caller's stream applies the current pair to the block columns beyond the next one (the single-GPU factorisation gained 8 % from the
+        same reordering).  The only orderings needed: the chain of the next pair follows the update of ITS block columns by
+        the current pair, and every update by the next pair follows that chain.  lookahead=False issues the same operations on one stream
+        (bit-identical results); pair=False is the one-column-at-a-time sequence of round 5."""
         torch = _lib.require_gpu()
         cm, nb = self.comm, self.nblk
         main = torch.cuda.current_stream()
         side = torch.cuda.Stream() if lookahead else main
-        P = self._panel(0)
+        step = 2 if pair else 1
+        chain = self._pair_chain if pair else self._panel
+        update = self._update_pair if pair else self._update
+        P = chain(0)
         ready = torch.cuda.Event()
         ready.record(main)
-        for k in range(nb - 1):
-            main.wait_event(ready)                                         # panel k (and diag k) are complete
-            self._update(k, P, k + 1, 1)                                   # block column k + 1 first: the next chain needs only this
+        k = 0
+        while P is not None:
+            main.wait_event(ready)                                         # the panels of this step are complete
+            first = k + step                                               # first block column beyond this step
+            nxt = min(step, nb - first)
+            update(k, P, first, nxt)                                       # the next step's own block columns first: its chain needs only these
             done = torch.cuda.Event()
             done.record(main)
             side.wait_event(done)
             with torch.cuda.stream(side):
-                Pn = self._panel(k + 1)
+                Pn = chain(first)
                 ready = torch.cuda.Event()
                 ready.record(side)
-            self._update(k, P, k + 2, nb - k - 2)                          # the rest of the trailing matrix, under the chain of k + 1
+            update(k, P, first + nxt, nb - first - nxt)                    # the rest of the trailing matrix, under the next chain
             if Pn is not None:
                 Pn.record_stream(main)
             P.record_stream(side)
             P = Pn
+            k = first
         main.wait_event(ready)
         # a failed pivot is seen by the block's owner only: every rank learns of it through ONE all-reduce after the loop, so that all
         # ranks raise together instead of the others walking into the collectives of solve() without the one that raised

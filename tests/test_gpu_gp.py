@@ -90,6 +90,41 @@ def test_cholesky_lookahead_path_on_a_side_stream():
     assert float(torch.triu(L, 1).abs().max()) == 0.0
     assert float(err_inv) < 1e-9          # condition number ~ 1e3 here
 
+def test_dma_staged_update_tile_equals_the_register_staged_tile_bit_for_bit(monkeypatch):
+    """The 128 x 128 FP64 update tile with LDS-DMA operand staging (csrc/f64_tile_dma.hpp) sums K in the order of the register-staged tile it
+    replaces in the large trailing updates: the factor of a ragged matrix (edge tiles of 32 valid rows) and a ragged scasml_gemm_nt_sub
+    (edge tiles on both sides, K not a multiple of the old 32-column chunk's pair) come out bit-identical either way, and right."""
+    import torch
+    from scasml_gp_amd import _lib
+    lib = _lib.load()
+    s = _lib.stream_ptr()
+    M = 8192 + 9 * 32
+    g = torch.Generator(device="cuda").manual_seed(11)
+    R = torch.randn((M, 640), dtype=torch.float64, device="cuda", generator=g)
+    A = R @ R.T + 40.0 * torch.eye(M, dtype=torch.float64, device="cuda")
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    rows, cols, K = 4096 + 96, 4096 + 224, 352
+    Ap = torch.randn((rows, K + 32), dtype=torch.float64, device="cuda", generator=g)
+    Bp = torch.randn((cols, K + 32), dtype=torch.float64, device="cuda", generator=g)
+    C0 = torch.randn((rows, cols), dtype=torch.float64, device="cuda", generator=g)
+    out = {}
+    for mode in ("dma", "registers"):
+        if mode == "registers":
+            monkeypatch.setenv("SCASML_F64_TILE_REGISTER_STAGED", "1")
+        L = A.clone()
+        _lib.check(lib.scasml_cholesky(_lib.ptr(L), M, 0.0, _lib.ptr(info), s), "chol")
+        Cm = C0.clone()
+        _lib.check(lib.scasml_gemm_nt_sub(_lib.ptr(Cm), cols, rows, cols, _lib.ptr(Ap), K + 32, _lib.ptr(Bp), K + 32, K, 0, 0, 0, s), "gemm_nt_sub")
+        torch.cuda.synchronize()
+        assert int(info.item()) == 0
+        out[mode] = (L, Cm)
+    monkeypatch.delenv("SCASML_F64_TILE_REGISTER_STAGED")
+    assert torch.equal(out["dma"][0], out["registers"][0]) and torch.equal(out["dma"][1], out["registers"][1])
+    want = C0 - Ap[:, :K] @ Bp[:, :K].T
+    assert float((out["dma"][1] - want).abs().max()) < 1e-11 * float(want.abs().max()) * K
+    assert float((out["dma"][0] - torch.linalg.cholesky(A)).abs().max()) < 1e-10 * 40 * float(A.abs().max()) ** 0.5
+
+
 @pytest.mark.parametrize("d,nd,nb", [(4, 30, 10), (20, 120, 40)])
 def test_training_matches_oracle(d, nd, nb):
     gp, ora, dom, bdy = _setup(d, nd, nb, seed=2)
