@@ -191,10 +191,17 @@ class DistCholesky:
         return out
 
     # -------------------------------------------------------------------------------------------- Gram
-    def build(self):
+    def build(self, reuse=None):
+        """``reuse``: the panel of a finished factorisation of the same shape, overwritten in place -- a second factorisation then needs no second
+        panel and does not depend on the caching allocator handing a 100+ GB block back (at M = 140 002, one 157 GB panel on a 288 GB GPU, the
+        freed panel stayed reserved and the second one did not fit)."""
         torch = _lib.require_gpu()
         lib, s = self.lib, _lib.stream_ptr()
-        self.R = torch.zeros((len(self.mine) * BLK, self.Mp), dtype=torch.float64, device="cuda")
+        shape = (len(self.mine) * BLK, self.Mp)
+        if reuse is not None and tuple(reuse.shape) == shape and reuse.dtype == torch.float64 and reuse.is_contiguous():
+            self.R = reuse.zero_()
+        else:
+            self.R = torch.zeros(shape, dtype=torch.float64, device="cuda")
         for slot, i in enumerate(self.mine):
             row0 = i * BLK
             nrows = max(0, min(BLK, self.M - row0))
@@ -573,11 +580,12 @@ class DistributedGP:
             # z4 = time_der_rep(sol).astype(float16) (:719); right_vector = solve(float16(K_p), z) (:268, 599): a second factorisation, of the
             # matrix with the float16-rounded diagonal, in the memory of the first
             _lib.check(lib.scasml_round16(C.c_void_p(b.data_ptr() + 8 * (2 * N + Nb)), N, s), "round16")
-            ch.R = None
+            panel, ch.R = ch.R, None
             ch.diag, ch.ninv, ch._scratch = [None] * ch.nblk, None, None
             torch.cuda.empty_cache()
             ch2 = DistCholesky(d, 1.0 / float(gp.sigma) ** 2, x_t_domain, x_t_boundary, gp.nugget, self.comm, compat_idx=compat_idx,
-                               round_diag=True, f16_graph=graph, f16_extra=getattr(gp, "_f16_extra", 0)).build().factor()
+                               round_diag=True, f16_graph=graph, f16_extra=getattr(gp, "_f16_extra", 0)).build(reuse=panel).factor()
+            del panel
             rv = ch2.solve(b)
             self.chol = ch2
         gp.N_domain, gp.N_boundary, gp.phi_dim = N, Nb, M

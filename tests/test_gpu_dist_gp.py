@@ -55,6 +55,12 @@ def test_world1_factor_and_solve_match_the_single_gpu_path():
     plain = DistCholesky(20, 1.0 / float(gp.sigma) ** 2, dom, bdy, gp.nugget).build().factor(lookahead=False)
     torch.cuda.synchronize()
     assert torch.equal(plain.R, ch.R) and all(torch.equal(a, b) for a, b in zip(plain.diag, ch.diag))
+    # block columns one at a time (round 5's sequence) and in pairs (one K = 512 trailing update per pair, the default): the same factor to rounding,
+    # (9 block rows: four pairs and a last odd column)
+    single = DistCholesky(20, 1.0 / float(gp.sigma) ** 2, dom, bdy, gp.nugget).build().factor(pair=False)
+    torch.cuda.synchronize()
+    assert float((single.R - ch.R).abs().max()) <= 1e-13 * float(ch.R.abs().max())
+    del single, plain
     Lg = ch.gather_factor()
     assert float((Lg - L).abs().max()) <= 1e-12 * float(L.abs().max())
     b = torch.from_numpy(np.random.default_rng(0).standard_normal(ch.M)).cuda()

@@ -43,38 +43,39 @@ def worker(rank, world, port, args, q):
     probe = GP_Grad_Dependent_Nonlinear(eq, compat=compat)
     cm = Comm(force=force)
     # stage timings of the distributed factorisation alone
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    ch = DistCholesky(args.d, 1.0 / (0.25 ** 2 * args.d), dom, bdy, 1e-2, cm, compat_idx=probe.laplacian_idx).build()
-    torch.cuda.synchronize(); t1 = time.perf_counter()
-    say("Gram rows built")
-    ch.factor()
-    torch.cuda.synchronize(); t2 = time.perf_counter()
-    say("factored")
-    b = torch.from_numpy(np.random.default_rng(0).standard_normal(ch.M)).cuda()
-    ch.solve(b)                                            # the first solve also assembles and inverts the diagonal super-blocks (once per factor)
-    torch.cuda.synchronize(); t_first = time.perf_counter() - t2
-    torch.cuda.synchronize(); ta = time.perf_counter()
-    ch.solve(b)
-    torch.cuda.synchronize(); tb = time.perf_counter()
-    ch.matvec(b)                                           # (allocates the ordered sweep's scratch)
-    torch.cuda.synchronize(); tc = time.perf_counter()
-    ch.matvec(b)
-    torch.cuda.synchronize(); td = time.perf_counter()
-    t2, t3, t4 = t2, t2 + (tb - ta), t2 + (tb - ta) + (td - tc)
-    out["first_solve_s_incl_group_inverses"] = round(t_first, 3)
-    out.update(M=ch.M, block_rows=ch.nblk, panel_gb_per_rank=round(ch.memory_bytes() / 1e9, 2), gram_s=round(t1 - t0, 3),
-               factor_s=round(t2 - t1, 3), factor_tflops_all_ranks=round(ch.M ** 3 / 3 / (t2 - t1) / 1e12, 2),
-               solve_s=round(t3 - t2, 3), matvec_s=round(t4 - t3, 3), collective_gb_per_rank=round(cm.bytes_moved / 1e9, 2),
-               collective_calls=dict(cm.calls),
-               gram_pair_rows_per_s=round(sum(min(256, ch.M - i * 256) for i in ch.mine) * (args.n_dom + args.n_bdy) / (t1 - t0), 1))
-    del ch
-    torch.cuda.empty_cache()
-    if args.factor_only:
-        if rank == 0:
-            q.put(out)
-        dist.barrier()
-        dist.destroy_process_group()
-        return
+    if not args.fit_only:
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        ch = DistCholesky(args.d, 1.0 / (0.25 ** 2 * args.d), dom, bdy, 1e-2, cm, compat_idx=probe.laplacian_idx).build()
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        say("Gram rows built")
+        ch.factor()
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        say("factored")
+        b = torch.from_numpy(np.random.default_rng(0).standard_normal(ch.M)).cuda()
+        ch.solve(b)                                            # the first solve also assembles and inverts the diagonal super-blocks (once per factor)
+        torch.cuda.synchronize(); t_first = time.perf_counter() - t2
+        torch.cuda.synchronize(); ta = time.perf_counter()
+        ch.solve(b)
+        torch.cuda.synchronize(); tb = time.perf_counter()
+        ch.matvec(b)                                           # (allocates the ordered sweep's scratch)
+        torch.cuda.synchronize(); tc = time.perf_counter()
+        ch.matvec(b)
+        torch.cuda.synchronize(); td = time.perf_counter()
+        t2, t3, t4 = t2, t2 + (tb - ta), t2 + (tb - ta) + (td - tc)
+        out["first_solve_s_incl_group_inverses"] = round(t_first, 3)
+        out.update(M=ch.M, block_rows=ch.nblk, panel_gb_per_rank=round(ch.memory_bytes() / 1e9, 2), gram_s=round(t1 - t0, 3),
+                   factor_s=round(t2 - t1, 3), factor_tflops_all_ranks=round(ch.M ** 3 / 3 / (t2 - t1) / 1e12, 2),
+                   solve_s=round(t3 - t2, 3), matvec_s=round(t4 - t3, 3), collective_gb_per_rank=round(cm.bytes_moved / 1e9, 2),
+                   collective_calls=dict(cm.calls),
+                   gram_pair_rows_per_s=round(sum(min(256, ch.M - i * 256) for i in ch.mine) * (args.n_dom + args.n_bdy) / (t1 - t0), 1))
+        del ch
+        torch.cuda.empty_cache()
+        if args.factor_only:
+            if rank == 0:
+                q.put(out)
+            dist.barrier()
+            dist.destroy_process_group()
+            return
     gp = GP_Grad_Dependent_Nonlinear(eq, compat=compat)
     fit = DistributedGP(gp, Comm(force=force))
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -111,6 +112,8 @@ def main():
     ap.add_argument("--no-single", action="store_true")
     ap.add_argument("--adaptive-cg", action="store_true", help="inexact Newton: the inner CG tolerance follows the gradient norm (DistributedGP.fit(cg_tol='adaptive'))")
     ap.add_argument("--factor-only", action="store_true", help="Gram rows, factorisation, one solve and one matvec; no Newton fit")
+    ap.add_argument("--fit-only", action="store_true", help="skip the stage timings before the fit (sizes whose panel fills more than a third of the GPU: "
+                                                             "the caching allocator may still hold the first panel when the fit allocates its own)")
     ap.add_argument("--backend", choices=["gloo", "nccl"], default="gloo",
                     help="nccl = RCCL: needs one GPU per rank, so --ranks 1 on a one-GPU box (every collective is then forced through RCCL: Comm(force=True))")
     ap.add_argument("--compat", choices=["reference", "none"], default="reference",
@@ -129,7 +132,18 @@ def main():
     procs = [ctx.Process(target=worker, args=(r, args.ranks, port, args, q)) for r in range(args.ranks)]
     for p in procs:
         p.start()
-    print(json.dumps(q.get(timeout=3000)), flush=True)
+    import queue as _queue
+    result = None
+    while result is None:                                 # a worker that dies (out of memory, a failed collective) must not leave this process waiting
+        try:
+            result = q.get(timeout=5)
+        except _queue.Empty:
+            if any(p.exitcode not in (None, 0) for p in procs):
+                for p in procs:
+                    if p.is_alive():
+                        p.terminate()
+                raise SystemExit("a rank exited with an error before the result was reported")
+    print(json.dumps(result), flush=True)
     for p in procs:
         p.join()
 
