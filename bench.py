@@ -80,6 +80,7 @@ def parse():
                     help="stated cost of the one all-reduce in that prediction: bus bandwidth of RCCL's all-reduce at this message size (GB/s) ...")
     ap.add_argument("--allreduce-latency-us", type=float, default=40.0, help="... and its fixed latency; no multi-GPU node has measured either yet")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-fit", action="store_true", help="skip the oracle's own GP fit (cpu_baseline.fit: ~20 s of CPU at the reference's 1000 + 200 points)")
     ap.add_argument("--no-reference-logs-check", action="store_true", help="skip the d = 20 runs on the reference's own random stream (about a second)")
     ap.add_argument("--no-other-runs", action="store_true", help="skip the other_runs block (the other BASELINE configs and modes, 5 timed steps each)")
     ap.add_argument("--no-gp-train-large", action="store_true",
@@ -507,7 +508,26 @@ def cpu_baseline(args, wl, x_dom, x_bdy):
     except Exception:
         threads = os.cpu_count()
     diff = np.abs(uz_gpu - uz_cpu)
-    return {"value": round(ns * wl.steps_exec / t_cpu, 1), "unit": "path-steps/s", "cores": threads, "kind": "port",
+    fit = None
+    if gp is not None and not args.no_cpu_fit and 4 * len(x_dom) + len(x_bdy) <= 6000:
+        # the sample above runs on the device's right_vector (same trained surrogate on both sides); here the oracle FITS on its own -- Gram, factor,
+        # Newton (models/GP.py:182-268, 487-604 restated) -- and the two fits are compared: the training half of the path, timed and checked
+        ofit = OracleGPCompat(oeq, gp.laplacian_idx, round_factor=False) if gp.compat == "reference" else OracleGP(oeq)
+        t0 = time.perf_counter()
+        ofit.GPsolver(np.asarray(x_dom, dtype=np.float64), np.asarray(x_bdy, dtype=np.float64), GN_steps=20)
+        t_fit = time.perf_counter() - t0
+        rv_c, rv_g = np.asarray(ofit.right_vector, dtype=np.float64).ravel(), np.asarray(gp.right_vector, dtype=np.float64).ravel()
+        xs = np.asarray(wl.x_t[:1024], dtype=np.float64)
+        ex = oeq.exact_solution(xs)[:, 0]
+        fit = {"M": int(4 * len(x_dom) + len(x_bdy)), "cpu_s": round(t_fit, 2), "newton_steps_cpu": len(ofit.loss_history) - 1,
+               "newton_steps_gpu": len(gp.loss_history) - 1,
+               "right_vector_max_diff_over_max": float(np.abs(rv_c - rv_g).max() / np.abs(rv_c).max()),
+               "final_loss_rel_diff": float(abs(ofit.loss_history[-1] - gp.loss_history[-1]) / abs(ofit.loss_history[-1])),
+               "gp_rel_l2_cpu_fit": round(rel_l2(ofit.predict(xs)[:, 0], ex), 6),
+               "gp_rel_l2_gpu_fit": round(rel_l2(np.asarray(gp.predict(np.asarray(wl.x_t[:1024])), dtype=np.float64)[:, 0], ex), 6),
+               "note": "the oracle's own fit on the same training set (NumPy float64, eigh factor) against the device fit (gp_train[0].fit_s); predictions on "
+                       "the first 1024 roots"}
+    return {"value": round(ns * wl.steps_exec / t_cpu, 1), "unit": "path-steps/s", "cores": threads, "kind": "port", "fit": fit,
             "sample": "%d of the %d roots, same inputs and Philox streams, NumPy float64 oracle (oracle/mlp.py%s), %.1f s"
                       % (ns, B, (" + oracle/gp_compat.py" if gp.compat == "reference" else " + oracle/gp.py") if gp is not None else "", t_cpu),
             "rel_l2_gpu": round(rel_gpu, 6), "rel_l2_cpu": round(rel_cpu, 6), "abs_diff": round(abs(rel_gpu - rel_cpu), 7),

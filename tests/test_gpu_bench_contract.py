@@ -35,6 +35,10 @@ def test_bench_prints_one_contract_line(extra):
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["unit"] == "path-steps/s" and cpu["sample"]
     # north_star: L2 relative error within 1e-3 of the reference CPU path, on the same roots
     assert cpu["abs_diff"] <= 1e-3 and abs(cpu["rel_l2_gpu"] - cpu["rel_l2_cpu"]) <= 1e-3 and cpu["max_abs_diff_u"] < 1e-3
+    if "--solver" not in extra:                         # the oracle's OWN fit on the same training set beside the device fit (timed, compared)
+        fit = cpu["fit"]
+        assert fit["M"] == 4 * 96 + 32 and fit["cpu_s"] > 0 and fit["newton_steps_cpu"] == fit["newton_steps_gpu"]
+        assert fit["right_vector_max_diff_over_max"] <= 1e-6 and abs(fit["gp_rel_l2_cpu_fit"] - fit["gp_rel_l2_gpu_fit"]) <= 1e-3
     chk = j["reference_logs_check"]                     # the reference's own d = 20 experiment on its own random stream, against its logs
     assert chk["d"] == 20 and set(chk["rel_l2"]) == {"GP", "MLP", "ScaSML", "MLP_full_history"} and chk["max_relative_difference"] <= 6e-3
     assert abs(chk["rel_l2"]["MLP"] - chk["logged"]["MLP"]) <= 5e-4 * chk["logged"]["MLP"]
