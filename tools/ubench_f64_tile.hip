@@ -15,6 +15,8 @@
 #include <map>
 #include <vector>
 
+#include "../scasml_gp_amd/csrc/f64_tile_dma.hpp"
+
 constexpr int kNB = 32, kLDP = kNB + 2, WS = 4, TBX = 32 * WS, THREADS = 64 * WS * WS, PER = TBX * kNB / THREADS;
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int kStamps = 8;
@@ -254,6 +256,16 @@ __global__ __launch_bounds__(THREADS) void tile_dma_kernel(double *C, int64_t ld
 #endif
 }
 
+// variants 6, 7: the product's tile function itself (csrc/f64_tile_dma.hpp) at (32 columns, 2 stages) and (16, 4); no stamps
+template <int NB, int STAGES>
+__global__ __launch_bounds__(THREADS) void tile_hdr_kernel(double *C, int64_t ldc, int64_t n, const double *A, int64_t lda, const double *B, int64_t ldb,
+                                                           int64_t K, uint64_t *stamps) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int64_t nt = n / TBX, bid = blockIdx.x;
+    const int64_t r0 = (bid / nt) * TBX, c0 = (bid % nt) * TBX;
+    scasml::f64_tile_dma<NB, STAGES>(smem, A + r0 * lda, lda, TBX, B + c0 * ldb, ldb, TBX, K, C + r0 * ldc + c0, ldc);
+}
+
 __global__ void fill_kernel(double *p, int64_t n, uint32_t seed) {   // non-zero operands: the matrix cores draw less power on zeros
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         uint32_t h = (uint32_t)i * 2654435761u + seed;
@@ -283,8 +295,8 @@ static int run(int64_t n, int64_t K) {
     hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, A, n * K, 1u);
     hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, B, n * K, 2u);
     hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, C, n * n, 3u);
-    const size_t lds = V == 4 ? (size_t)kStages * kStageBytes : (size_t)2 * 2 * TBX * kLDP * 8;
-    auto kern = V == 4 ? tile_dma_kernel : tile_kernel<(V == 4 ? 0 : V)>;
+    const size_t lds = V >= 4 ? (size_t)kStages * kStageBytes : (size_t)2 * 2 * TBX * kLDP * 8;
+    auto kern = V == 4 ? tile_dma_kernel : V == 6 ? tile_hdr_kernel<32, 2> : V == 7 ? tile_hdr_kernel<16, 4> : tile_kernel<(V >= 4 ? 0 : V)>;
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
@@ -334,6 +346,7 @@ static int run(int64_t n, int64_t K) {
 
 
 // variant 4 against variant 0 from the same C: the two sum K in the same order, so the results must agree bit for bit
+template <int V>
 static int verify(int64_t n, int64_t K) {
     double *A, *B, *C0, *C4;
     uint64_t *st;
@@ -349,9 +362,10 @@ static int verify(int64_t n, int64_t K) {
     hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, C4, n * n, 3u);
     const size_t lds0 = (size_t)2 * 2 * TBX * kLDP * 8, lds4 = (size_t)kStages * kStageBytes;
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(tile_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0));
-    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(tile_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+    auto other = V == 6 ? tile_hdr_kernel<32, 2> : tile_dma_kernel;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(other), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
     hipLaunchKernelGGL(tile_kernel<0>, dim3((unsigned)tiles), dim3(THREADS), lds0, 0, C0, n, n, A, K, B, K, K, st);
-    hipLaunchKernelGGL(tile_dma_kernel, dim3((unsigned)tiles), dim3(THREADS), lds4, 0, C4, n, n, A, K, B, K, K, st);
+    hipLaunchKernelGGL(other, dim3((unsigned)tiles), dim3(THREADS), lds4, 0, C4, n, n, A, K, B, K, K, st);
     CHECK(hipDeviceSynchronize());
     std::vector<double> h0(n * n), h4(n * n);
     CHECK(hipMemcpy(h0.data(), C0, n * n * 8, hipMemcpyDeviceToHost));
@@ -365,7 +379,7 @@ static int verify(int64_t n, int64_t K) {
         const double a = h0[i] < 0 ? -h0[i] : h0[i];
         if (a > ref) ref = a;
     }
-    printf("verify n=%lld K=%lld: max |variant 4 - variant 0| = %.3e (max |C| %.3e), %lld of %lld elements differ\n", (long long)n, (long long)K, worst, ref,
+    printf("verify n=%lld K=%lld: max |variant 4 or 6 - variant 0| = %.3e (max |C| %.3e), %lld of %lld elements differ\n", (long long)n, (long long)K, worst, ref,
            (long long)differ, (long long)(n * n));
     return worst == 0 ? 0 : 3;
 }
@@ -380,7 +394,10 @@ int main(int argc, char **argv) {
         case 2: return run<2>(n, K);
         case 3: return run<3>(n, K);
         case 4: return run<4>(n, K);
-        case 5: return verify(n, K);
+        case 6: return run<6>(n, K);
+        case 7: return run<7>(n, K);
+        case 8: return verify<6>(n, K);
+        case 5: return verify<4>(n, K);
     }
     return 2;
 }
