@@ -251,7 +251,7 @@ extern "C" int scasml_gemm_nt_sub(double *C, int64_t ldc, int64_t rows, int64_t 
     const int tb = big ? 128 : 64;
     const int64_t gx = (cols + tb - 1) / tb, gy = (rows + tb - 1) / tb;
     if (gy > 65535) return fail(SCASML_ERR_UNSUPPORTED, "gemm_nt_sub: too many rows for one launch");
-    const bool dma = big && K >= 4 * kDmaNB && lda % 2 == 0 && ldb % 2 == 0 && ((uintptr_t)A | (uintptr_t)B) % 16 == 0 && lda < (1 << 21) && ldb < (1 << 21) &&
+    const bool dma = big && K >= kDmaStages * kDmaNB && lda % 2 == 0 && ldb % 2 == 0 && ((uintptr_t)A | (uintptr_t)B) % 16 == 0 && lda < (1 << 21) && ldb < (1 << 21) &&
                      ldc < (1 << 21) && !getenv("SCASML_F64_TILE_REGISTER_STAGED");   // (development: the register-staged tile for A/B runs)
     if (dma) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_sub_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDmaLdsBytes) != hipSuccess)

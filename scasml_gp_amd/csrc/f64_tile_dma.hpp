@@ -53,9 +53,13 @@ __device__ __forceinline__ void f64_rendezvous() {
 }
 
 // One tile.  At, Bt: first valid row of the tile's operand panels at K column 0 (16-byte aligned, lda / ldb even); rows_a / rows_b (1..128):
-// valid rows -- rows beyond them re-read the last valid row, their products land in output rows / columns that are never stored.
+// valid rows -- rows beyond them re-read the last valid row (pair of rows), their products land in output rows / columns that are never stored.
+// KMA / KMB: that operand is stored K-MAJOR, element (row, k) at P[k * ld + row] (the right-hand sides and the transposed factor of the
+// triangular-solve updates): its stage is [k][row] in LDS -- the DMA's 16 bytes are two adjacent ROWS of one k, one instruction per k --
+// with the granule (row pair) index XORed by (k & 1) << 3, so that the two k of a ds_read_b64 pass use different halves of the banks;
+// rows_a / rows_b must then be even.
 // K: a multiple of NB, >= STAGES * NB.  Ct: the tile's corner in C.  All arguments are workgroup-uniform.
-template <int NB = kDmaNB, int STAGES = kDmaStages>
+template <int NB = kDmaNB, int STAGES = kDmaStages, bool KMA = false, bool KMB = false>
 __device__ __forceinline__ void f64_tile_dma(double *smem, const double *At, int64_t lda, int rows_a, const double *Bt, int64_t ldb, int rows_b, int64_t K,
                                              double *Ct, int64_t ldc) {
     using S = DmaShape<NB, STAGES>;
@@ -66,31 +70,45 @@ __device__ __forceinline__ void f64_tile_dma(double *smem, const double *At, int
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
     const int wr = (wv >> 2) * 32, wc = (wv & 3) * 32;
     const int l15 = lane & 15, l4 = lane >> 4;
-    // DMA: wave w stages rows 8 w .. 8 w + 7 of either operand, kRowsPerInstr rows per instruction (32-bit byte offsets: rows < 128,
-    // leading dimensions < 2^21)
-    uint32_t offa[S::kInstrPerOperand], offb[S::kInstrPerOperand];
+    // DMA, row-major operand: wave w stages rows 8 w .. 8 w + 7, kRowsPerInstr rows per instruction; k-major operand: wave w stages the
+    // k-rows w * NB / 16 .. (one instruction = the 128 rows of one k).  32-bit byte offsets: rows < 128, k < NB, leading dimensions < 2^21.
+    constexpr int Q = S::kInstrPerOperand;
+    uint32_t offa[Q], offb[Q];
 #pragma unroll
-    for (int q = 0; q < S::kInstrPerOperand; ++q) {
-        const uint32_t drow = 8 * wvs + q * S::kRowsPerInstr + lane / S::kGranules, dgran = (lane % S::kGranules) ^ S::swz(drow);
-        const uint32_t ra = drow < (uint32_t)rows_a ? drow : (uint32_t)rows_a - 1u, rb = drow < (uint32_t)rows_b ? drow : (uint32_t)rows_b - 1u;
-        offa[q] = ra * ((uint32_t)lda * 8u) + dgran * 16u;
-        offb[q] = rb * ((uint32_t)ldb * 8u) + dgran * 16u;
+    for (int q = 0; q < Q; ++q) {
+        auto row_major = [&](int rows, int64_t ld) {
+            const uint32_t drow = 8 * wvs + q * S::kRowsPerInstr + lane / S::kGranules, dgran = (lane % S::kGranules) ^ S::swz(drow);
+            const uint32_t r = drow < (uint32_t)rows ? drow : (uint32_t)rows - 1u;
+            return r * ((uint32_t)ld * 8u) + dgran * 16u;
+        };
+        auto k_major = [&](int rows, int64_t ld) {
+            const uint32_t kq = Q * wvs + q, g = (uint32_t)lane ^ ((kq & 1u) << 3), last = (uint32_t)rows / 2u - 1u;
+            return kq * ((uint32_t)ld * 8u) + (g < last ? g : last) * 16u;
+        };
+        offa[q] = KMA ? k_major(rows_a, lda) : row_major(rows_a, lda);
+        offb[q] = KMB ? k_major(rows_b, ldb) : row_major(rows_b, ldb);
     }
     auto stage = [&](int64_t c) {   // chunk c -> slot c % STAGES
-        const uint32_t dst = lds_base + (uint32_t)(c % STAGES) * S::kStageBytes + (uint32_t)wvs * (8 * S::kRowBytes);
+        const uint32_t dst = lds_base + (uint32_t)(c % STAGES) * S::kStageBytes + (uint32_t)wvs * (Q * 1024);   // either layout: Q KB per wave and operand
+        const double *pa = KMA ? At + c * NB * lda : At + c * NB, *pb = KMB ? Bt + c * NB * ldb : Bt + c * NB;
 #pragma unroll
-        for (int q = 0; q < S::kInstrPerOperand; ++q) {
-            f64_glds16(At + c * NB, offa[q], dst + q * 1024);
-            f64_glds16(Bt + c * NB, offb[q], dst + S::kOpBytes + q * 1024);
+        for (int q = 0; q < Q; ++q) {
+            f64_glds16(pa, offa[q], dst + q * 1024);
+            f64_glds16(pb, offb[q], dst + S::kOpBytes + q * 1024);
         }
     };
-    // fragment reads: byte offsets inside a stage; the K step k0 enters by XOR (k0 * 8 flips the upper bits of the granule's slot)
+    // fragment reads: byte offsets inside a stage.  Row-major: the K step k0 enters by XOR (k0 * 8 flips the upper bits of the granule's slot);
+    // k-major: by addition (k0 KB further)
     uint32_t fa[2], fb[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const uint32_t r_a = wr + 16 * i + l15, r_b = wc + 16 * i + l15;
-        fa[i] = r_a * S::kRowBytes + ((((uint32_t)l4 >> 1) ^ S::swz(r_a)) * 16u) + ((uint32_t)l4 & 1) * 8u;
-        fb[i] = S::kOpBytes + r_b * S::kRowBytes + ((((uint32_t)l4 >> 1) ^ S::swz(r_b)) * 16u) + ((uint32_t)l4 & 1) * 8u;
+        auto frag = [&](bool km, uint32_t r) {
+            return km ? (uint32_t)l4 * 1024u + (((r >> 1) ^ (((uint32_t)l4 & 1u) << 3)) * 16u) + (r & 1u) * 8u
+                      : r * S::kRowBytes + ((((uint32_t)l4 >> 1) ^ S::swz(r)) * 16u) + ((uint32_t)l4 & 1) * 8u;
+        };
+        fa[i] = frag(KMA, r_a);
+        fb[i] = S::kOpBytes + frag(KMB, r_b);
     }
     dma_f64x4 acc[2][2], cin[2][2];
 #pragma unroll
@@ -104,9 +122,9 @@ __device__ __forceinline__ void f64_tile_dma(double *smem, const double *At, int
         for (int k0 = 0; k0 < NB; k0 += 4) {
             double av[2], bv[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const double *>(st + (fa[i] ^ (uint32_t)(k0 * 8)));
+            for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const double *>(st + (KMA ? fa[i] + (uint32_t)(k0 * 1024) : fa[i] ^ (uint32_t)(k0 * 8)));
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const double *>(st + (fb[j] ^ (uint32_t)(k0 * 8)));
+            for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const double *>(st + (KMB ? fb[j] + (uint32_t)(k0 * 1024) : fb[j] ^ (uint32_t)(k0 * 8)));
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll

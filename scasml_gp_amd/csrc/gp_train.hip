@@ -686,6 +686,21 @@ __global__ void zero_upper_kernel(double *A, int64_t M) {
 
 using namespace scasml;
 
+// The large substitution updates on the LDS-DMA tile (f64_tile_dma.hpp): the right-hand sides (and, in the transposed solve, the factor) are
+// k-major operands.  Results bit-identical to trsm_update_kernel<TRANS, 2, 4> (same summation order), which stays as the fallback.
+template <int TRANS>
+__global__ __launch_bounds__(kDmaThreads) void trsm_update_dma_kernel(const double *L, int64_t M, double *B, int64_t nrhs, int64_t J, int64_t K, int64_t rbase,
+                                                                      int64_t rend, int tri, int64_t ntc) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    int64_t ti, tj;
+    if (!super_tile_of_block(blockIdx.x, (rend - rbase + kDmaTile - 1) / kDmaTile, ntc, false, ti, tj)) return;
+    const int64_t r0 = rbase + ti * kDmaTile, c0 = tj * kDmaTile;
+    if (r0 >= rend || c0 >= nrhs || (tri && c0 >= r0 + kDmaTile)) return;   // block-uniform
+    const int ra = (int)(rend - r0 < kDmaTile ? rend - r0 : kDmaTile), rb = (int)(nrhs - c0 < kDmaTile ? nrhs - c0 : kDmaTile);
+    const double *At = TRANS == 0 ? L + r0 * M + J : L + J * M + r0;
+    f64_tile_dma<kDmaNB, kDmaStages, TRANS == 1, true>(smem, At, M, ra, B + J * nrhs + c0, nrhs, rb, K, B + r0 * nrhs + c0, nrhs);
+}
+
 // ---- launch helpers ------------------------------------------------------------------------------------------
 template <class Kern>
 static bool reserve_lds(Kern kern, size_t bytes) {
@@ -703,7 +718,7 @@ static void launch_chol_update_ws(double *A, int64_t M, int64_t J, int64_t K, in
     constexpr int TBX = 16 * NT * WS;
     const int64_t nti = (M - R0 + TBX - 1) / TBX, ntj = (col_end - R0 + TBX - 1) / TBX;
     if (nti <= 0 || ntj <= 0) return;
-    if (WS == 4 && K >= 4 * kDmaNB && (uintptr_t)A % 16 == 0 && M < (1 << 21) && !getenv("SCASML_F64_TILE_REGISTER_STAGED")) {   // (development knob: A/B runs)
+    if (WS == 4 && K >= kDmaStages * kDmaNB && (uintptr_t)A % 16 == 0 && M < (1 << 21) && !getenv("SCASML_F64_TILE_REGISTER_STAGED")) {   // (development knob: A/B runs)
         if (!reserve_lds(chol_update_dma_kernel, kDmaLdsBytes)) return;   // reported by check_launch through hipGetLastError
         hipLaunchKernelGGL(chol_update_dma_kernel, dim3(super_tile_grid(nti, nti, true)), dim3(kDmaThreads), kDmaLdsBytes, s, A, M, J, K, R0, col_end);
         return;
@@ -729,6 +744,13 @@ static void launch_trsm_update_ws(const double *L, int64_t M, double *B, int64_t
     constexpr int TBX = 16 * NT * WS;
     const int64_t ntr = (rend - rbase + TBX - 1) / TBX, ntc = (ncols + TBX - 1) / TBX;
     if (ntr <= 0 || ntc <= 0) return;
+    if (WS == 4 && K >= kDmaStages * kDmaNB && ((uintptr_t)L | (uintptr_t)B) % 16 == 0 && M % 2 == 0 && nrhs % 2 == 0 && (rend - rbase) % 2 == 0 &&
+        M < (1 << 21) && nrhs < (1 << 21) && !getenv("SCASML_F64_TILE_REGISTER_STAGED")) {
+        if (!reserve_lds(trsm_update_dma_kernel<TRANS>, kDmaLdsBytes)) return;
+        hipLaunchKernelGGL(trsm_update_dma_kernel<TRANS>, dim3(super_tile_grid(ntr, ntc, false)), dim3(kDmaThreads), kDmaLdsBytes, s, L, M, B, nrhs, J, K, rbase,
+                           rend, tri, ntc);
+        return;
+    }
     auto kern = trsm_update_kernel<TRANS, NT, WS>;
     constexpr size_t lds = tile_lds_bytes<NT, WS>();
     if (!reserve_lds(kern, lds)) return;

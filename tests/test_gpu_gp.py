@@ -115,11 +115,15 @@ def test_dma_staged_update_tile_equals_the_register_staged_tile_bit_for_bit(monk
         _lib.check(lib.scasml_cholesky(_lib.ptr(L), M, 0.0, _lib.ptr(info), s), "chol")
         Cm = C0.clone()
         _lib.check(lib.scasml_gemm_nt_sub(_lib.ptr(Cm), cols, rows, cols, _lib.ptr(Ap), K + 32, _lib.ptr(Bp), K + 32, K, 0, 0, 0, s), "gemm_nt_sub")
+        Ainv = torch.empty_like(L)      # the substitution updates: k-major operands (right-hand sides; the factor transposed in the backward sweep)
+        _lib.check(lib.scasml_cholesky_inverse(_lib.ptr(L), M, _lib.ptr(Ainv), s), "cholesky_inverse")
         torch.cuda.synchronize()
         assert int(info.item()) == 0
-        out[mode] = (L, Cm)
+        out[mode] = (L, Cm, Ainv)
     monkeypatch.delenv("SCASML_F64_TILE_REGISTER_STAGED")
-    assert torch.equal(out["dma"][0], out["registers"][0]) and torch.equal(out["dma"][1], out["registers"][1])
+    assert all(torch.equal(a, b) for a, b in zip(out["dma"], out["registers"]))
+    want_inv = torch.cholesky_inverse(torch.linalg.cholesky(A))
+    assert float((out["dma"][2] - want_inv).abs().max()) < 1e-9 * float(want_inv.abs().max())
     want = C0 - Ap[:, :K] @ Bp[:, :K].T
     assert float((out["dma"][1] - want).abs().max()) < 1e-11 * float(want.abs().max()) * K
     assert float((out["dma"][0] - torch.linalg.cholesky(A)).abs().max()) < 1e-10 * 40 * float(A.abs().max()) ** 0.5
