@@ -445,6 +445,14 @@ int scasml_gemv_sub(const double *A, int64_t lda, int64_t rows, int64_t cols, co
 int64_t scasml_gemv_t_ordered_scratch(int64_t rows, int64_t cols);
 int scasml_gemv_t_sub_ordered(const double *A, int64_t lda, int64_t rows, int64_t cols, const double *x, double *y, double *scratch,
                               int64_t scratch_elems, void *stream);
+/* The same two sweeps over the stacked block rows of a LOWER-TRIANGULAR factor (DistCholesky's panel: local row block lb is global block row
+ * tri_row0 + lb * tri_stride, blocks of SCASML_DIST_BLOCK rows; nothing is stored beyond a row's own diagonal block): the row sweep stops at the
+ * diagonal block, the transposed sweep starts at the first block row that reaches the column -- half the bytes of the full-width sweeps
+ * (K_p v = L (L^T v), models/GP.py:430-444 as used by the matrix-free Newton iteration).  The skipped entries are zeros: the same sums, added in a
+ * fixed order (bitwise reproducible between runs). */
+int scasml_gemv_sub_tri(const double *A, int64_t lda, int64_t rows, int64_t cols, const double *x, double *y, int64_t tri_row0, int64_t tri_stride, void *stream);
+int scasml_gemv_t_sub_ordered_tri(const double *A, int64_t lda, int64_t rows, int64_t cols, const double *x, double *y, double *scratch,
+                                  int64_t scratch_elems, int64_t tri_row0, int64_t tri_stride, void *stream);
 
 #ifdef __cplusplus
 }

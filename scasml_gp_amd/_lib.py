@@ -118,6 +118,9 @@ SIGNATURES = {
     "scasml_gemv_sub": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "scasml_gemv_t_ordered_scratch": (C.c_int64, [C.c_int64, C.c_int64]),
     "scasml_gemv_t_sub_ordered": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "scasml_gemv_sub_tri": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "scasml_gemv_t_sub_ordered_tri": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                                C.c_void_p]),
     "scasml_cholesky": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_void_p]),
     "scasml_cholesky_inverse": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "scasml_trsm_lower": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),

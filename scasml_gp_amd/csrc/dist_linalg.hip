@@ -175,10 +175,16 @@ __global__ __launch_bounds__(256) void trsm_right_lt32_kernel(const double *L, i
 }
 
 // ---------------------------------------------------------------------------------- y -= A x, y -= A^T x
-__global__ __launch_bounds__(256) void gemv_sub_kernel(const double *A, int64_t lda, int64_t rows, int64_t cols, const double *x, double *y) {
+// tri.stride > 0 (block-row panels of a lower-triangular factor, TriMap above with col0 unused): row block lb is global block row
+// tri.row0 + lb * tri.stride and holds nothing beyond its own diagonal block -- the sweep stops there instead of reading the zeros
+__global__ __launch_bounds__(256) void gemv_sub_kernel(const double *A, int64_t lda, int64_t rows, int64_t cols, const double *x, double *y, TriMap tri) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
+    if (tri.stride > 0) {
+        const int64_t lim = (tri.row0 + (row / SCASML_DIST_BLOCK) * tri.stride + 1) * SCASML_DIST_BLOCK;
+        cols = lim < cols ? lim : cols;
+    }
     double acc = 0.0;
     for (int64_t k = lane; k < cols; k += 64) acc = fma(A[row * lda + k], x[k], acc);
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
@@ -222,10 +228,15 @@ __global__ __launch_bounds__(256) void gemv_t_sub_kernel(const double *A, int64_
 // the same product with the row groups' partial sums written to a scratch buffer and added in FIXED order: bitwise reproducible between runs
 // (the atomic path's last bits depend on the order the row groups retire in)
 __global__ __launch_bounds__(256) void gemv_t_partial_kernel(const double *A, int64_t lda, int64_t rows, int64_t cols, const double *x, double *partial,
-                                                             int64_t rows_per_block) {
+                                                             int64_t rows_per_block, TriMap tri) {
     const int64_t c = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
-    const int64_t rb = (int64_t)blockIdx.y * rows_per_block;
+    int64_t rb = (int64_t)blockIdx.y * rows_per_block;
     const int64_t re = rb + rows_per_block < rows ? rb + rows_per_block : rows;
+    if (tri.stride > 0) {   // the 64 columns of this workgroup lie in ONE block column: the rows above its first block row hold zeros there (block-uniform)
+        const int64_t cb = (int64_t)blockIdx.x * 64 / SCASML_DIST_BLOCK;
+        const int64_t lb = cb <= tri.row0 ? 0 : (cb - tri.row0 + tri.stride - 1) / tri.stride;
+        rb = lb * SCASML_DIST_BLOCK > rb ? lb * SCASML_DIST_BLOCK : rb;
+    }
     const double acc = gemv_t_columns(A, lda, rb, re, c, c < cols, x);
     if (threadIdx.x < 64 && c < cols) partial[(int64_t)blockIdx.y * cols + c] = acc;
 }
@@ -302,8 +313,19 @@ extern "C" int64_t scasml_gemv_t_ordered_scratch(int64_t rows, int64_t cols) {
     return groups * cols;
 }
 
+static int gemv_t_sub_ordered(const double *A, int64_t lda, int64_t rows, int64_t cols, const double *x, double *y, double *scratch, int64_t scratch_elems,
+                              TriMap tri, void *stream);
 extern "C" int scasml_gemv_t_sub_ordered(const double *A, int64_t lda, int64_t rows, int64_t cols, const double *x, double *y, double *scratch,
                                          int64_t scratch_elems, void *stream) {
+    return gemv_t_sub_ordered(A, lda, rows, cols, x, y, scratch, scratch_elems, TriMap{0, 0, 0}, stream);
+}
+extern "C" int scasml_gemv_t_sub_ordered_tri(const double *A, int64_t lda, int64_t rows, int64_t cols, const double *x, double *y, double *scratch,
+                                             int64_t scratch_elems, int64_t tri_row0, int64_t tri_stride, void *stream) {
+    if (tri_row0 < 0 || tri_stride < 1) return fail(SCASML_ERR_ARG, "gemv_t_sub_ordered_tri: bad block map");
+    return gemv_t_sub_ordered(A, lda, rows, cols, x, y, scratch, scratch_elems, TriMap{tri_row0, tri_stride, 0}, stream);
+}
+static int gemv_t_sub_ordered(const double *A, int64_t lda, int64_t rows, int64_t cols, const double *x, double *y, double *scratch, int64_t scratch_elems,
+                              TriMap tri, void *stream) {
     if (!A || !x || !y || rows < 0 || cols < 0 || lda < cols) return fail(SCASML_ERR_ARG, "gemv_t_sub_ordered: bad argument");
     if (rows == 0 || cols == 0) return 0;
     const int64_t need = scasml_gemv_t_ordered_scratch(rows, cols);
@@ -311,9 +333,17 @@ extern "C" int scasml_gemv_t_sub_ordered(const double *A, int64_t lda, int64_t r
     const int64_t rpb = rows <= 64 * 64 ? 64 : (rows + 63) / 64;
     const int64_t groups = (rows + rpb - 1) / rpb;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(gemv_t_partial_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)groups), dim3(256), 0, s, A, lda, rows, cols, x, scratch, rpb);
+    hipLaunchKernelGGL(gemv_t_partial_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)groups), dim3(256), 0, s, A, lda, rows, cols, x, scratch, rpb, tri);
     hipLaunchKernelGGL(gemv_t_reduce_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, scratch, groups, cols, y);
     return check_launch("gemv_t_sub_ordered launch");
+}
+
+extern "C" int scasml_gemv_sub_tri(const double *A, int64_t lda, int64_t rows, int64_t cols, const double *x, double *y, int64_t tri_row0, int64_t tri_stride,
+                                   void *stream) {
+    if (!A || !x || !y || rows < 0 || cols < 0 || lda < cols || tri_row0 < 0 || tri_stride < 1) return fail(SCASML_ERR_ARG, "gemv_sub_tri: bad argument");
+    if (rows == 0 || cols == 0) return 0;
+    hipLaunchKernelGGL(gemv_sub_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, A, lda, rows, cols, x, y, TriMap{tri_row0, tri_stride, 0});
+    return check_launch("gemv_sub_tri launch");
 }
 
 extern "C" int scasml_gemv_sub(const double *A, int64_t lda, int64_t rows, int64_t cols, const double *x, double *y, int trans, void *stream) {
@@ -321,7 +351,7 @@ extern "C" int scasml_gemv_sub(const double *A, int64_t lda, int64_t rows, int64
     if (rows == 0 || cols == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     if (!trans) {
-        hipLaunchKernelGGL(gemv_sub_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, A, lda, rows, cols, x, y);
+        hipLaunchKernelGGL(gemv_sub_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, A, lda, rows, cols, x, y, TriMap{0, 0, 0});
     } else {
         const int64_t rpb = rows <= 1024 ? rows : 64;     // up to 1024 rows (a group of four block rows of the distributed substitutions): one writer per column
         const int64_t gy = (rows + rpb - 1) / rpb;

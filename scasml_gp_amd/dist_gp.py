@@ -427,9 +427,10 @@ class DistCholesky:
         return x[:self.M].clone()
 
     def matvec(self, v):
-        """K_p v = L (L^T v) for a replicated v (length M): TWO sweeps over the rank's whole stacked panel (its strict upper part is zero after
-        factor(), so the full width can be swept: twice the bytes of the triangle, one launch instead of one per block row) and two collectives
-        of Mp doubles.  The transposed sweep adds its row groups' partial sums in fixed order (scasml_gemv_t_sub_ordered): bitwise reproducible."""
+        """K_p v = L (L^T v) for a replicated v (length M): TWO sweeps over the rank's stacked panel, one launch each, and two collectives of Mp
+        doubles.  The sweeps know the block map (scasml_gemv_sub_tri / scasml_gemv_t_sub_ordered_tri): a block row is read up to its diagonal
+        block only -- the triangle's bytes, not the full width's (round 6; before, the zeros of the strict upper part were swept too: twice the
+        bytes).  The transposed sweep adds its row groups' partial sums in fixed order: bitwise reproducible."""
         torch = _lib.require_gpu()
         lib, s, cm = self.lib, _lib.stream_ptr(), self.comm
         R, Mp = self.R, self.Mp
@@ -441,13 +442,13 @@ class DistCholesky:
             need = int(lib.scasml_gemv_t_ordered_scratch(rows, Mp))
             if self._scratch is None or self._scratch.numel() < need:
                 self._scratch = torch.empty(need, dtype=torch.float64, device="cuda")
-            _lib.check(lib.scasml_gemv_t_sub_ordered(_lib.ptr(R), Mp, rows, Mp, _lib.ptr(self._local_rows(vp)), _lib.ptr(acc), _lib.ptr(self._scratch),
-                                                     self._scratch.numel(), s), "gemv_t_sub_ordered")
+            _lib.check(lib.scasml_gemv_t_sub_ordered_tri(_lib.ptr(R), Mp, rows, Mp, _lib.ptr(self._local_rows(vp)), _lib.ptr(acc), _lib.ptr(self._scratch),
+                                                         self._scratch.numel(), self.mine[0], cm.world, s), "gemv_t_sub_ordered_tri")
         cm.all_reduce(acc)
         out = torch.zeros(Mp, dtype=torch.float64, device="cuda")
         if rows:
             loc = torch.zeros(rows, dtype=torch.float64, device="cuda")    # u_i = -L_i acc = L_i (L^T v), this rank's rows
-            _lib.check(lib.scasml_gemv_sub(_lib.ptr(R), Mp, rows, Mp, _lib.ptr(acc), _lib.ptr(loc), 0, s), "gemv_sub")
+            _lib.check(lib.scasml_gemv_sub_tri(_lib.ptr(R), Mp, rows, Mp, _lib.ptr(acc), _lib.ptr(loc), self.mine[0], cm.world, s), "gemv_sub_tri")
             out.view(self.nblk, BLK)[self._mine_idx()] = loc.view(-1, BLK)
         cm.all_reduce(out)
         return out[:self.M].clone()
