@@ -273,7 +273,8 @@ def test_bench_chooses_the_sample_ranks_by_predicted_efficiency():
 
 @pytest.fixture(scope="module")
 def kernel_regs_reports():
-    """tools/kernel_regs.py (device-only compile to ISA text, ~50 s per file) for the two evaluation kernels, run side by side once per module."""
+    """tools/kernel_regs.py (device-only compile to ISA text, ~50 s per file) for the evaluation kernels and the FP64 linear algebra, run side by
+    side once per module."""
     import subprocess, sys, os
     from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -283,8 +284,8 @@ def kernel_regs_reports():
 
     def run(name):
         return subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_regs.py"), name], capture_output=True, text=True, check=True).stdout
-    files = ["gp_eval_bf16.hip", "gp_eval_compat_mfma.hip"]
-    with ThreadPoolExecutor(max_workers=2) as ex:
+    files = ["gp_eval_bf16.hip", "gp_eval_compat_mfma.hip", "gp_train.hip", "dist_linalg.hip"]
+    with ThreadPoolExecutor(max_workers=4) as ex:
         return dict(zip(files, ex.map(run, files)))
 
 
@@ -324,6 +325,22 @@ def test_launch_bounds_of_the_as_coded_evaluation_kernel_hold_without_scratch(ke
         assert vgpr <= 512 // bpc, line                      # 512 VGPRs per SIMD lane, one 256-thread workgroup = one wave per SIMD
         assert scratch == 0 if r16 else scratch <= 32, line
     assert seen == 3 * 16                                     # KS = 1..16 (d <= 252) x {as coded, geometry with 1 plane, geometry with 2}
+
+
+def test_fp64_dma_tiles_fit_a_1024_thread_workgroup_without_scratch(kernel_regs_reports):
+    """The 128 x 128 FP64 update tile with LDS-DMA operand staging (csrc/f64_tile_dma.hpp) runs as ONE 1024-thread workgroup per CU, four waves per
+    SIMD: 128 VGPRs per wave at most, and its counted `s_waitcnt vmcnt(N)` hand-over assumes that nothing else -- no spill, no reload -- issues
+    vector-memory operations inside the stage loop (a round-6 draft that streamed several tiles per workgroup spilled with `vmcnt(0)` waits in the
+    middle of the output tile's loads).  Pinned from the code objects for the three kernels built on it."""
+    import re
+    want = {"gp_train.hip": ["chol_update_dma_kernel", "trsm_update_dma_kernel<0>", "trsm_update_dma_kernel<1>"], "dist_linalg.hip": ["gemm_nt_sub_dma_kernel"]}
+    for f, names in want.items():
+        out = kernel_regs_reports[f]
+        for name in names:
+            lines = [l for l in out.splitlines() if name in l]
+            assert len(lines) == 1, (name, lines)
+            m = re.search(r"scratch\s+(\d+)\s+vgpr\s+(\d+)", lines[0])
+            assert m and int(m.group(1)) == 0 and int(m.group(2)) <= 128 and "!!" not in lines[0], lines[0]
 
 
 def test_root_bound_is_cached_for_the_callers_tensor_only():
